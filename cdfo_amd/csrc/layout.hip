@@ -1,0 +1,48 @@
+// NCHW <-> pixel-major (NHWC) transposes at the module boundary.  The reference's tensors are NCHW
+// (arch/SIDECVSR_our.py:4409); everything inside the HIP path is pixel-major so that a pixel's channels are
+// one contiguous 256-byte run.  LDS-tiled 32x32 transpose, coalesced on both sides.
+#include "common.h"
+
+namespace {
+
+// in: [B][R][Cc] with row pitch ldi  ->  out: [B][Cc][R] with row pitch ldo   (generic 2-D transpose per batch)
+__global__ void transpose2d(const float* __restrict__ in, long long in_bstride, int ldi, float* __restrict__ out,
+                            long long out_bstride, int ldo, int R, int Cc) {
+  __shared__ float tile[32][33];
+  const int b = blockIdx.z;
+  const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+  const float* ip = in + b * in_bstride;
+  float* op = out + b * out_bstride;
+  for (int k = ty; k < 32; k += 8) {
+    const int r = r0 + k, c = c0 + tx;
+    tile[k][tx] = (r < R && c < Cc) ? ip[(long long)r * ldi + c] : 0.f;
+  }
+  __syncthreads();
+  for (int k = ty; k < 32; k += 8) {
+    const int c = c0 + k, r = r0 + tx;
+    if (c < Cc && r < R) op[(long long)c * ldo + r] = tile[tx][k];
+  }
+}
+
+}  // namespace
+
+extern "C" int cdfo_nchw_to_nhwc(const float* in, float* out, int B, int C, int H, int W, int ldo, void* stream) {
+  if (B <= 0 || C <= 0 || H <= 0 || W <= 0 || ldo < C) return CDFO_EINVAL;
+  const int P = H * W;
+  dim3 grid(cdiv(P, 32), cdiv(C, 32), B);  // in rows = channels (R=C), cols = pixels (Cc=P)
+  hipLaunchKernelGGL(transpose2d, grid, dim3(256), 0, static_cast<hipStream_t>(stream), in, (long long)C * P, P, out,
+                     (long long)P * ldo, ldo, C, P);
+  CDFO_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int cdfo_nhwc_to_nchw(const float* in, int ldi, float* out, int B, int C, int H, int W, void* stream) {
+  if (B <= 0 || C <= 0 || H <= 0 || W <= 0 || ldi < C) return CDFO_EINVAL;
+  const int P = H * W;
+  dim3 grid(cdiv(C, 32), cdiv(P, 32), B);  // in rows = pixels (R=P), cols = channels (Cc=C)
+  hipLaunchKernelGGL(transpose2d, grid, dim3(256), 0, static_cast<hipStream_t>(stream), in, (long long)P * ldi, ldi, out,
+                     (long long)C * P, P, P, C);
+  CDFO_LAUNCH_CHECK();
+  return 0;
+}

@@ -19,7 +19,7 @@ class CdfoError(RuntimeError):
 
 class ConvArgs(C.Structure):
     _fields_ = [
-        ("src", C.c_void_p * 3), ("ld", C.c_int * 3), ("cs", C.c_int * 3), ("nsrc", C.c_int),
+        ("src", C.c_void_p * 8), ("ld", C.c_int * 8), ("cs", C.c_int * 8), ("nsrc", C.c_int),
         ("B", C.c_int), ("H", C.c_int), ("W", C.c_int), ("Ho", C.c_int), ("Wo", C.c_int),
         ("ks", C.c_int), ("stride", C.c_int), ("pad", C.c_int),
         ("Cin", C.c_int), ("Cout", C.c_int), ("CoutP", C.c_int),
@@ -40,8 +40,40 @@ def lib() -> C.CDLL:
                 f"{LIB_PATH} is missing: the HIP extension has not been built "
                 "(run `python -m cdfo_amd.build`).  There is no CPU fallback for the product path.")
         _lib = C.CDLL(LIB_PATH)
-        _lib.cdfo_build_info.restype = C.c_char_p
+        for name, (restype, argtypes) in header_prototypes().items():
+            fn = getattr(_lib, name)          # AttributeError here = header/library mismatch: fail loudly
+            fn.restype = restype
+            fn.argtypes = argtypes
     return _lib
+
+
+HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "cdfo_hip.h")
+
+
+def header_prototypes(path: str = HEADER_PATH):
+    """Parse include/cdfo_hip.h -> {symbol: (restype, [argtypes])}; the header is the single source of truth."""
+    import re
+    text = open(path).read()
+    text = re.sub(r"/\*.*?\*/", " ", text, flags=re.S)
+    protos = {}
+    for m in re.finditer(r"(const char\*|int)\s+(cdfo_[a-z0-9_]+)\s*\(([^)]*)\)\s*;", text):
+        ret, name, args = m.group(1), m.group(2), m.group(3).strip()
+        at = []
+        if args and args != "void":
+            for a in args.split(","):
+                a = " ".join(a.split())
+                if "*" in a:
+                    at.append(C.c_void_p)
+                elif a.startswith("long long"):
+                    at.append(C.c_longlong)
+                elif a.startswith("float"):
+                    at.append(C.c_float)
+                elif a.startswith("int"):
+                    at.append(C.c_int)
+                else:
+                    raise CdfoError(f"cannot map C type in prototype of {name}: {a!r}")
+        protos[name] = (C.c_char_p if ret.startswith("const char") else C.c_int, at)
+    return protos
 
 
 def check(status: int, what: str) -> None:

@@ -1,0 +1,251 @@
+// Prior-fusion attention `LLongRangAttention` (arch/SIDECVSR_our.py:2179-2249): residual-driven hard mask, row /
+// column long-range attention and 8x8 window attention -- without ever writing a WxW / HxH / 64x64 score map to HBM.
+//
+//   rdab_prep   : Gumbel-softmax hard mask (arch.py:2168-2195) from the injected uniform noise; q,v split of the
+//                 128-channel input_conv output; sparse_q = conv1x9_over_channels(mask*q), v' = conv1x9(v)
+//                 (directW1_conv, arch.py:2216-2219); window query (1-mask)*q (arch.py:2235-2238).
+//   colconv9    : directH1_conv, the 9-tap conv along H on sparse_q (arch.py:2225).
+//   seq_attn    : softmax(Q Q^T) V over a row, a column or an 8x8 window, one query per lane, keys streamed through
+//                 wave-uniform (scalar) loads, online softmax in registers.
+#include "common.h"
+
+namespace {
+
+constexpr int ZS = 65;  // LDS pitch for the [pixel][channel] logits (conflict-free both ways)
+constexpr int QS = 72;  // 4 zero floats on both sides of the 64 channels for the 9-tap channel conv
+
+__global__ __launch_bounds__(256) void rdab_prep_kernel(const float* __restrict__ xq, int ldx,  // [.,128]: q | v
+                                                        const float* __restrict__ vmax,         // [B][64]
+                                                        const float* __restrict__ noise,        // [B][64][P] (NCHW)
+                                                        const float* __restrict__ wW, const float* __restrict__ bW,
+                                                        long long P, float* __restrict__ sq, int lds_,
+                                                        float* __restrict__ vrow, int ldv, float* __restrict__ qwin,
+                                                        int ldw) {
+  __shared__ float z[64 * ZS];
+  __shared__ float mq[64 * QS];
+  __shared__ float vv[64 * QS];
+  const int tid = threadIdx.x;
+  const long long p0 = (long long)blockIdx.x * 64;  // P % 64 == 0, so the 64 pixels share one image
+  const long long b = p0 / P, pin = p0 - b * P;
+  // phase 1: logits z[i][c] = vmax[c] - log(-log(u))   (coalesced along pixels)
+  {
+    const int i = tid & 63;
+    for (int c = tid >> 6; c < 64; c += 4) {
+      const float u = noise[(b * 64 + c) * P + pin + i];
+      z[i * ZS + c] = vmax[b * 64 + c] + (-logf(-logf(u)));
+    }
+  }
+  for (int i = tid; i < 64 * QS; i += 256) { mq[i] = 0.f; vv[i] = 0.f; }
+  __syncthreads();
+  // phase 2: hard mask = softmax_c(z) >= 0.5 ; 4 lanes per pixel, 16 channels each
+  const int i = tid >> 2, part = tid & 3;
+  {
+    float m = -INFINITY;
+#pragma unroll
+    for (int c = 0; c < 16; ++c) m = fmaxf(m, z[i * ZS + part * 16 + c]);
+    m = fmaxf(m, __shfl_xor(m, 1, 64));
+    m = fmaxf(m, __shfl_xor(m, 2, 64));
+    float e[16], s = 0.f;
+#pragma unroll
+    for (int c = 0; c < 16; ++c) { e[c] = expf(z[i * ZS + part * 16 + c] - m); s += e[c]; }
+    s += __shfl_xor(s, 1, 64);
+    s += __shfl_xor(s, 2, 64);
+    const float* px = xq + (p0 + i) * ldx + part * 16;
+    float* pw = qwin + (p0 + i) * ldw + part * 16;
+#pragma unroll
+    for (int c4 = 0; c4 < 4; ++c4) {
+      const f32x4 q4 = *reinterpret_cast<const f32x4*>(px + c4 * 4);
+      const f32x4 v4 = *reinterpret_cast<const f32x4*>(px + 64 + c4 * 4);
+      f32x4 w4;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float mk = (e[c4 * 4 + k] / s >= 0.5f) ? 1.f : 0.f;
+        mq[i * QS + 4 + part * 16 + c4 * 4 + k] = mk * q4[k];
+        vv[i * QS + 4 + part * 16 + c4 * 4 + k] = v4[k];
+        w4[k] = (1.f - mk) * q4[k];
+      }
+      *reinterpret_cast<f32x4*>(pw + c4 * 4) = w4;
+    }
+  }
+  __syncthreads();
+  // phase 3: 9-tap cross-correlation along the channel axis (zero padded), + bias
+  {
+    float w9[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) w9[t] = wW[t];
+    const float bb = bW[0];
+    float* ps = sq + (p0 + i) * lds_ + part * 16;
+    float* pv = vrow + (p0 + i) * ldv + part * 16;
+#pragma unroll
+    for (int c4 = 0; c4 < 4; ++c4) {
+      f32x4 a, bq;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int c = part * 16 + c4 * 4 + k;
+        float s1 = bb, s2 = bb;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+          s1 += w9[t] * mq[i * QS + c + t];
+          s2 += w9[t] * vv[i * QS + c + t];
+        }
+        a[k] = s1;
+        bq[k] = s2;
+      }
+      *reinterpret_cast<f32x4*>(ps + c4 * 4) = a;
+      *reinterpret_cast<f32x4*>(pv + c4 * 4) = bq;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void colconv9_kernel(const float* __restrict__ in, int ldi,
+                                                       const float* __restrict__ wH, const float* __restrict__ bH,
+                                                       int B, int H, int W, float* __restrict__ out, int ldo) {
+  float w9[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) w9[t] = wH[t];
+  const float bb = bH[0];
+  const long long total = (long long)B * H * W * 16;
+  for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total;
+       idx += (long long)gridDim.x * blockDim.x) {
+    const int cg = idx & 15;
+    const long long p = idx >> 4;
+    const int x = p % W;
+    const int y = (p / W) % H;
+    const long long b = p / ((long long)W * H);
+    f32x4 acc = {bb, bb, bb, bb};
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      const int yy = y + t - 4;
+      if (yy < 0 || yy >= H) continue;
+      acc += w9[t] * *reinterpret_cast<const f32x4*>(in + ((b * H + yy) * W + x) * ldi + cg * 4);
+    }
+    *reinterpret_cast<f32x4*>(out + p * ldo + cg * 4) = acc;
+  }
+}
+
+// MODE 0: sequence = image row (keys along W); 1: image column (keys along H); 2: 8x8 window.
+template <int MODE>
+__global__ __launch_bounds__(64) void seq_attn_kernel(const float* __restrict__ q, int ldq, const float* __restrict__ v,
+                                                      int ldv, float* __restrict__ out, int ldo, int B, int H, int W) {
+  const int lane = threadIdx.x;
+  long long kbase;      // pixel index of key 0
+  long long kstep;      // pixel stride between consecutive keys (MODE 0/1)
+  int L;                // number of keys
+  long long qpix;       // this lane's query pixel
+  bool active = true;
+  if (MODE == 0) {
+    const int nb = (W + 63) / 64;
+    const int blk = blockIdx.x % nb;
+    const long long row = blockIdx.x / nb;  // b*H + h
+    kbase = row * W; kstep = 1; L = W;
+    int x = blk * 64 + lane;
+    if (x >= W) { x = W - 1; active = false; }
+    qpix = kbase + x;
+  } else if (MODE == 1) {
+    const int nb = (H + 63) / 64;
+    const int blk = blockIdx.x % nb;
+    const long long col = blockIdx.x / nb;  // b*W + w
+    const long long b = col / W, w = col - b * W;
+    kbase = b * H * W + w; kstep = W; L = H;
+    int y = blk * 64 + lane;
+    if (y >= H) { y = H - 1; active = false; }
+    qpix = kbase + (long long)y * W;
+  } else {
+    const int nwx = W >> 3, nwy = H >> 3;
+    const int wx = blockIdx.x % nwx, wy = (blockIdx.x / nwx) % nwy;
+    const long long b = blockIdx.x / (nwx * nwy);
+    kbase = (b * H + wy * 8) * W + wx * 8; kstep = 0; L = 64;
+    qpix = kbase + (long long)(lane >> 3) * W + (lane & 7);
+  }
+  float qr[64], o[64];
+#pragma unroll
+  for (int c4 = 0; c4 < 16; ++c4) {
+    const f32x4 t = *reinterpret_cast<const f32x4*>(q + qpix * ldq + c4 * 4);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { qr[c4 * 4 + e] = t[e]; o[c4 * 4 + e] = 0.f; }
+  }
+  float m = -INFINITY, l = 0.f;
+  for (int j = 0; j < L; ++j) {
+    const long long kp = (MODE == 2) ? kbase + (long long)(j >> 3) * W + (j & 7) : kbase + (long long)j * kstep;
+    const float* __restrict__ kr = q + kp * ldq;  // wave-uniform address -> scalar loads
+    const float* __restrict__ vr = v + kp * ldv;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+#pragma unroll
+    for (int c = 0; c < 64; c += 4) {
+      s0 = fmaf(qr[c], kr[c], s0);
+      s1 = fmaf(qr[c + 1], kr[c + 1], s1);
+      s2 = fmaf(qr[c + 2], kr[c + 2], s2);
+      s3 = fmaf(qr[c + 3], kr[c + 3], s3);
+    }
+    const float s = (s0 + s1) + (s2 + s3);
+    if (s > m) {  // new running max: rescale what has been accumulated so far
+      const float alpha = expf(m - s);
+      l *= alpha;
+#pragma unroll
+      for (int c = 0; c < 64; ++c) o[c] *= alpha;
+      m = s;
+    }
+    const float pj = expf(s - m);
+    l += pj;
+#pragma unroll
+    for (int c = 0; c < 64; ++c) o[c] = fmaf(pj, vr[c], o[c]);
+  }
+  if (active) {
+    const float inv = 1.f / l;
+    float* po = out + qpix * ldo;
+#pragma unroll
+    for (int c4 = 0; c4 < 16; ++c4) {
+      f32x4 t;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) t[e] = o[c4 * 4 + e] * inv;
+      *reinterpret_cast<f32x4*>(po + c4 * 4) = t;
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int cdfo_rdab_prep(const float* xq, int ldx, const float* vmax, const float* noise, const float* wW,
+                              const float* bW, int B, long long P, float* sq, int lds_, float* vrow, int ldv, float* qwin,
+                              int ldw, void* stream) {
+  if (B <= 0 || P <= 0 || P % 64 || ldx % 4 || lds_ % 4 || ldv % 4 || ldw % 4) return CDFO_EINVAL;
+  if (!aligned16(xq) || !aligned16(sq) || !aligned16(vrow) || !aligned16(qwin)) return CDFO_EALIGN;
+  hipLaunchKernelGGL(rdab_prep_kernel, dim3((unsigned)(B * P / 64)), dim3(256), 0, static_cast<hipStream_t>(stream), xq,
+                     ldx, vmax, noise, wW, bW, P, sq, lds_, vrow, ldv, qwin, ldw);
+  CDFO_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int cdfo_colconv9(const float* in, int ldi, const float* wH, const float* bH, int B, int H, int W, float* out,
+                             int ldo, void* stream) {
+  if (B <= 0 || ldi % 4 || ldo % 4) return CDFO_EINVAL;
+  if (!aligned16(in) || !aligned16(out)) return CDFO_EALIGN;
+  long long blocks = ((long long)B * H * W * 16 + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(colconv9_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), in, ldi, wH,
+                     bH, B, H, W, out, ldo);
+  CDFO_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int cdfo_seq_attn(const float* q, int ldq, const float* v, int ldv, float* out, int ldo, int B, int H, int W,
+                             int mode, void* stream) {
+  if (B <= 0 || H <= 0 || W <= 0 || ldq % 4 || ldv % 4 || ldo % 4) return CDFO_EINVAL;
+  if (!aligned16(q) || !aligned16(v) || !aligned16(out)) return CDFO_EALIGN;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (mode == 0) {
+    hipLaunchKernelGGL(seq_attn_kernel<0>, dim3((unsigned)((long long)B * H * cdiv(W, 64))), dim3(64), 0, st, q, ldq, v,
+                       ldv, out, ldo, B, H, W);
+  } else if (mode == 1) {
+    hipLaunchKernelGGL(seq_attn_kernel<1>, dim3((unsigned)((long long)B * W * cdiv(H, 64))), dim3(64), 0, st, q, ldq, v,
+                       ldv, out, ldo, B, H, W);
+  } else if (mode == 2) {
+    if ((H & 7) || (W & 7)) return CDFO_EINVAL;
+    hipLaunchKernelGGL(seq_attn_kernel<2>, dim3((unsigned)((long long)B * (H / 8) * (W / 8))), dim3(64), 0, st, q, ldq, v,
+                       ldv, out, ldo, B, H, W);
+  } else {
+    return CDFO_EINVAL;
+  }
+  CDFO_LAUNCH_CHECK();
+  return 0;
+}

@@ -186,7 +186,7 @@ int launch(const cdfo_conv_args& a, hipStream_t st) {
 extern "C" int cdfo_conv_igemm(const cdfo_conv_args* pa, void* stream) {
   const cdfo_conv_args& a = *pa;
   hipStream_t st = static_cast<hipStream_t>(stream);
-  if (a.nsrc < 1 || a.nsrc > 3 || a.B <= 0 || a.H <= 0 || a.W <= 0) return CDFO_EINVAL;
+  if (a.nsrc < 1 || a.nsrc > CDFO_MAXSRC || a.B <= 0 || a.H <= 0 || a.W <= 0) return CDFO_EINVAL;
   int csum = 0;
   for (int s = 0; s < a.nsrc; ++s) {
     if (a.cs[s] <= 0 || a.cs[s] % KC || a.ld[s] % 4 || a.ld[s] < a.cs[s]) return CDFO_EINVAL;

@@ -25,6 +25,18 @@ __global__ void transpose2d(const float* __restrict__ in, long long in_bstride, 
   }
 }
 
+
+__global__ void swap_outer_kernel(const f32x4* __restrict__ in, f32x4* __restrict__ out, int B, int N, long long blk4) {
+  const long long total = (long long)B * N * blk4;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const long long e = i % blk4;
+    const long long bn = i / blk4;
+    const int n = bn % N, b = bn / N;
+    out[((long long)n * B + b) * blk4 + e] = in[i];
+  }
+}
+
 }  // namespace
 
 extern "C" int cdfo_nchw_to_nhwc(const float* in, float* out, int B, int C, int H, int W, int ldo, void* stream) {
@@ -43,6 +55,17 @@ extern "C" int cdfo_nhwc_to_nchw(const float* in, int ldi, float* out, int B, in
   dim3 grid(cdiv(C, 32), cdiv(P, 32), B);  // in rows = pixels (R=P), cols = channels (Cc=C)
   hipLaunchKernelGGL(transpose2d, grid, dim3(256), 0, static_cast<hipStream_t>(stream), in, (long long)P * ldi, ldi, out,
                      (long long)C * P, P, P, C);
+  CDFO_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int cdfo_swap_outer(const float* in, float* out, int B, int N, long long block, void* stream) {
+  if (B <= 0 || N <= 0 || block <= 0 || block % 4) return CDFO_EINVAL;
+  if (!aligned16(in) || !aligned16(out)) return CDFO_EALIGN;
+  long long blocks = ((long long)B * N * (block / 4) + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(swap_outer_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     reinterpret_cast<const f32x4*>(in), reinterpret_cast<f32x4*>(out), B, N, block / 4);
   CDFO_LAUNCH_CHECK();
   return 0;
 }

@@ -1,0 +1,361 @@
+// HBM-bound pixel-major kernels of the CVSR_V8 path: prior/pixel stems, LayerNorm, depthwise 3x3, motion-vector
+// warp, 2x2 mean / bilinear x2 resampling, channel gating, the final 64->1 conv fused with the bilinear x4 skip.
+// One pixel's 64 channels are a contiguous 256-B run, so 16 consecutive lanes (a float4 each) cover a pixel and
+// every wave-instruction moves 4 whole pixels = 1 KiB, fully coalesced.
+#include "common.h"
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------------------
+// 3x3 conv, 1 input channel -> 64 output channels (+bias, +act) [+ second output = result + add]
+// replaces conv_first / conv_second / conv_expand_ufs / conv_expand_rms (arch/SIDECVSR_our.py:4379-4384,4417-4418,
+// 4446-4449 incl. `fea_com = fea_i + rms_prior`).
+__global__ __launch_bounds__(256) void stem_conv_kernel(const float* __restrict__ img, long long img_bstride,
+                                                        const float* __restrict__ w, const float* __restrict__ bias,
+                                                        int B, int H, int W, int act, float* __restrict__ out, int ldo,
+                                                        const float* __restrict__ add, int lda, float* __restrict__ out2,
+                                                        int ldo2) {
+  const int cg = threadIdx.x & 15;  // channel group: couts 4cg..4cg+3
+  float wr[9][4], br[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    br[j] = bias ? bias[cg * 4 + j] : 0.f;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) wr[t][j] = w[(cg * 4 + j) * 9 + t];
+  }
+  const long long npix = (long long)B * H * W;
+  for (long long p = (blockIdx.x * (long long)blockDim.x + threadIdx.x) >> 4; p < npix;
+       p += ((long long)gridDim.x * blockDim.x) >> 4) {
+    const int x = p % W;
+    const int y = (p / W) % H;
+    const int b = p / ((long long)W * H);
+    const float* ip = img + b * img_bstride;
+    float v[9];
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+      for (int dx = 0; dx < 3; ++dx) {
+        const int yy = y + dy - 1, xx = x + dx - 1;
+        v[dy * 3 + dx] = (yy >= 0 && yy < H && xx >= 0 && xx < W) ? ip[(long long)yy * W + xx] : 0.f;
+      }
+    f32x4 o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float s = br[j];
+#pragma unroll
+      for (int t = 0; t < 9; ++t) s += v[t] * wr[t][j];
+      o[j] = act_apply(s, act);
+    }
+    *reinterpret_cast<f32x4*>(out + p * ldo + cg * 4) = o;
+    if (out2) {
+      const f32x4 ad = *reinterpret_cast<const f32x4*>(add + p * lda + cg * 4);
+      *reinterpret_cast<f32x4*>(out2 + p * ldo2 + cg * 4) = o + ad;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// per-pixel LayerNorm over 64 channels, biased variance, eps 1e-5 (arch.py:1169-1185)
+__global__ __launch_bounds__(256) void layernorm64_kernel(const float* __restrict__ in, int ldi,
+                                                          const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta, long long npix,
+                                                          float* __restrict__ out, int ldo) {
+  const int cg = threadIdx.x & 15;
+  const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + cg * 4);
+  const f32x4 be = *reinterpret_cast<const f32x4*>(beta + cg * 4);
+  for (long long p = (blockIdx.x * (long long)blockDim.x + threadIdx.x) >> 4; p < npix;
+       p += ((long long)gridDim.x * blockDim.x) >> 4) {
+    const f32x4 v = *reinterpret_cast<const f32x4*>(in + p * ldi + cg * 4);
+    float s = (v[0] + v[1]) + (v[2] + v[3]);
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    const float mu = s * (1.f / 64.f);
+    const f32x4 d = v - mu;
+    float q = (d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3]);
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) q += __shfl_xor(q, o, 64);
+    const float rstd = 1.f / sqrtf(q * (1.f / 64.f) + 1e-5f);
+    *reinterpret_cast<f32x4*>(out + p * ldo + cg * 4) = d * rstd * g + be;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// depthwise 3x3, pad 1, no bias (qkv_dwconv, arch.py:1552,1559). weights raw [C][1][3][3]; C % 4 == 0, C <= 256
+__global__ __launch_bounds__(256) void dwconv3x3_kernel(const float* __restrict__ in, int ldi,
+                                                        const float* __restrict__ w, int B, int H, int W, int C,
+                                                        float* __restrict__ out, int ldo) {
+  __shared__ float sw[9 * 256];
+  for (int i = threadIdx.x; i < C * 9; i += blockDim.x) sw[(i % 9) * C + i / 9] = w[i];
+  __syncthreads();
+  const int cgs = C >> 2;
+  const long long total = (long long)B * H * W * cgs;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int cg = i % cgs;
+    const long long p = i / cgs;
+    const int x = p % W;
+    const int y = (p / W) % H;
+    const long long b = p / ((long long)W * H);
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy) {
+      const int yy = y + dy - 1;
+      if (yy < 0 || yy >= H) continue;
+#pragma unroll
+      for (int dx = 0; dx < 3; ++dx) {
+        const int xx = x + dx - 1;
+        if (xx < 0 || xx >= W) continue;
+        const f32x4 v = *reinterpret_cast<const f32x4*>(in + ((b * H + yy) * W + xx) * ldi + cg * 4);
+        const f32x4 ww = *reinterpret_cast<const f32x4*>(sw + (dy * 3 + dx) * C + cg * 4);
+        acc += v * ww;
+      }
+    }
+    *reinterpret_cast<f32x4*>(out + p * ldo + cg * 4) = acc;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// flow_warp (arch.py:3068-3099): bilinear sample at (x + mv_x, y + mv_y), zeros outside, align_corners=True
+// with the same normalise / un-normalise arithmetic as F.grid_sample.  mv: [B][2][H][W] planes.
+__global__ __launch_bounds__(256) void flow_warp_kernel(const float* __restrict__ in, int ldi,
+                                                        const float* __restrict__ mv, long long mv_bstride, int B,
+                                                        int H, int W, int C, float* __restrict__ out, int ldo) {
+  const int cgs = C >> 2;
+  const long long total = (long long)B * H * W * cgs;
+  const float wm = (float)(W - 1 > 1 ? W - 1 : 1), hm = (float)(H - 1 > 1 ? H - 1 : 1);
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int cg = i % cgs;
+    const long long p = i / cgs;
+    const int x = p % W;
+    const int y = (p / W) % H;
+    const long long b = p / ((long long)W * H);
+    const float* m = mv + b * mv_bstride;
+    const float fx = m[(long long)y * W + x], fy = m[(long long)(H + y) * W + x];
+    const float nx = 2.0f * ((float)x + fx) / wm - 1.0f;
+    const float ny = 2.0f * ((float)y + fy) / hm - 1.0f;
+    const float sx = ((nx + 1.f) / 2.f) * (float)(W - 1);
+    const float sy = ((ny + 1.f) / 2.f) * (float)(H - 1);
+    const float x0f = floorf(sx), y0f = floorf(sy);
+    const int x0 = (int)x0f, y0 = (int)y0f;
+    const float tx = sx - x0f, ty = sy - y0f;
+    const float w00 = (1.f - tx) * (1.f - ty), w01 = tx * (1.f - ty), w10 = (1.f - tx) * ty, w11 = tx * ty;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    const float* base = in + b * H * W * ldi + cg * 4;
+    const bool xa = x0 >= 0 && x0 < W, xb = x0 + 1 >= 0 && x0 + 1 < W;
+    if (y0 >= 0 && y0 < H) {
+      if (xa) acc += *reinterpret_cast<const f32x4*>(base + ((long long)y0 * W + x0) * ldi) * w00;
+      if (xb) acc += *reinterpret_cast<const f32x4*>(base + ((long long)y0 * W + x0 + 1) * ldi) * w01;
+    }
+    if (y0 + 1 >= 0 && y0 + 1 < H) {
+      if (xa) acc += *reinterpret_cast<const f32x4*>(base + ((long long)(y0 + 1) * W + x0) * ldi) * w10;
+      if (xb) acc += *reinterpret_cast<const f32x4*>(base + ((long long)(y0 + 1) * W + x0 + 1) * ldi) * w11;
+    }
+    *reinterpret_cast<f32x4*>(out + p * ldo + cg * 4) = acc;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// bilinear x0.5 (== 2x2 mean for even sizes) and x2, align_corners=False (Interpolate, arch.py:324-333)
+__global__ __launch_bounds__(256) void down2_kernel(const float* __restrict__ in, int ldi, int B, int H, int W, int C,
+                                                    float* __restrict__ out, int ldo, int accumulate) {
+  const int Ho = H >> 1, Wo = W >> 1, cgs = C >> 2;
+  const long long total = (long long)B * Ho * Wo * cgs;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int cg = i % cgs;
+    const long long p = i / cgs;
+    const int x = p % Wo;
+    const int y = (p / Wo) % Ho;
+    const long long b = p / ((long long)Wo * Ho);
+    const float* s = in + ((b * H + 2 * y) * W + 2 * x) * ldi + cg * 4;
+    const f32x4 a0 = *reinterpret_cast<const f32x4*>(s), a1 = *reinterpret_cast<const f32x4*>(s + ldi);
+    const f32x4 b0 = *reinterpret_cast<const f32x4*>(s + (long long)W * ldi);
+    const f32x4 b1 = *reinterpret_cast<const f32x4*>(s + (long long)W * ldi + ldi);
+    f32x4 v = 0.5f * (0.5f * a0 + 0.5f * a1) + 0.5f * (0.5f * b0 + 0.5f * b1);
+    float* o = out + p * ldo + cg * 4;
+    if (accumulate) v += *reinterpret_cast<const f32x4*>(o);
+    *reinterpret_cast<f32x4*>(o) = v;
+  }
+}
+
+__global__ __launch_bounds__(256) void up2_kernel(const float* __restrict__ in, int ldi, int B, int H, int W, int C,
+                                                  float* __restrict__ out, int ldo, int accumulate) {
+  const int Ho = H * 2, Wo = W * 2, cgs = C >> 2;
+  const long long total = (long long)B * Ho * Wo * cgs;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int cg = i % cgs;
+    const long long p = i / cgs;
+    const int x = p % Wo;
+    const int y = (p / Wo) % Ho;
+    const long long b = p / ((long long)Wo * Ho);
+    // src = (dst + 0.5) * 0.5 - 0.5, clamped at 0
+    float sy = ((float)y + 0.5f) * 0.5f - 0.5f, sx = ((float)x + 0.5f) * 0.5f - 0.5f;
+    sy = sy < 0.f ? 0.f : sy;
+    sx = sx < 0.f ? 0.f : sx;
+    const int y0 = (int)sy, x0 = (int)sx;
+    const int y1 = y0 + (y0 < H - 1 ? 1 : 0), x1 = x0 + (x0 < W - 1 ? 1 : 0);
+    const float ly = sy - (float)y0, lx = sx - (float)x0;
+    const float* base = in + b * H * W * ldi + cg * 4;
+    const f32x4 v00 = *reinterpret_cast<const f32x4*>(base + ((long long)y0 * W + x0) * ldi);
+    const f32x4 v01 = *reinterpret_cast<const f32x4*>(base + ((long long)y0 * W + x1) * ldi);
+    const f32x4 v10 = *reinterpret_cast<const f32x4*>(base + ((long long)y1 * W + x0) * ldi);
+    const f32x4 v11 = *reinterpret_cast<const f32x4*>(base + ((long long)y1 * W + x1) * ldi);
+    f32x4 v = (1.f - ly) * ((1.f - lx) * v00 + lx * v01) + ly * ((1.f - lx) * v10 + lx * v11);
+    float* o = out + p * ldo + cg * 4;
+    if (accumulate) v += *reinterpret_cast<const f32x4*>(o);
+    *reinterpret_cast<f32x4*>(o) = v;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// out = x * gate[b][c]   (CALayer, arch.py:2041-2043)
+__global__ __launch_bounds__(256) void scale_channels_kernel(const float* __restrict__ in, int ldi,
+                                                             const float* __restrict__ gate, int B, long long P, int C,
+                                                             float* __restrict__ out, int ldo) {
+  const int cgs = C >> 2;
+  const long long total = (long long)B * P * cgs;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int cg = i % cgs;
+    const long long p = i / cgs;
+    const long long b = p / P;
+    const f32x4 g = *reinterpret_cast<const f32x4*>(gate + b * C + cg * 4);
+    *reinterpret_cast<f32x4*>(out + p * ldo + cg * 4) = *reinterpret_cast<const f32x4*>(in + p * ldi + cg * 4) * g;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// conv_last (3x3, 64 -> 1, +bias) fused with `out += bilinear_x4(x_center)` (arch.py:4476-4480).
+// 16 lanes per HR pixel (a float4 of channels each), 9 taps, then a 16-lane shuffle reduction.
+__global__ __launch_bounds__(256) void conv_last_kernel(const float* __restrict__ in, int ldi,
+                                                        const float* __restrict__ w, const float* __restrict__ bias,
+                                                        const float* __restrict__ xc, long long xc_bstride, int B,
+                                                        int Hh, int Wh, float* __restrict__ out) {
+  const int cg = threadIdx.x & 15;
+  f32x4 wr[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) wr[t][j] = w[(cg * 4 + j) * 9 + t];
+  const float b0 = bias[0];
+  const int H = Hh >> 2, W = Wh >> 2;
+  const long long npix = (long long)B * Hh * Wh;
+  for (long long p = (blockIdx.x * (long long)blockDim.x + threadIdx.x) >> 4; p < npix;
+       p += ((long long)gridDim.x * blockDim.x) >> 4) {
+    const int x = p % Wh;
+    const int y = (p / Wh) % Hh;
+    const long long b = p / ((long long)Wh * Hh);
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy) {
+      const int yy = y + dy - 1;
+      if (yy < 0 || yy >= Hh) continue;
+#pragma unroll
+      for (int dx = 0; dx < 3; ++dx) {
+        const int xx = x + dx - 1;
+        if (xx < 0 || xx >= Wh) continue;
+        acc += *reinterpret_cast<const f32x4*>(in + ((b * Hh + yy) * Wh + xx) * ldi + cg * 4) * wr[dy * 3 + dx];
+      }
+    }
+    float s = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    if (cg == 0) {
+      float sy = ((float)y + 0.5f) * 0.25f - 0.5f, sx = ((float)x + 0.5f) * 0.25f - 0.5f;
+      sy = sy < 0.f ? 0.f : sy;
+      sx = sx < 0.f ? 0.f : sx;
+      const int y0 = (int)sy, x0 = (int)sx;
+      const int y1 = y0 + (y0 < H - 1 ? 1 : 0), x1 = x0 + (x0 < W - 1 ? 1 : 0);
+      const float ly = sy - (float)y0, lx = sx - (float)x0;
+      const float* c = xc + b * xc_bstride;
+      const float base = (1.f - ly) * ((1.f - lx) * c[(long long)y0 * W + x0] + lx * c[(long long)y0 * W + x1]) +
+                         ly * ((1.f - lx) * c[(long long)y1 * W + x0] + lx * c[(long long)y1 * W + x1]);
+      out[p] = (s + b0) + base;
+    }
+  }
+}
+
+inline int grid_for(long long threads) {
+  long long blocks = (threads + 255) / 256;
+  return (int)(blocks < 1 ? 1 : (blocks > 8192 ? 8192 : blocks));
+}
+
+}  // namespace
+
+extern "C" int cdfo_stem_conv(const float* img, long long img_bstride, const float* w, const float* bias, int B, int H,
+                              int W, int act, float* out, int ldo, const float* add, int lda, float* out2, int ldo2,
+                              void* stream) {
+  if (B <= 0 || H <= 0 || W <= 0 || ldo % 4 || (out2 && (!add || lda % 4 || ldo2 % 4))) return CDFO_EINVAL;
+  if (!aligned16(out) || (out2 && (!aligned16(out2) || !aligned16(add)))) return CDFO_EALIGN;
+  hipLaunchKernelGGL(stem_conv_kernel, dim3(grid_for((long long)B * H * W * 16)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), img, img_bstride, w, bias, B, H, W, act, out, ldo, add, lda, out2,
+                     ldo2);
+  CDFO_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int cdfo_layernorm64(const float* in, int ldi, const float* gamma, const float* beta, long long npix,
+                                float* out, int ldo, void* stream) {
+  if (npix <= 0 || ldi % 4 || ldo % 4) return CDFO_EINVAL;
+  if (!aligned16(in) || !aligned16(out) || !aligned16(gamma) || !aligned16(beta)) return CDFO_EALIGN;
+  hipLaunchKernelGGL(layernorm64_kernel, dim3(grid_for(npix * 16)), dim3(256), 0, static_cast<hipStream_t>(stream), in,
+                     ldi, gamma, beta, npix, out, ldo);
+  CDFO_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int cdfo_dwconv3x3(const float* in, int ldi, const float* w, int B, int H, int W, int C, float* out, int ldo,
+                              void* stream) {
+  if (B <= 0 || C % 4 || C > 256 || ldi % 4 || ldo % 4) return CDFO_EINVAL;
+  if (!aligned16(in) || !aligned16(out)) return CDFO_EALIGN;
+  hipLaunchKernelGGL(dwconv3x3_kernel, dim3(grid_for((long long)B * H * W * (C / 4))), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), in, ldi, w, B, H, W, C, out, ldo);
+  CDFO_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int cdfo_flow_warp(const float* in, int ldi, const float* mv, long long mv_bstride, int B, int H, int W, int C,
+                              float* out, int ldo, void* stream) {
+  if (B <= 0 || C % 4 || ldi % 4 || ldo % 4) return CDFO_EINVAL;
+  if (!aligned16(in) || !aligned16(out)) return CDFO_EALIGN;
+  hipLaunchKernelGGL(flow_warp_kernel, dim3(grid_for((long long)B * H * W * (C / 4))), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), in, ldi, mv, mv_bstride, B, H, W, C, out, ldo);
+  CDFO_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int cdfo_resample2(const float* in, int ldi, int B, int H, int W, int C, float* out, int ldo, int up,
+                              int accumulate, void* stream) {
+  if (B <= 0 || C % 4 || ldi % 4 || ldo % 4 || (!up && ((H | W) & 1))) return CDFO_EINVAL;
+  if (!aligned16(in) || !aligned16(out)) return CDFO_EALIGN;
+  if (up)
+    hipLaunchKernelGGL(up2_kernel, dim3(grid_for((long long)B * H * W * C)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), in, ldi, B, H, W, C, out, ldo, accumulate);
+  else
+    hipLaunchKernelGGL(down2_kernel, dim3(grid_for((long long)B * H * W * C / 16)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), in, ldi, B, H, W, C, out, ldo, accumulate);
+  CDFO_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int cdfo_scale_channels(const float* in, int ldi, const float* gate, int B, long long P, int C, float* out,
+                                   int ldo, void* stream) {
+  if (B <= 0 || C % 4 || ldi % 4 || ldo % 4) return CDFO_EINVAL;
+  if (!aligned16(in) || !aligned16(out) || !aligned16(gate)) return CDFO_EALIGN;
+  hipLaunchKernelGGL(scale_channels_kernel, dim3(grid_for((long long)B * P * (C / 4))), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), in, ldi, gate, B, P, C, out, ldo);
+  CDFO_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int cdfo_conv_last(const float* in, int ldi, const float* w, const float* bias, const float* xc,
+                              long long xc_bstride, int B, int Hh, int Wh, float* out, void* stream) {
+  if (B <= 0 || (Hh & 3) || (Wh & 3) || ldi % 4) return CDFO_EINVAL;
+  if (!aligned16(in)) return CDFO_EALIGN;
+  hipLaunchKernelGGL(conv_last_kernel, dim3(grid_for((long long)B * Hh * Wh * 16)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), in, ldi, w, bias, xc, xc_bstride, B, Hh, Wh, out);
+  CDFO_LAUNCH_CHECK();
+  return 0;
+}

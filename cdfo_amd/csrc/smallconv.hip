@@ -1,0 +1,153 @@
+// Direct (VALU) convolutions for the thin 16-channel layers of the prior U-net `side_to_feaoneUDSA_2`
+// (arch/SIDECVSR_our.py:1815-1834): 3x3 stride-2 pad-2 convs, the two stride-2 transposed convs, and the
+// SpatialAttention gate (arch.py:2719-2730, ChannelPool 1883-1885).  They run at 1/4 and 1/16 of the LR pixel
+// count and carry < 0.1 % of the FLOPs, so they stay off the matrix cores.
+#include "common.h"
+
+namespace {
+
+// thread = (output pixel, 4 output channels); weights staged in LDS as [tap][cin][cout]
+template <int CIN, int COUT, bool TRANSPOSED>
+__global__ __launch_bounds__(256) void small_conv3x3_kernel(const float* __restrict__ in, int ldi,
+                                                            const float* __restrict__ w,
+                                                            const float* __restrict__ bias, int B, int H, int W, int Ho,
+                                                            int Wo, int stride, int pad, int act,
+                                                            float* __restrict__ out, int ldo) {
+  __shared__ __attribute__((aligned(16))) float sw[9 * CIN * COUT];
+  for (int i = threadIdx.x; i < 9 * CIN * COUT; i += blockDim.x) {
+    const int co = i % COUT, ci = (i / COUT) % CIN, t = i / (COUT * CIN);
+    // Conv2d weight is [co][ci][t]; ConvTranspose2d weight is [ci][co][t]
+    sw[i] = TRANSPOSED ? w[(ci * COUT + co) * 9 + t] : w[(co * CIN + ci) * 9 + t];
+  }
+  __syncthreads();
+  constexpr int CGS = COUT / 4;
+  const long long total = (long long)B * Ho * Wo * CGS;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int cg = i % CGS;
+    const long long p = i / CGS;
+    const int ox = p % Wo;
+    const int oy = (p / Wo) % Ho;
+    const long long b = p / ((long long)Wo * Ho);
+    f32x4 acc = bias ? *reinterpret_cast<const f32x4*>(bias + cg * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+      int iy;
+      if (TRANSPOSED) {  // oy = iy*stride - pad + ky
+        const int num = oy + pad - ky;
+        if (num < 0 || num % stride) continue;
+        iy = num / stride;
+      } else {
+        iy = oy * stride - pad + ky;
+      }
+      if (iy < 0 || iy >= H) continue;
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) {
+        int ix;
+        if (TRANSPOSED) {
+          const int num = ox + pad - kx;
+          if (num < 0 || num % stride) continue;
+          ix = num / stride;
+        } else {
+          ix = ox * stride - pad + kx;
+        }
+        if (ix < 0 || ix >= W) continue;
+        const float* ip = in + ((b * H + iy) * W + ix) * ldi;
+        const float* wp = sw + (ky * 3 + kx) * CIN * COUT + cg * 4;
+#pragma unroll
+        for (int c4 = 0; c4 < CIN / 4; ++c4) {
+          const f32x4 v = *reinterpret_cast<const f32x4*>(ip + c4 * 4);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc += v[e] * *reinterpret_cast<const f32x4*>(wp + (c4 * 4 + e) * COUT);
+        }
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) acc[e] = act_apply(acc[e], act);
+    *reinterpret_cast<f32x4*>(out + p * ldo + cg * 4) = acc;
+  }
+}
+
+// SpatialAttention on a 16-channel map: x * sigmoid(conv7x7([max_c x, mean_c x]) + b)
+__global__ __launch_bounds__(256) void spatial_gate16_kernel(const float* __restrict__ in, int ldi,
+                                                             const float* __restrict__ w,
+                                                             const float* __restrict__ bias, int B, int H, int W,
+                                                             float* __restrict__ out, int ldo) {
+  __shared__ float sw[98];
+  if (threadIdx.x < 98) sw[threadIdx.x] = w[threadIdx.x];  // [1][2][7][7]: plane 0 = max, plane 1 = mean
+  __syncthreads();
+  const long long npix = (long long)B * H * W;
+  for (long long p = blockIdx.x * (long long)blockDim.x + threadIdx.x; p < npix;
+       p += (long long)gridDim.x * blockDim.x) {
+    const int x = p % W;
+    const int y = (p / W) % H;
+    const long long b = p / ((long long)W * H);
+    float s = bias[0];
+    for (int dy = 0; dy < 7; ++dy) {
+      const int yy = y + dy - 3;
+      if (yy < 0 || yy >= H) continue;
+      for (int dx = 0; dx < 7; ++dx) {
+        const int xx = x + dx - 3;
+        if (xx < 0 || xx >= W) continue;
+        const float* q = in + ((b * H + yy) * W + xx) * ldi;
+        float mx = -INFINITY, sm = 0.f;
+#pragma unroll
+        for (int c4 = 0; c4 < 4; ++c4) {
+          const f32x4 v = *reinterpret_cast<const f32x4*>(q + c4 * 4);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { mx = fmaxf(mx, v[e]); sm += v[e]; }
+        }
+        s += mx * sw[dy * 7 + dx] + (sm * (1.f / 16.f)) * sw[49 + dy * 7 + dx];
+      }
+    }
+    const float g = 1.f / (1.f + expf(-s));
+    const float* q = in + p * ldi;
+    float* o = out + p * ldo;
+#pragma unroll
+    for (int c4 = 0; c4 < 4; ++c4)
+      *reinterpret_cast<f32x4*>(o + c4 * 4) = *reinterpret_cast<const f32x4*>(q + c4 * 4) * g;
+  }
+}
+
+inline int grid_for(long long threads) {
+  long long blocks = (threads + 255) / 256;
+  return (int)(blocks < 1 ? 1 : (blocks > 8192 ? 8192 : blocks));
+}
+
+}  // namespace
+
+extern "C" int cdfo_small_conv16(const float* in, int ldi, const float* w, const float* bias, int B, int H, int W,
+                                 int stride, int pad, int out_pad, int transposed, int act, float* out, int ldo,
+                                 void* stream) {
+  if (B <= 0 || ldi % 4 || ldo % 4 || stride < 1) return CDFO_EINVAL;
+  if (!aligned16(in) || !aligned16(out) || (bias && !aligned16(bias))) return CDFO_EALIGN;
+  int Ho, Wo;
+  if (transposed) {
+    Ho = (H - 1) * stride - 2 * pad + 3 + out_pad;
+    Wo = (W - 1) * stride - 2 * pad + 3 + out_pad;
+  } else {
+    Ho = (H + 2 * pad - 3) / stride + 1;
+    Wo = (W + 2 * pad - 3) / stride + 1;
+  }
+  if (Ho <= 0 || Wo <= 0) return CDFO_EINVAL;
+  const int grid = grid_for((long long)B * Ho * Wo * 4);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (transposed)
+    hipLaunchKernelGGL((small_conv3x3_kernel<16, 16, true>), dim3(grid), dim3(256), 0, st, in, ldi, w, bias, B, H, W, Ho,
+                       Wo, stride, pad, act, out, ldo);
+  else
+    hipLaunchKernelGGL((small_conv3x3_kernel<16, 16, false>), dim3(grid), dim3(256), 0, st, in, ldi, w, bias, B, H, W, Ho,
+                       Wo, stride, pad, act, out, ldo);
+  CDFO_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int cdfo_spatial_gate16(const float* in, int ldi, const float* w, const float* bias, int B, int H, int W,
+                                   float* out, int ldo, void* stream) {
+  if (B <= 0 || ldi % 4 || ldo % 4) return CDFO_EINVAL;
+  if (!aligned16(in) || !aligned16(out)) return CDFO_EALIGN;
+  hipLaunchKernelGGL(spatial_gate16_kernel, dim3(grid_for((long long)B * H * W)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), in, ldi, w, bias, B, H, W, out, ldo);
+  CDFO_LAUNCH_CHECK();
+  return 0;
+}

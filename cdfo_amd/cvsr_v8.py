@@ -1,0 +1,355 @@
+"""``CVSR_V8`` -- the reference's seven-frame x4 VSR model (arch/SIDECVSR_our.py:4371-4481) with the forward pass
+running entirely in hand-written gfx950 kernels (libcdfo_hip.so, C-ABI in include/cdfo_hip.h).
+
+Drop-in boundary B1: same class name, constructor signature, ``forward(x, mvs0, mvs1, pms, rms,
+ufs, pre_L1_fea=None) -> (out, L1_fea)`` and the same 261 ``state_dict`` entries (names + shapes), so a published
+``.pth`` loads with ``load_state_dict(strict=True)``.
+
+Differences, all deliberate:
+  * forward needs CUDA (ROCm) tensors and ``torch.no_grad()``/``eval`` use: there is NO CPU or autograd fallback --
+    it raises ``NotImplementedError`` like the reference's own CUDA-only operator does (ops/dcn/deform_conv.py:136).
+  * ``gumbel_uniform=`` (kwarg or attribute): the six uniform draws of ``LLongRangAttention.gumbel_softmax``
+    (arch.py:2169) may be injected as six ``[B,64,H,W]`` tensors; default is to draw them with ``torch.rand`` like
+    the reference.
+  * the debug side effects of the reference forward (``featuremap_visual`` PNG dumps, arch.py:4450-4475) are absent.
+  * ``L1_fea`` is returned as a ``[B*7,64,H,W]`` tensor in channels-last memory format (a view of the kernels'
+    pixel-major buffer); feeding it back as ``pre_L1_fea`` needs no conversion.  Plain NCHW tensors are accepted too.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Optional, Sequence
+
+import torch
+import torch.nn as nn
+
+from . import kernels as K
+
+NF, NFRAMES = 64, 7
+
+
+# ------------------------------------------------------------------------------------------------ parameters
+def _param_spec():
+    """(key, shape, fan_in, init) of the reference's state_dict (arch.py:4379-4398 and the sub-modules it builds)."""
+    sp = []
+
+    def conv(key, co, ci, kh, kw=None, bias=True, init="default"):
+        kw = kw or kh
+        sp.append((key + ".weight", (co, ci, kh, kw), ci * kh * kw, init))
+        if bias:
+            sp.append((key + ".bias", (co,), ci * kh * kw, "zero" if init == "kaiming0.1" else "bias"))
+
+    conv("conv_first", 64, 1, 3)
+    conv("conv_second", 64, 1, 3)
+    p = "transformer_feature_extraction.path1."
+    for n in ("norm1", "norm2"):
+        sp.append((p + n + ".body.weight", (64,), None, "ones"))
+        sp.append((p + n + ".body.bias", (64,), None, "zero"))
+    sp.append((p + "attn.temperature", (8, 1, 1), None, "ones"))
+    conv(p + "attn.qkv", 192, 64, 1, bias=False)
+    conv(p + "attn.qkv_dwconv", 192, 1, 3, bias=False)
+    conv(p + "attn.project_out", 64, 64, 1, bias=False)
+    conv(p + "conv", 64, 64, 3)
+    u = p + "side_to_feaoneUDSA.body."
+    conv(u + "0", 16, 64, 3)
+    conv(u + "2", 16, 16, 3)
+    conv(u + "4", 16, 16, 3)
+    conv(u + "6.spatial", 1, 2, 7)
+    conv(u + "7", 16, 16, 3)
+    conv(u + "9", 16, 16, 3)
+    conv(u + "11", 64, 16, 3)
+    conv("conv_expand_fea_r", 64, 128, 3)
+    conv("conv_expand_ufs", 64, 1, 3)
+    conv("conv_expand_rms", 64, 1, 3)
+    conv("tsa_fusion", 64, 448, 1)
+    for g in range(7):
+        gp = f"recon_trunk.body.{g}."
+        conv(gp + "conv", 64, 64, 3)
+        for b in range(3):
+            bp = gp + f"body.{b}."
+            conv(bp + "body.0", 256, 64, 3, init="kaiming0.1")
+            conv(bp + "body.2", 64, 256, 3, init="kaiming0.1")
+            conv(bp + "down.0", 64, 64, 1, init="kaiming0.1")
+            conv(bp + "up.0", 64, 64, 1, init="kaiming0.1")
+    conv("upconv1", 256, 64, 1)
+    conv("upconv2", 256, 64, 1)
+    conv("conv_last", 1, 64, 3)
+    a = "MV_deform_align."
+    sp.append((a + "temperature", (4, 1, 1), None, "ones"))
+    conv(a + "conv_du.0", 4, 64, 1)
+    conv(a + "conv_du.2", 64, 4, 1)
+    conv(a + "project_out", 64, 64, 1, bias=False)
+    conv(a + "fusion_in.0", 64, 128, 1)          # has parameters, never called (arch.py:3441-3444)
+    conv(a + "fusion_in.2", 64, 64, 1)
+    conv(a + "fusion_out.0", 64, 128, 1, bias=False)
+    conv(a + "CALayer.conv_du.0", 64, 64, 1)
+    conv(a + "CALayer.conv_du.2", 64, 64, 1)
+    for rb in ("ResidualBlock.", "ResidualBlock1."):
+        conv(a + rb + "conv1", 64, 64, 3, init="kaiming0.1")
+        conv(a + rb + "conv2", 64, 64, 3, init="kaiming0.1")
+    r = "RDAB."
+    conv(r + "input_conv", 128, 64, 1)
+    conv(r + "conv_du_re.0", 64, 64, 1)
+    conv(r + "conv_du_re.2", 64, 64, 3)
+    conv(r + "conv_du_re2.0", 64, 64, 1)
+    conv(r + "fuse", 64, 128, 1)
+    conv(r + "directW1_conv", 1, 1, 1, 9)
+    conv(r + "directH1_conv", 1, 1, 9, 1)
+    return sp
+
+
+class _Holder(nn.Module):
+    """Parameter container: reproduces the reference's module tree names without its Python forward code."""
+
+
+def _register(root: nn.Module, key: str, param: nn.Parameter):
+    parts = key.split(".")
+    m = root
+    for name in parts[:-1]:
+        if name not in m._modules:
+            m.add_module(name, _Holder())
+        m = m._modules[name]
+    m.register_parameter(parts[-1], param)
+
+
+# ------------------------------------------------------------------------------------------------ the module
+class CVSR_V8(nn.Module):
+    def __init__(self, nf=64, nframes=7, fea_ext_RBs=7, SCGs=4, istraining=False):
+        super().__init__()
+        if nf != 64 or nframes != 7:
+            raise ValueError("the HIP path is specialised for nf=64, nframes=7 (the only configuration the reference runs)")
+        self.nf, self.center, self.istraining, self.stride = nf, nframes // 2, istraining, 4
+        self.gumbel_uniform: Optional[Sequence[torch.Tensor]] = None
+        for key, shape, fan_in, init in _param_spec():
+            t = torch.empty(shape)
+            if init == "default":
+                nn.init.kaiming_uniform_(t, a=math.sqrt(5))
+            elif init == "kaiming0.1":
+                nn.init.kaiming_normal_(t, a=0, mode="fan_in")
+                t.mul_(0.1)
+            elif init == "bias":
+                bound = 1.0 / math.sqrt(fan_in)
+                nn.init.uniform_(t, -bound, bound)
+            elif init == "ones":
+                t.fill_(1.0)
+            else:
+                t.zero_()
+            _register(self, key, nn.Parameter(t))
+        self.debug_taps: Optional[dict] = None      # set to {} to collect stage outputs (tests only)
+        self._packed: Optional[dict] = None
+        self._packed_sig = None
+
+    # -- packed / device-resident weights, rebuilt whenever a parameter changed ----------------------------------
+    def _signature(self):
+        return tuple((p.data_ptr(), p._version) for p in self.parameters())
+
+    def _weights(self) -> dict:
+        sig = self._signature()
+        if self._packed is not None and sig == self._packed_sig:
+            return self._packed
+        sd = {k: v.detach() for k, v in self.named_parameters()}
+        for k, v in sd.items():
+            if not v.is_cuda:
+                raise NotImplementedError("CVSR_V8 (HIP): parameters must live on the GPU; call .cuda() / .to(device)")
+            if v.dtype != torch.float32:
+                raise NotImplementedError("CVSR_V8 (HIP): fp32 parameters expected")
+        w: Dict[str, object] = {}
+
+        def pc(key, **kw):
+            w[key] = K.pack_conv(sd[key + ".weight"], sd.get(key + ".bias"), **kw)
+
+        p = "transformer_feature_extraction.path1."
+        for key in (p + "attn.qkv", p + "conv", p + "side_to_feaoneUDSA.body.0", p + "side_to_feaoneUDSA.body.11",
+                    "conv_expand_fea_r", "tsa_fusion", "MV_deform_align.fusion_out.0",
+                    "MV_deform_align.ResidualBlock.conv1", "MV_deform_align.ResidualBlock.conv2",
+                    "MV_deform_align.ResidualBlock1.conv1", "MV_deform_align.ResidualBlock1.conv2",
+                    "RDAB.input_conv", "RDAB.conv_du_re.0", "RDAB.conv_du_re.2", "RDAB.fuse"):
+            pc(key)
+        for g in range(7):
+            pc(f"recon_trunk.body.{g}.conv")
+            for b in range(3):
+                for leaf in ("body.0", "body.2", "down.0", "up.0"):
+                    pc(f"recon_trunk.body.{g}.body.{b}.{leaf}")
+        pc("upconv1", shuffle2=True)
+        pc("upconv2", shuffle2=True)
+        w["raw"] = {k: v.contiguous() for k, v in sd.items()}
+        self._packed, self._packed_sig = w, sig
+        return w
+
+    # -- building blocks ------------------------------------------------------------------------------------------
+    def _udsa(self, w, x2, res):
+        raw = w["raw"]
+        u = "transformer_feature_extraction.path1.side_to_feaoneUDSA.body."
+        t = K.conv(x2, w[u + "0"], pad=1, act=K.ACT_LRELU)
+        t = K.small_conv16(t, raw[u + "2.weight"], raw[u + "2.bias"], 2, 2, act=K.ACT_LRELU)
+        t = K.small_conv16(t, raw[u + "4.weight"], raw[u + "4.bias"], 2, 2, act=K.ACT_LRELU)
+        t = K.spatial_gate16(t, raw[u + "6.spatial.weight"], raw[u + "6.spatial.bias"])
+        t = K.small_conv16(t, raw[u + "7.weight"], raw[u + "7.bias"], 2, 2, 0, True, K.ACT_LRELU)
+        t = K.small_conv16(t, raw[u + "9.weight"], raw[u + "9.bias"], 2, 2, 1, True, K.ACT_LRELU)
+        return K.conv(t, w[u + "11"], pad=1, act=K.ACT_LRELU, res1=res)
+
+    def _feature_extraction(self, w, x1, x2):
+        raw = w["raw"]
+        p = "transformer_feature_extraction.path1."
+        for rnd in range(3):
+            x2 = self._udsa(w, x2, x1 if rnd == 0 else x2)
+            ln = K.layernorm64(x1, raw[p + "norm1.body.weight"], raw[p + "norm1.body.bias"])
+            qkv = K.dwconv3x3(K.conv(ln, w[p + "attn.qkv"]), raw[p + "attn.qkv_dwconv.weight"])
+            part, n = K.gram_partial(qkv[..., 0:64], qkv[..., 64:128], 8)
+            fold = K.mdta_fold(part, n, raw[p + "attn.temperature"], raw[p + "attn.project_out.weight"])
+            x1 = K.conv(qkv[..., 128:192], fold, res1=x1)
+            ln = K.layernorm64(x1, raw[p + "norm2.body.weight"], raw[p + "norm2.body.bias"])
+            x1 = K.conv(ln, w[p + "conv"], pad=1, res1=x1, res2=x2)
+        return x1
+
+    def _rdab(self, w, res, x, noise):
+        raw = w["raw"]
+        B, H, W, _ = x.shape
+        t = K.conv(res, w["RDAB.conv_du_re.0"], act=K.ACT_RELU)
+        t = K.conv(t, w["RDAB.conv_du_re.2"], stride=2, pad=2, act=K.ACT_RELU)
+        part, n = K.chan_sum_partial(t)
+        vmax = K.vec_mlp(part, n, t.shape[1] * t.shape[2], raw["RDAB.conv_du_re2.0.weight"],
+                         raw["RDAB.conv_du_re2.0.bias"], 64, K.ACT_RELU)
+        xq = K.conv(x, w["RDAB.input_conv"])
+        sq, vrow, qwin = K.rdab_prep(xq, vmax, noise, raw["RDAB.directW1_conv.weight"], raw["RDAB.directW1_conv.bias"])
+        cat = K.empty_act(B, H, W, 128, x.device)
+        rowo = K.seq_attn(sq, vrow, 0)
+        qc = K.colconv9(sq, raw["RDAB.directH1_conv.weight"], raw["RDAB.directH1_conv.bias"])
+        K.seq_attn(qc, rowo, 1, out=cat[..., 0:64])
+        K.seq_attn(qwin, xq[..., 64:128], 2, out=cat[..., 64:128])
+        return K.conv(cat, w["RDAB.fuse"], res1=x)
+
+    def _align(self, w, xc, extra, pred, mv, mv_bstride, out):
+        raw = w["raw"]
+        a = "MV_deform_align."
+        B, H, W, _ = xc.shape
+        warped = K.flow_warp(extra, mv, mv_bstride)
+        kf = K.conv([warped, pred], w[a + "fusion_out.0"], act=K.ACT_RELU)
+        gp, ng = K.gram_partial(xc, kf, 16)
+        sw, ns = K.chan_sum_partial(warped)
+        sp, _ = K.chan_sum_partial(pred)
+        fold = K.align_fold(gp, ng, sw, sp, ns, H * W, raw[a + "temperature"], raw[a + "conv_du.0.weight"],
+                            raw[a + "conv_du.0.bias"], raw[a + "conv_du.2.weight"], raw[a + "conv_du.2.bias"],
+                            raw[a + "project_out.weight"], raw[a + "fusion_out.0.weight"])
+        o = K.conv([warped, pred, xc], fold, act=K.ACT_RELU)
+        part, n = K.chan_sum_partial(o)
+        gate = K.vec_mlp(part, n, H * W, raw[a + "CALayer.conv_du.0.weight"], raw[a + "CALayer.conv_du.0.bias"], 64,
+                         K.ACT_RELU, raw[a + "CALayer.conv_du.2.weight"], raw[a + "CALayer.conv_du.2.bias"], 64,
+                         K.ACT_SIGMOID)
+        o = K.scale_channels(o, gate)
+        r = K.conv(o, w[a + "ResidualBlock.conv1"], pad=1, act=K.ACT_RELU)
+        o = K.conv(r, w[a + "ResidualBlock.conv2"], pad=1, res1=o)
+        r = K.conv(o, w[a + "ResidualBlock1.conv1"], pad=1, act=K.ACT_RELU)
+        return K.conv(r, w[a + "ResidualBlock1.conv2"], pad=1, res1=o, res2=xc, out=out)
+
+    def _block(self, w, p, x):
+        """Block_ (arch.py:378-406): x + body(x) + up(body(down(x))) + down(body(up(x))).
+        The 1x1 convs commute with the (linear) resampling, so they run on the smaller side of it."""
+        b0, b2, dn, up = w[p + "body.0"], w[p + "body.2"], w[p + "down.0"], w[p + "up.0"]
+        out = K.conv(K.conv(x, b0, pad=1, act=K.ACT_LRELU), b2, pad=1, res1=x)
+        # half-resolution branch
+        d = K.conv(K.resample2(x, up=False), dn)
+        d = K.conv(K.conv(d, b0, pad=1, act=K.ACT_LRELU), b2, pad=1)
+        K.resample2(K.conv(d, up), up=True, out=out, accumulate=True)
+        # double-resolution branch
+        u = K.resample2(K.conv(x, up), up=True)
+        u = K.conv(K.conv(u, b0, pad=1, act=K.ACT_LRELU), b2, pad=1)
+        return K.conv(K.resample2(u, up=False), dn, res1=out)
+
+    def _trunk(self, w, fused):
+        y = fused
+        for g in range(7):
+            r = y
+            for b in range(3):
+                r = self._block(w, f"recon_trunk.body.{g}.body.{b}.", r)
+            y = K.conv(r, w[f"recon_trunk.body.{g}.conv"], pad=1, res1=y, res2=fused if g == 6 else None)
+        return y
+
+    # -- forward ---------------------------------------------------------------------------------------------------
+    def forward(self, x, mvs0, mvs1, pms, rms, ufs, pre_L1_fea=None, gumbel_uniform=None):
+        if not x.is_cuda:
+            raise NotImplementedError("CVSR_V8 (HIP): CPU tensors are not supported; there is no CPU fallback")
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            raise NotImplementedError("CVSR_V8 (HIP): forward only -- wrap the call in torch.no_grad() "
+                                      "(backward kernels are not part of this path yet)")
+        B, N, C, H, W = x.shape
+        if N != NFRAMES or C != 1:
+            raise ValueError(f"expected x of shape [B,7,1,H,W], got {tuple(x.shape)}")
+        if H % 8 or W % 8:
+            raise ValueError(f"H and W must be multiples of 8 (window attention, arch.py:2147,2235); got {H}x{W}")
+        w = self._weights()
+        raw = w["raw"]
+        self.H, self.W = H, W
+        ctr = self.center
+        x = x.contiguous().float()
+        pms = pms.contiguous().float()
+        mvs1 = mvs1.contiguous().float()
+        P = H * W
+
+        # 1. feature extraction (arch.py:4416-4427)
+        if pre_L1_fea is None:
+            f = K.stem_conv(x, P, B * N, H, W, raw["conv_first.weight"], raw["conv_first.bias"], K.ACT_LRELU)
+            s = K.stem_conv(pms, P, B * N, H, W, raw["conv_second.weight"], raw["conv_second.bias"])
+            L1 = self._feature_extraction(w, f, s)                       # [B*7,H,W,64], clip-major
+        else:
+            last_x, last_p = x[:, -1].contiguous(), pms[:, -1].contiguous()
+            f = K.stem_conv(last_x, P, B, H, W, raw["conv_first.weight"], raw["conv_first.bias"], K.ACT_LRELU)
+            s = K.stem_conv(last_p, P, B, H, W, raw["conv_second.weight"], raw["conv_second.bias"])
+            new = self._feature_extraction(w, f, s)                      # [B,H,W,64]
+            pre = self._as_pixel_major(pre_L1_fea, B * N, H, W)
+            L1 = torch.empty_like(pre)
+            L1v, prev = L1.view(B, N, H, W, NF), pre.view(B, N, H, W, NF)
+            L1v[:, :-1].copy_(prev[:, 1:])                               # device-side shift of the feature cache
+            L1v[:, -1].copy_(new)
+        Lf = (K.swap_outer(L1, B, N) if B > 1 else L1).view(N, B, H, W, NF)   # frame-major views for the loop
+
+        # 2. per-neighbour compensation + alignment (arch.py:4443-4460)
+        if ufs.shape[1] != 1:
+            ufs, rms = ufs.transpose(1, 2), rms.transpose(1, 2)
+        ufs = ufs.contiguous().float()
+        rms = rms.contiguous().float()
+        noise = gumbel_uniform if gumbel_uniform is not None else self.gumbel_uniform
+        aligned: List[torch.Tensor] = []
+        draw = 0
+        for i in range(N):
+            if i == ctr:
+                aligned.append(Lf[ctr])
+                continue
+            ufs_prior = K.stem_conv(ufs[:, 0, i], N * P, B, H, W, raw["conv_expand_ufs.weight"],
+                                    raw["conv_expand_ufs.bias"])
+            rms_prior, fea_com = K.stem_conv(rms[:, 0, i], N * P, B, H, W, raw["conv_expand_rms.weight"],
+                                             raw["conv_expand_rms.bias"], add=Lf[i])
+            if noise is None:
+                u = torch.rand((B, NF, H, W), device=x.device, dtype=torch.float32).clamp_min_(1e-30)
+            else:
+                u = noise[draw].to(device=x.device, dtype=torch.float32).contiguous()
+            draw += 1
+            x_n = self._rdab(w, rms_prior, fea_com, u)
+            if self.debug_taps is not None:
+                self.debug_taps[f"rdab_{i}"] = x_n
+                self.debug_taps[f"align_{i}"] = al_ref = K.empty_act(B, H, W, NF, x.device)
+            fea_i = K.conv([Lf[i], x_n], w["conv_expand_fea_r"], pad=1)
+            al = al_ref if self.debug_taps is not None else K.empty_act(B, H, W, NF, x.device)
+            self._align(w, Lf[ctr], fea_i, ufs_prior, mvs1[:, i], N * 2 * P, al)
+            aligned.append(al)
+
+        # 3. temporal fusion, 4. reconstruction trunk, 5. upsampling + skip (arch.py:4463-4481)
+        fused = K.conv(aligned, w["tsa_fusion"], act=K.ACT_LRELU)
+        t = self._trunk(w, fused)
+        if self.debug_taps is not None:
+            self.debug_taps.update(L1_fea=L1, fused=fused, trunk=t)
+        t = K.conv(t, w["upconv1"], act=K.ACT_LRELU)
+        t = K.conv(t, w["upconv2"], act=K.ACT_LRELU)
+        out = K.conv_last(t, raw["conv_last.weight"], raw["conv_last.bias"], x[:, ctr], N * P)
+        return out, L1.permute(0, 3, 1, 2)
+
+    @staticmethod
+    def _as_pixel_major(t: torch.Tensor, F: int, H: int, W: int) -> torch.Tensor:
+        """[F,64,H,W] in either memory format -> dense pixel-major [F,H,W,64]."""
+        if tuple(t.shape) != (F, NF, H, W):
+            raise ValueError(f"pre_L1_fea must be [{F},{NF},{H},{W}], got {tuple(t.shape)}")
+        t = t.float()
+        v = t.permute(0, 2, 3, 1)
+        if v.is_contiguous():
+            return v
+        return K.nchw_to_nhwc(t.contiguous())

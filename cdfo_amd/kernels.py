@@ -146,3 +146,189 @@ def conv(srcs: Sequence[torch.Tensor], pc: PackedConv, *, stride: int = 1, pad: 
     a.prec = 0
     check(_lib.lib().cdfo_conv_igemm(C.byref(a), _stream()), "cdfo_conv_igemm")
     return out
+
+
+# ----------------------------------------------------------------------------------------------- pointwise
+def _vp(t):
+    return C.c_void_p(None if t is None else t.data_ptr())
+
+
+def swap_outer(x: torch.Tensor, B: int, N: int) -> torch.Tensor:
+    """x: dense [B*N, ...] -> dense [N*B, ...] (out[n*B+b] = in[b*N+n])."""
+    x = x if x.is_contiguous() else x.contiguous()
+    out = torch.empty_like(x)
+    block = x.numel() // (B * N)
+    check(_lib.lib().cdfo_swap_outer(_vp(x), _vp(out), B, N, C.c_longlong(block), _stream()), "cdfo_swap_outer")
+    return out
+
+
+def stem_conv(img: torch.Tensor, img_bstride: int, B: int, H: int, W: int, w: torch.Tensor, bias: torch.Tensor,
+              act: int = ACT_NONE, add: Optional[torch.Tensor] = None):
+    """img: any fp32 device tensor whose element [b][y][x] sits at data_ptr + (b*img_bstride + y*W + x)*4."""
+    out = empty_act(B, H, W, 64, img.device)
+    out2 = None
+    lda = ldo2 = 0
+    if add is not None:
+        _, _, _, _, lda = _chk_act(add, "add")
+        out2 = empty_act(B, H, W, 64, img.device)
+        ldo2 = 64
+    check(_lib.lib().cdfo_stem_conv(_vp(img), C.c_longlong(img_bstride), _vp(w), _vp(bias), B, H, W, act, _vp(out), 64,
+                                    _vp(add), lda, _vp(out2), ldo2, _stream()), "cdfo_stem_conv")
+    return (out, out2) if add is not None else out
+
+
+def layernorm64(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor) -> torch.Tensor:
+    B, H, W, Cc, ld = _chk_act(x)
+    assert Cc == 64
+    out = empty_act(B, H, W, 64, x.device)
+    check(_lib.lib().cdfo_layernorm64(_vp(x), ld, _vp(gamma), _vp(beta), C.c_longlong(B * H * W), _vp(out), 64,
+                                      _stream()), "cdfo_layernorm64")
+    return out
+
+
+def dwconv3x3(x: torch.Tensor, w: torch.Tensor) -> torch.Tensor:
+    B, H, W, Cc, ld = _chk_act(x)
+    out = empty_act(B, H, W, Cc, x.device)
+    check(_lib.lib().cdfo_dwconv3x3(_vp(x), ld, _vp(w), B, H, W, Cc, _vp(out), Cc, _stream()), "cdfo_dwconv3x3")
+    return out
+
+
+def flow_warp(x: torch.Tensor, mv: torch.Tensor, mv_bstride: int) -> torch.Tensor:
+    B, H, W, Cc, ld = _chk_act(x)
+    out = empty_act(B, H, W, Cc, x.device)
+    check(_lib.lib().cdfo_flow_warp(_vp(x), ld, _vp(mv), C.c_longlong(mv_bstride), B, H, W, Cc, _vp(out), Cc,
+                                    _stream()), "cdfo_flow_warp")
+    return out
+
+
+def resample2(x: torch.Tensor, up: bool, out: Optional[torch.Tensor] = None, accumulate: bool = False) -> torch.Tensor:
+    B, H, W, Cc, ld = _chk_act(x)
+    Ho, Wo = (2 * H, 2 * W) if up else (H // 2, W // 2)
+    if out is None:
+        assert not accumulate
+        out = empty_act(B, Ho, Wo, Cc, x.device)
+    ob, oh, ow, oc, ldo = _chk_act(out, "out")
+    assert (ob, oh, ow, oc) == (B, Ho, Wo, Cc)
+    check(_lib.lib().cdfo_resample2(_vp(x), ld, B, H, W, Cc, _vp(out), ldo, int(up), int(accumulate), _stream()),
+          "cdfo_resample2")
+    return out
+
+
+def scale_channels(x: torch.Tensor, gate: torch.Tensor) -> torch.Tensor:
+    B, H, W, Cc, ld = _chk_act(x)
+    out = empty_act(B, H, W, Cc, x.device)
+    check(_lib.lib().cdfo_scale_channels(_vp(x), ld, _vp(gate), B, C.c_longlong(H * W), Cc, _vp(out), Cc, _stream()),
+          "cdfo_scale_channels")
+    return out
+
+
+def conv_last(x: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, xc: torch.Tensor, xc_bstride: int) -> torch.Tensor:
+    B, Hh, Wh, Cc, ld = _chk_act(x)
+    assert Cc == 64
+    out = torch.empty((B, 1, Hh, Wh), dtype=torch.float32, device=x.device)
+    check(_lib.lib().cdfo_conv_last(_vp(x), ld, _vp(w), _vp(bias), _vp(xc), C.c_longlong(xc_bstride), B, Hh, Wh,
+                                    _vp(out), _stream()), "cdfo_conv_last")
+    return out
+
+
+def small_conv16(x: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, stride: int, pad: int, out_pad: int = 0,
+                 transposed: bool = False, act: int = ACT_NONE) -> torch.Tensor:
+    B, H, W, Cc, ld = _chk_act(x)
+    assert Cc == 16
+    if transposed:
+        Ho, Wo = (H - 1) * stride - 2 * pad + 3 + out_pad, (W - 1) * stride - 2 * pad + 3 + out_pad
+    else:
+        Ho, Wo = (H + 2 * pad - 3) // stride + 1, (W + 2 * pad - 3) // stride + 1
+    out = empty_act(B, Ho, Wo, 16, x.device)
+    check(_lib.lib().cdfo_small_conv16(_vp(x), ld, _vp(w), _vp(bias), B, H, W, stride, pad, out_pad, int(transposed),
+                                       act, _vp(out), 16, _stream()), "cdfo_small_conv16")
+    return out
+
+
+def spatial_gate16(x: torch.Tensor, w: torch.Tensor, bias: torch.Tensor) -> torch.Tensor:
+    B, H, W, Cc, ld = _chk_act(x)
+    assert Cc == 16
+    out = empty_act(B, H, W, 16, x.device)
+    check(_lib.lib().cdfo_spatial_gate16(_vp(x), ld, _vp(w), _vp(bias), B, H, W, _vp(out), 16, _stream()),
+          "cdfo_spatial_gate16")
+    return out
+
+
+# ----------------------------------------------------------------------------------------------- reductions / folds
+def nchunks_for(P: int) -> int:
+    return max(1, min(128, P // 2048))
+
+
+def chan_sum_partial(x: torch.Tensor):
+    B, H, W, Cc, ld = _chk_act(x)
+    assert Cc == 64
+    n = nchunks_for(H * W)
+    part = torch.empty((B, n, 64), dtype=torch.float32, device=x.device)
+    check(_lib.lib().cdfo_chan_sum_partial(_vp(x), ld, B, C.c_longlong(H * W), n, _vp(part), _stream()),
+          "cdfo_chan_sum_partial")
+    return part, n
+
+
+def gram_partial(q: torch.Tensor, k: torch.Tensor, ch_per_head: int):
+    B, H, W, Cc, ldq = _chk_act(q, "q")
+    _, _, _, _, ldk = _chk_act(k, "k")
+    n = nchunks_for(H * W)
+    part = torch.empty((B, n, 64 * (ch_per_head + 2)), dtype=torch.float32, device=q.device)
+    check(_lib.lib().cdfo_gram_partial(_vp(q), ldq, _vp(k), ldk, B, C.c_longlong(H * W), ch_per_head, n, _vp(part),
+                                       _stream()), "cdfo_gram_partial")
+    return part, n
+
+
+def mdta_fold(part: torch.Tensor, n: int, temperature: torch.Tensor, proj_w: torch.Tensor) -> PackedConv:
+    B = part.shape[0]
+    wout = torch.empty((B, 4096), dtype=torch.float32, device=part.device)
+    check(_lib.lib().cdfo_mdta_fold(_vp(part), n, _vp(temperature), _vp(proj_w), B, _vp(wout), _stream()),
+          "cdfo_mdta_fold")
+    return PackedConv(wout, None, 64, 64, 1, 64, False, 4096)
+
+
+def align_fold(gpart, ng, sw, sp, ns, P, temperature, du0_w, du0_b, du2_w, du2_b, proj_w, fusion_w) -> PackedConv:
+    B = gpart.shape[0]
+    wout = torch.empty((B, 192 * 64), dtype=torch.float32, device=gpart.device)
+    check(_lib.lib().cdfo_align_fold(_vp(gpart), ng, _vp(sw), _vp(sp), ns, C.c_longlong(P), _vp(temperature),
+                                     _vp(du0_w), _vp(du0_b), _vp(du2_w), _vp(du2_b), _vp(proj_w), _vp(fusion_w), B,
+                                     _vp(wout), _stream()), "cdfo_align_fold")
+    return PackedConv(wout, None, 64, 192, 1, 64, False, 192 * 64)
+
+
+def vec_mlp(part: torch.Tensor, n: int, P: int, w1, b1, c1: int, act1: int, w2=None, b2=None, c2: int = 0,
+            act2: int = ACT_NONE) -> torch.Tensor:
+    B = part.shape[0]
+    out = torch.empty((B, c2 if w2 is not None else c1), dtype=torch.float32, device=part.device)
+    check(_lib.lib().cdfo_vec_mlp(_vp(part), n, C.c_longlong(P), _vp(w1), _vp(b1), c1, act1, _vp(w2), _vp(b2), c2, act2,
+                                  B, _vp(out), _stream()), "cdfo_vec_mlp")
+    return out
+
+
+# ----------------------------------------------------------------------------------------------- prior-fusion attention
+def rdab_prep(xq: torch.Tensor, vmax: torch.Tensor, noise: torch.Tensor, wW: torch.Tensor, bW: torch.Tensor):
+    B, H, W, Cc, ld = _chk_act(xq)
+    assert Cc == 128 and noise.is_contiguous() and tuple(noise.shape) == (B, 64, H, W)
+    sq = empty_act(B, H, W, 64, xq.device)
+    vrow = empty_act(B, H, W, 64, xq.device)
+    qwin = empty_act(B, H, W, 64, xq.device)
+    check(_lib.lib().cdfo_rdab_prep(_vp(xq), ld, _vp(vmax), _vp(noise), _vp(wW), _vp(bW), B, C.c_longlong(H * W),
+                                    _vp(sq), 64, _vp(vrow), 64, _vp(qwin), 64, _stream()), "cdfo_rdab_prep")
+    return sq, vrow, qwin
+
+
+def colconv9(x: torch.Tensor, wH: torch.Tensor, bH: torch.Tensor) -> torch.Tensor:
+    B, H, W, Cc, ld = _chk_act(x)
+    out = empty_act(B, H, W, 64, x.device)
+    check(_lib.lib().cdfo_colconv9(_vp(x), ld, _vp(wH), _vp(bH), B, H, W, _vp(out), 64, _stream()), "cdfo_colconv9")
+    return out
+
+
+def seq_attn(q: torch.Tensor, v: torch.Tensor, mode: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    B, H, W, Cc, ldq = _chk_act(q, "q")
+    _, _, _, _, ldv = _chk_act(v, "v")
+    if out is None:
+        out = empty_act(B, H, W, 64, q.device)
+    _, _, _, _, ldo = _chk_act(out, "out")
+    check(_lib.lib().cdfo_seq_attn(_vp(q), ldq, _vp(v), ldv, _vp(out), ldo, B, H, W, mode, _stream()), "cdfo_seq_attn")
+    return out

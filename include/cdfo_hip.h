@@ -21,6 +21,7 @@ extern "C" {
 
 #define CDFO_EINVAL (-1)   /* bad shape / unsupported configuration */
 #define CDFO_EALIGN (-2)   /* pointer or pitch not 16-byte aligned  */
+#define CDFO_MAXSRC 8
 
 enum { CDFO_ACT_NONE = 0, CDFO_ACT_LRELU = 1, CDFO_ACT_RELU = 2, CDFO_ACT_SIGMOID = 3 };
 enum { CDFO_STORE_PLAIN = 0, CDFO_STORE_SHUFFLE2 = 1 };
@@ -32,11 +33,11 @@ const char* cdfo_build_info(void);
 
 /* Dense convolution as an implicit GEMM on the matrix cores (replaces F.conv2d for 1x1 / 3x3, stride 1|2;
  * arch/SIDECVSR_our.py e.g. :383-387 Block_.body, :4382, :4386, :4390-4391).
- * Input = channel-concatenation of up to three sources (replaces torch.cat(...,1) in front of a conv).
+ * Input = channel-concatenation of up to CDFO_MAXSRC sources (replaces torch.cat(...,1) in front of a conv).
  * w: packed by cdfo_pack_conv_weight(); optional per-image weights (w_bstride != 0).
  * Epilogue: +bias -> act -> +res1 -> +res2 -> store (plain or 2x pixel-shuffle, arch.py:4473-4474).  */
 typedef struct {
-  const float* src[3]; int ld[3]; int cs[3]; int nsrc;
+  const float* src[CDFO_MAXSRC]; int ld[CDFO_MAXSRC]; int cs[CDFO_MAXSRC]; int nsrc;
   int B, H, W, Ho, Wo;
   int ks, stride, pad;
   int Cin, Cout, CoutP;
@@ -59,6 +60,63 @@ int cdfo_pack_conv_weight(const float* w_oihw, float* packed, int Cout, int Cin,
 /* Layout changes at the module boundary (reference tensors are NCHW).  */
 int cdfo_nchw_to_nhwc(const float* in, float* out, int B, int C, int H, int W, int ldo, void* stream);
 int cdfo_nhwc_to_nchw(const float* in, int ldi, float* out, int B, int C, int H, int W, void* stream);
+/* out[n][b] = in[b][n] for blocks of `block` floats (clip-major <-> frame-major feature stacks).  */
+int cdfo_swap_outer(const float* in, float* out, int B, int N, long long block, void* stream);
+
+/* ---- bandwidth-bound pixel-major kernels (pointwise.hip) ------------------------------------------------- */
+/* 3x3 conv 1 -> 64 channels on a single-channel plane [B][H][W] (image pitch img_bstride floats); raw OIHW weight
+ * [64][1][3][3]; optional second output out2 = result + add.  arch/SIDECVSR_our.py:4379-4384,4417-4418,4446-4449. */
+int cdfo_stem_conv(const float* img, long long img_bstride, const float* w, const float* bias, int B, int H, int W,
+                   int act, float* out, int ldo, const float* add, int lda, float* out2, int ldo2, void* stream);
+/* per-pixel LayerNorm over 64 channels (arch.py:1169-1198). */
+int cdfo_layernorm64(const float* in, int ldi, const float* gamma, const float* beta, long long npix, float* out,
+                     int ldo, void* stream);
+/* depthwise 3x3, pad 1, no bias; raw weight [C][1][3][3] (arch.py:1552). */
+int cdfo_dwconv3x3(const float* in, int ldi, const float* w, int B, int H, int W, int C, float* out, int ldo,
+                   void* stream);
+/* flow_warp (arch.py:3068-3099); mv = [B][2][H][W] planes (x then y), image pitch mv_bstride floats. */
+int cdfo_flow_warp(const float* in, int ldi, const float* mv, long long mv_bstride, int B, int H, int W, int C,
+                   float* out, int ldo, void* stream);
+/* bilinear x2 (up=1) or x0.5 (up=0), align_corners=False (arch.py:324-333); accumulate: out += result. */
+int cdfo_resample2(const float* in, int ldi, int B, int H, int W, int C, float* out, int ldo, int up, int accumulate,
+                   void* stream);
+/* out = in * gate[b][c] (CALayer, arch.py:2041-2043). */
+int cdfo_scale_channels(const float* in, int ldi, const float* gate, int B, long long P, int C, float* out, int ldo,
+                        void* stream);
+/* conv_last 3x3 64->1 (+bias) + bilinear x4 of the centre LR frame (arch.py:4476-4480); out = [B][Hh][Wh]. */
+int cdfo_conv_last(const float* in, int ldi, const float* w, const float* bias, const float* xc, long long xc_bstride,
+                   int B, int Hh, int Wh, float* out, void* stream);
+
+/* ---- thin 16-channel layers of the prior U-net (smallconv.hip; arch.py:1815-1834, 2719-2730) --------------- */
+int cdfo_small_conv16(const float* in, int ldi, const float* w, const float* bias, int B, int H, int W, int stride,
+                      int pad, int out_pad, int transposed, int act, float* out, int ldo, void* stream);
+int cdfo_spatial_gate16(const float* in, int ldi, const float* w, const float* bias, int B, int H, int W, float* out,
+                        int ldo, void* stream);
+
+/* ---- reductions + per-image weight folding of the channel attentions (stats.hip) --------------------------- */
+int cdfo_chan_sum_partial(const float* in, int ldi, int B, long long P, int nchunk, float* partial, void* stream);
+int cdfo_gram_partial(const float* q, int ldq, const float* k, int ldk, int B, long long P, int ch_per_head, int nchunk,
+                      float* partial, void* stream);
+/* MDTA (arch.py:1555-1575): wout[b] = packed 1x1 weights (64->64) = project_out x blockdiag(softmax(...)). */
+int cdfo_mdta_fold(const float* partial, int nchunk, const float* temperature, const float* proj_w, int B, float* wout,
+                   void* stream);
+/* DualAttAlignment (arch.py:3459-3491): wout[b] = packed 1x1 weights (192->64) over cat[warped, pred, x]. */
+int cdfo_align_fold(const float* gram_partial, int nchunk_g, const float* sum_warp, const float* sum_pred, int nchunk_s,
+                    long long P, const float* temperature, const float* du0_w, const float* du0_b, const float* du2_w,
+                    const float* du2_b, const float* proj_w, const float* fusion_w, int B, float* wout, void* stream);
+/* out[b] = act2(W2 act1(W1 mean_b + b1) + b2) from channel-sum partials (CALayer / conv_du_re2). */
+int cdfo_vec_mlp(const float* sum_partial, int nchunk, long long P, const float* w1, const float* b1, int c1, int act1,
+                 const float* w2, const float* b2, int c2, int act2, int B, float* out, void* stream);
+
+/* ---- LLongRangAttention (attention.hip; arch.py:2179-2249) -------------------------------------------------- */
+/* noise: the uniform draws of arch.py:2169 as [B][64][H*W]. */
+int cdfo_rdab_prep(const float* xq, int ldx, const float* vmax, const float* noise, const float* wW, const float* bW,
+                   int B, long long P, float* sq, int lds_, float* vrow, int ldv, float* qwin, int ldw, void* stream);
+int cdfo_colconv9(const float* in, int ldi, const float* wH, const float* bH, int B, int H, int W, float* out, int ldo,
+                  void* stream);
+/* out = softmax(Q Q^T) V per row (mode 0), column (1) or 8x8 window (2). */
+int cdfo_seq_attn(const float* q, int ldq, const float* v, int ldv, float* out, int ldo, int B, int H, int W, int mode,
+                  void* stream);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,196 @@
+#!/usr/bin/env python3
+"""Headline benchmark: x4 SR frames/s of the CVSR_V8 forward on synthetic JCT-VC ClassB-shape clips.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch 8] [--height 270 --width 480] [--no-cpu-baseline]
+
+A "step" is one forward of the hot path over one batch of clips already resident in HBM: 8 clips per GPU of
+7 x 1 x 272 x 480 luma (270 rows zero-padded to 272) + MV / residual / partition / unfiltered priors ->
+8 HR frames of 1088 x 1920 (crop to 1080).  For N > 1 the driver starts one process per GPU (torchrun); clips are
+sharded by batch (weak scaling: 8 clips per GPU), there is no data-path collective, and ONE all_gather over RCCL
+carries the per-rank metrics.  Rank 0 prints one JSON line.
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+# algorithmic FLOPs per clip-forward, counted on the reference itself: F = P*(73.55e6 + 1536*(W+H))
+EXACT_FLOPS = {(272, 480): 9_753_744_609_072, (120, 240): 2_134_302_625_536, (64, 64): 302_119_013_712,
+               (544, 960): 39_617_571_644_688}
+PEAK_F32_MFMA_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md, dense fp32 matrix peak
+KID_NAMES = ["conv3x3_wide", "conv3x3_narrow", "conv1x1", "conv3x3_s2", "stem", "layernorm", "dwconv", "flow_warp",
+             "resample", "scale", "conv_last", "small_conv", "spatial_gate", "chan_sum", "gram", "fold", "rdab_prep",
+             "colconv9", "attn_row", "attn_col", "attn_win", "layout", "pack", "dcn"]
+
+
+def flops_per_clip(H, W):
+    return EXACT_FLOPS.get((H, W), H * W * (73.55e6 + 1536.0 * (W + H)))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=8, help="clips per GPU")
+    ap.add_argument("--height", type=int, default=270)
+    ap.add_argument("--width", type=int, default=480)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--breakdown", type=str, default="", help="write the per-kernel-family event timings to this file")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
+
+    from arch.SIDECVSR_our import CVSR_V8
+    from cdfo_amd import _lib
+    from oracle.cvsr_v8_ref import cvsr_v8_forward, make_inputs, make_state_dict, psnr_y
+
+    lib = _lib.lib()
+    sd = make_state_dict(0, perturb=False)                # random init of the reference architecture
+    model = CVSR_V8()
+    model.load_state_dict(sd, strict=True)
+    model = model.to(dev).eval()
+
+    # ---- parity spot-check against the CPU oracle on the reference's own CPU-runnable config (c1: 64x64, B=1)
+    c1 = make_inputs(1, 64, 64, 1000)
+    with torch.no_grad():
+        ref_out, _ = cvsr_v8_forward(sd, c1["x"], None, c1["mvs1"], c1["pms"], c1["rms"], c1["ufs"], None, c1["gumbel_u"])
+        got, _ = model(c1["x"].to(dev), None, c1["mvs1"].to(dev), c1["pms"].to(dev), c1["rms"].to(dev),
+                       c1["ufs"].to(dev), gumbel_uniform=[u.to(dev) for u in c1["gumbel_u"]])
+    max_abs = (got.cpu() - ref_out).abs().max().item()
+    psnr = psnr_y(got.cpu(), ref_out)
+
+    # ---- workload: B clips, H padded to a multiple of 8 (test_LD_37.py:24-26 semantics)
+    B = args.batch
+    Hp = (args.height + 7) // 8 * 8
+    Wp = (args.width + 7) // 8 * 8
+    inp = make_inputs(B, Hp, Wp, 1002 + rank, pad_rows=Hp - args.height)
+    d = {k: v.to(dev) for k, v in inp.items() if k != "gumbel_u"}
+    noise = [u.to(dev) for u in inp["gumbel_u"]]
+
+    def step():
+        with torch.no_grad():
+            return model(d["x"], d["mvs0"], d["mvs1"], d["pms"], d["rms"], d["ufs"], gumbel_uniform=noise)
+
+    for _ in range(args.warmup):
+        step()
+    nk = lib.cdfo_prof_kid_count()
+    _lib.check(lib.cdfo_prof_begin(2000 * max(1, args.steps)), "cdfo_prof_begin")
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out, _ = step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+
+    launches = (C.c_int * nk)()
+    ms = (C.c_double * nk)()
+    fl = (C.c_double * nk)()
+    by = (C.c_double * nk)()
+    nrec = lib.cdfo_prof_end(launches, ms, fl, by, nk)
+    if nrec < 0:
+        raise SystemExit(f"cdfo_prof_end failed: {nrec}")
+
+    # ---- the single collective: all_gather of per-rank metrics (time, checksum, parity)
+    mine = torch.tensor([elapsed, out.double().mean().item(), max_abs, psnr if psnr != float("inf") else 999.0],
+                        dtype=torch.float64, device=dev)
+    if world > 1:
+        allm = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(allm, mine)
+        allm = torch.stack(allm).cpu()
+    else:
+        allm = mine.cpu().unsqueeze(0)
+    t_max = allm[:, 0].max().item()
+
+    if rank == 0:
+        clips_total = B * world * args.steps
+        value = clips_total / t_max
+        F = flops_per_clip(Hp, Wp)
+        dom = max(range(nk), key=lambda k: ms[k])
+        dom_avg_ms = ms[dom] / max(1, launches[dom])
+        achieved = (fl[dom] / max(1, launches[dom])) / (dom_avg_ms * 1e-3) / 1e12 if dom_avg_ms > 0 else 0.0
+        roofline = {"bound": "mfma", "kernel": KID_NAMES[dom], "achieved": round(achieved, 2),
+                    "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
+                    "traffic": None, "launches_per_step": launches[dom] // max(1, args.steps),
+                    "avg_launch_ms": round(dom_avg_ms, 4),
+                    "share_of_gpu_time": round(ms[dom] / max(1e-9, sum(ms)), 4),
+                    "whole_forward_tflops": round(F * B * args.steps / t_max / 1e12, 2)}
+        cpu = None
+        if not args.no_cpu_baseline:
+            cpu = cpu_baseline(sd, Hp, Wp)
+        res = {
+            "metric": "x4 SR frames/sec, 7-frame 270x480->1080p", "value": round(value, 4), "unit": "frames/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * t_max / args.steps, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"JCT-VC ClassB-shape synthetic clips: {B} clips/GPU x 7x1x{args.height}x{args.width} "
+                                   f"luma (padded to {Hp}x{Wp}) + MV/residual/partition/unfiltered priors -> "
+                                   f"{4 * args.height}x{4 * args.width}, fresh path (pre_L1_fea=None), fp32",
+                       "clips_per_gpu": B, "lr_padded": [Hp, Wp], "parallelism": f"batch-shard x{world}",
+                       "weights": "random init (seed 0)"},
+            "parity": {"config": "c1 64x64 B=1 vs CPU oracle", "max_abs": max_abs, "psnr_y_db": psnr,
+                       "per_rank_max_abs": [float(v) for v in allm[:, 2]]},
+            "roofline": roofline, "cpu_baseline": cpu,
+        }
+        print(json.dumps(res))
+        if args.breakdown:
+            with open(args.breakdown, "w") as f:
+                tot = sum(ms)
+                f.write(f"# HIP-event timing per kernel family, {args.steps} steps, B={B}, {Hp}x{Wp}; wall {t_max*1e3:.1f} ms\n")
+                f.write("family launches total_ms share avg_ms TFLOP/s GB/s(algorithmic)\n")
+                for k in sorted(range(nk), key=lambda k: -ms[k]):
+                    if launches[k] == 0:
+                        continue
+                    f.write(f"{KID_NAMES[k]} {launches[k]} {ms[k]:.3f} {ms[k]/tot:.4f} {ms[k]/launches[k]:.4f} "
+                            f"{fl[k]/ms[k]/1e9:.2f} {by[k]/ms[k]/1e6:.1f}\n")
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(sd, Hp, Wp):
+    """The oracle (a torch-cpu port of the reference forward) timed on this host on a bounded sample: ONE clip at half
+    the workload's height and width, scaled to the workload by the algorithmic-FLOP ratio."""
+    from oracle.cvsr_v8_ref import cvsr_v8_forward, make_inputs
+    cores = min(os.cpu_count() or 1, 32)
+    try:
+        cores = min(cores, len(os.sched_getaffinity(0)))
+    except Exception:
+        pass
+    torch.set_num_threads(cores)
+    h, w = max(8, Hp // 2 // 8 * 8), max(8, Wp // 2 // 8 * 8)
+    s = make_inputs(1, h, w, 77)
+    with torch.no_grad():
+        t0 = time.perf_counter()
+        cvsr_v8_forward(sd, s["x"], None, s["mvs1"], s["pms"], s["rms"], s["ufs"], None, s["gumbel_u"])
+        dt = time.perf_counter() - t0
+    scale = flops_per_clip(Hp, Wp) / flops_per_clip(h, w)
+    return {"value": round(1.0 / (dt * scale), 5), "unit": "frames/s", "cores": cores, "kind": "port",
+            "sample": f"1 clip 7x1x{h}x{w} forward = {dt:.2f} s on {cores} torch threads, scaled x{scale:.2f} by "
+                      f"algorithmic FLOPs to {Hp}x{Wp}", "torch": torch.__version__}
+
+
+if __name__ == "__main__":
+    main()

@@ -7,6 +7,12 @@ from __future__ import annotations
 import ctypes as C
 import os
 
+# torch first: its wheel bundles the HIP/HSA runtime (libamdhip64.so.7).  libcdfo_hip.so must bind to THAT copy --
+# the streams and device pointers handed across the C-ABI come from it -- so it has to be in the process before
+# our library's DT_NEEDED entries are resolved.  (Loading /opt/rocm's copy first leaves two HSA runtimes in one
+# process and every launch fails with hipErrorNoDevice.)
+import torch  # noqa: F401,E402
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libcdfo_hip.so")
 

@@ -210,6 +210,7 @@ extern "C" int cdfo_rdab_prep(const float* xq, int ldx, const float* vmax, const
                               int ldw, void* stream) {
   if (B <= 0 || P <= 0 || P % 64 || ldx % 4 || lds_ % 4 || ldv % 4 || ldw % 4) return CDFO_EINVAL;
   if (!aligned16(xq) || !aligned16(sq) || !aligned16(vrow) || !aligned16(qwin)) return CDFO_EALIGN;
+  CdfoProfScope prof(static_cast<hipStream_t>(stream), KID_RDAB_PREP, 0, 4.0*(128+64+192)*(double)B*P);
   hipLaunchKernelGGL(rdab_prep_kernel, dim3((unsigned)(B * P / 64)), dim3(256), 0, static_cast<hipStream_t>(stream), xq,
                      ldx, vmax, noise, wW, bW, P, sq, lds_, vrow, ldv, qwin, ldw);
   CDFO_LAUNCH_CHECK();
@@ -222,6 +223,7 @@ extern "C" int cdfo_colconv9(const float* in, int ldi, const float* wH, const fl
   if (!aligned16(in) || !aligned16(out)) return CDFO_EALIGN;
   long long blocks = ((long long)B * H * W * 16 + 255) / 256;
   if (blocks > 8192) blocks = 8192;
+  CdfoProfScope prof(static_cast<hipStream_t>(stream), KID_COLCONV9, 0, 4.0*128*(double)B*H*W);
   hipLaunchKernelGGL(colconv9_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), in, ldi, wH,
                      bH, B, H, W, out, ldo);
   CDFO_LAUNCH_CHECK();
@@ -233,6 +235,7 @@ extern "C" int cdfo_seq_attn(const float* q, int ldq, const float* v, int ldv, f
   if (B <= 0 || H <= 0 || W <= 0 || ldq % 4 || ldv % 4 || ldo % 4) return CDFO_EINVAL;
   if (!aligned16(q) || !aligned16(v) || !aligned16(out)) return CDFO_EALIGN;
   hipStream_t st = static_cast<hipStream_t>(stream);
+  CdfoProfScope prof(static_cast<hipStream_t>(stream), mode==0?KID_ATTN_ROW:(mode==1?KID_ATTN_COL:KID_ATTN_WIN), 4.0*64*(double)B*H*W*(mode==0?W:(mode==1?H:64)), 4.0*192*(double)B*H*W);
   if (mode == 0) {
     hipLaunchKernelGGL(seq_attn_kernel<0>, dim3((unsigned)((long long)B * H * cdiv(W, 64))), dim3(64), 0, st, q, ldq, v,
                        ldv, out, ldo, B, H, W);

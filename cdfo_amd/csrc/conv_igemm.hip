@@ -176,6 +176,10 @@ int launch(const cdfo_conv_args& a, hipStream_t st) {
     attr_set = true;
   }
   dim3 grid(cdiv(a.Wo, TW) * cdiv(a.Ho, TH), a.CoutP / G::BN, a.B);
+  const int kid = KS == 1 ? KID_CONV1 : (S == 2 ? KID_CONV3_S2 : (NT == 2 ? KID_CONV3_WIDE : KID_CONV3_NARROW));
+  const double px = (double)a.B * a.Ho * a.Wo;
+  CdfoProfScope prof(st, kid, 2.0 * px * a.Cout * a.Cin * KS * KS,
+                     4.0 * (px * a.Cout + (double)a.B * a.H * a.W * a.Cin + (double)KS * KS * a.Cin * a.Cout));
   hipLaunchKernelGGL((conv_igemm_f32<KS, S, TH, NT>), grid, dim3(256), G::LDS_BYTES, st, a);
   CDFO_LAUNCH_CHECK();
   return 0;
@@ -212,6 +216,7 @@ extern "C" int cdfo_pack_conv_weight(const float* w, float* packed, int Cout, in
   const int CoutP = (Cout + 31) / 32 * 32;
   const long long total = (long long)ks * ks * Cin * CoutP;
   const int blocks = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
+  CdfoProfScope prof(static_cast<hipStream_t>(stream), KID_PACK, 0, 8.0 * total);
   hipLaunchKernelGGL(pack_weight_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream), w, packed, Cout,
                      Cin, ks, CoutP, shuffle2, transposed);
   CDFO_LAUNCH_CHECK();

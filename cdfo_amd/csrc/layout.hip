@@ -43,6 +43,7 @@ extern "C" int cdfo_nchw_to_nhwc(const float* in, float* out, int B, int C, int 
   if (B <= 0 || C <= 0 || H <= 0 || W <= 0 || ldo < C) return CDFO_EINVAL;
   const int P = H * W;
   dim3 grid(cdiv(P, 32), cdiv(C, 32), B);  // in rows = channels (R=C), cols = pixels (Cc=P)
+  CdfoProfScope prof(static_cast<hipStream_t>(stream), KID_LAYOUT, 0, 8.0*(double)B*C*H*W);
   hipLaunchKernelGGL(transpose2d, grid, dim3(256), 0, static_cast<hipStream_t>(stream), in, (long long)C * P, P, out,
                      (long long)P * ldo, ldo, C, P);
   CDFO_LAUNCH_CHECK();
@@ -53,6 +54,7 @@ extern "C" int cdfo_nhwc_to_nchw(const float* in, int ldi, float* out, int B, in
   if (B <= 0 || C <= 0 || H <= 0 || W <= 0 || ldi < C) return CDFO_EINVAL;
   const int P = H * W;
   dim3 grid(cdiv(C, 32), cdiv(P, 32), B);  // in rows = pixels (R=P), cols = channels (Cc=C)
+  CdfoProfScope prof(static_cast<hipStream_t>(stream), KID_LAYOUT, 0, 8.0*(double)B*C*H*W);
   hipLaunchKernelGGL(transpose2d, grid, dim3(256), 0, static_cast<hipStream_t>(stream), in, (long long)P * ldi, ldi, out,
                      (long long)C * P, P, P, C);
   CDFO_LAUNCH_CHECK();
@@ -64,6 +66,7 @@ extern "C" int cdfo_swap_outer(const float* in, float* out, int B, int N, long l
   if (!aligned16(in) || !aligned16(out)) return CDFO_EALIGN;
   long long blocks = ((long long)B * N * (block / 4) + 255) / 256;
   if (blocks > 8192) blocks = 8192;
+  CdfoProfScope prof(static_cast<hipStream_t>(stream), KID_LAYOUT, 0, 8.0*(double)B*N*block);
   hipLaunchKernelGGL(swap_outer_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream),
                      reinterpret_cast<const f32x4*>(in), reinterpret_cast<f32x4*>(out), B, N, block / 4);
   CDFO_LAUNCH_CHECK();

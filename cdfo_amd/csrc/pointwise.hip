@@ -289,6 +289,7 @@ extern "C" int cdfo_stem_conv(const float* img, long long img_bstride, const flo
                               void* stream) {
   if (B <= 0 || H <= 0 || W <= 0 || ldo % 4 || (out2 && (!add || lda % 4 || ldo2 % 4))) return CDFO_EINVAL;
   if (!aligned16(out) || (out2 && (!aligned16(out2) || !aligned16(add)))) return CDFO_EALIGN;
+  CdfoProfScope prof(static_cast<hipStream_t>(stream), KID_STEM, 2.0*9*64*(double)B*H*W, 4.0*(double)B*H*W*(1+64+(out2?128:0)));
   hipLaunchKernelGGL(stem_conv_kernel, dim3(grid_for((long long)B * H * W * 16)), dim3(256), 0,
                      static_cast<hipStream_t>(stream), img, img_bstride, w, bias, B, H, W, act, out, ldo, add, lda, out2,
                      ldo2);
@@ -300,6 +301,7 @@ extern "C" int cdfo_layernorm64(const float* in, int ldi, const float* gamma, co
                                 float* out, int ldo, void* stream) {
   if (npix <= 0 || ldi % 4 || ldo % 4) return CDFO_EINVAL;
   if (!aligned16(in) || !aligned16(out) || !aligned16(gamma) || !aligned16(beta)) return CDFO_EALIGN;
+  CdfoProfScope prof(static_cast<hipStream_t>(stream), KID_LAYERNORM, 0, 4.0*128*(double)npix);
   hipLaunchKernelGGL(layernorm64_kernel, dim3(grid_for(npix * 16)), dim3(256), 0, static_cast<hipStream_t>(stream), in,
                      ldi, gamma, beta, npix, out, ldo);
   CDFO_LAUNCH_CHECK();
@@ -310,6 +312,7 @@ extern "C" int cdfo_dwconv3x3(const float* in, int ldi, const float* w, int B, i
                               void* stream) {
   if (B <= 0 || C % 4 || C > 256 || ldi % 4 || ldo % 4) return CDFO_EINVAL;
   if (!aligned16(in) || !aligned16(out)) return CDFO_EALIGN;
+  CdfoProfScope prof(static_cast<hipStream_t>(stream), KID_DWCONV, 2.0*9*C*(double)B*H*W, 8.0*C*(double)B*H*W);
   hipLaunchKernelGGL(dwconv3x3_kernel, dim3(grid_for((long long)B * H * W * (C / 4))), dim3(256), 0,
                      static_cast<hipStream_t>(stream), in, ldi, w, B, H, W, C, out, ldo);
   CDFO_LAUNCH_CHECK();
@@ -320,6 +323,7 @@ extern "C" int cdfo_flow_warp(const float* in, int ldi, const float* mv, long lo
                               float* out, int ldo, void* stream) {
   if (B <= 0 || C % 4 || ldi % 4 || ldo % 4) return CDFO_EINVAL;
   if (!aligned16(in) || !aligned16(out)) return CDFO_EALIGN;
+  CdfoProfScope prof(static_cast<hipStream_t>(stream), KID_FLOW_WARP, 0, 4.0*(2*C+2)*(double)B*H*W);
   hipLaunchKernelGGL(flow_warp_kernel, dim3(grid_for((long long)B * H * W * (C / 4))), dim3(256), 0,
                      static_cast<hipStream_t>(stream), in, ldi, mv, mv_bstride, B, H, W, C, out, ldo);
   CDFO_LAUNCH_CHECK();
@@ -330,6 +334,7 @@ extern "C" int cdfo_resample2(const float* in, int ldi, int B, int H, int W, int
                               int accumulate, void* stream) {
   if (B <= 0 || C % 4 || ldi % 4 || ldo % 4 || (!up && ((H | W) & 1))) return CDFO_EINVAL;
   if (!aligned16(in) || !aligned16(out)) return CDFO_EALIGN;
+  CdfoProfScope prof(static_cast<hipStream_t>(stream), KID_RESAMPLE, 0, 4.0*C*(double)B*H*W*(up?5.0:1.25));
   if (up)
     hipLaunchKernelGGL(up2_kernel, dim3(grid_for((long long)B * H * W * C)), dim3(256), 0,
                        static_cast<hipStream_t>(stream), in, ldi, B, H, W, C, out, ldo, accumulate);
@@ -344,6 +349,7 @@ extern "C" int cdfo_scale_channels(const float* in, int ldi, const float* gate, 
                                    int ldo, void* stream) {
   if (B <= 0 || C % 4 || ldi % 4 || ldo % 4) return CDFO_EINVAL;
   if (!aligned16(in) || !aligned16(out) || !aligned16(gate)) return CDFO_EALIGN;
+  CdfoProfScope prof(static_cast<hipStream_t>(stream), KID_SCALE, 0, 8.0*C*(double)B*P);
   hipLaunchKernelGGL(scale_channels_kernel, dim3(grid_for((long long)B * P * (C / 4))), dim3(256), 0,
                      static_cast<hipStream_t>(stream), in, ldi, gate, B, P, C, out, ldo);
   CDFO_LAUNCH_CHECK();
@@ -354,6 +360,7 @@ extern "C" int cdfo_conv_last(const float* in, int ldi, const float* w, const fl
                               long long xc_bstride, int B, int Hh, int Wh, float* out, void* stream) {
   if (B <= 0 || (Hh & 3) || (Wh & 3) || ldi % 4) return CDFO_EINVAL;
   if (!aligned16(in)) return CDFO_EALIGN;
+  CdfoProfScope prof(static_cast<hipStream_t>(stream), KID_CONV_LAST, 2.0*9*64*(double)B*Hh*Wh, 4.0*65*(double)B*Hh*Wh);
   hipLaunchKernelGGL(conv_last_kernel, dim3(grid_for((long long)B * Hh * Wh * 16)), dim3(256), 0,
                      static_cast<hipStream_t>(stream), in, ldi, w, bias, xc, xc_bstride, B, Hh, Wh, out);
   CDFO_LAUNCH_CHECK();

@@ -132,6 +132,7 @@ extern "C" int cdfo_small_conv16(const float* in, int ldi, const float* w, const
   if (Ho <= 0 || Wo <= 0) return CDFO_EINVAL;
   const int grid = grid_for((long long)B * Ho * Wo * 4);
   hipStream_t st = static_cast<hipStream_t>(stream);
+  CdfoProfScope prof(static_cast<hipStream_t>(stream), KID_SMALL_CONV, 2.0*9*256*(double)B*Ho*Wo, 4.0*16*((double)B*Ho*Wo+(double)B*H*W));
   if (transposed)
     hipLaunchKernelGGL((small_conv3x3_kernel<16, 16, true>), dim3(grid), dim3(256), 0, st, in, ldi, w, bias, B, H, W, Ho,
                        Wo, stride, pad, act, out, ldo);
@@ -146,6 +147,7 @@ extern "C" int cdfo_spatial_gate16(const float* in, int ldi, const float* w, con
                                    float* out, int ldo, void* stream) {
   if (B <= 0 || ldi % 4 || ldo % 4) return CDFO_EINVAL;
   if (!aligned16(in) || !aligned16(out)) return CDFO_EALIGN;
+  CdfoProfScope prof(static_cast<hipStream_t>(stream), KID_SPATIAL_GATE, 0, 4.0*32*(double)B*H*W);
   hipLaunchKernelGGL(spatial_gate16_kernel, dim3(grid_for((long long)B * H * W)), dim3(256), 0,
                      static_cast<hipStream_t>(stream), in, ldi, w, bias, B, H, W, out, ldo);
   CDFO_LAUNCH_CHECK();

@@ -212,6 +212,7 @@ __global__ __launch_bounds__(64) void vec_mlp_kernel(const float* __restrict__ s
 extern "C" int cdfo_chan_sum_partial(const float* in, int ldi, int B, long long P, int nchunk, float* partial,
                                      void* stream) {
   if (B <= 0 || P <= 0 || nchunk <= 0) return CDFO_EINVAL;
+  CdfoProfScope prof(static_cast<hipStream_t>(stream), KID_CHAN_SUM, 0, 4.0*64*(double)B*P);
   hipLaunchKernelGGL(chan_sum_partial_kernel, dim3(nchunk, B), dim3(256), 0, static_cast<hipStream_t>(stream), in, ldi,
                      P, nchunk, partial);
   CDFO_LAUNCH_CHECK();
@@ -223,6 +224,7 @@ extern "C" int cdfo_gram_partial(const float* q, int ldq, const float* k, int ld
   if (B <= 0 || P <= 0 || nchunk <= 0 || ldk % 4) return CDFO_EINVAL;
   if (!aligned16(k)) return CDFO_EALIGN;
   hipStream_t st = static_cast<hipStream_t>(stream);
+  CdfoProfScope prof(static_cast<hipStream_t>(stream), KID_GRAM, 2.0*64*(ch_per_head+2)*(double)B*P, 4.0*128*(double)B*P);
   if (ch_per_head == 8)
     hipLaunchKernelGGL(gram_partial_kernel<8>, dim3(nchunk, B), dim3(256), 0, st, q, ldq, k, ldk, P, nchunk, partial);
   else if (ch_per_head == 16)
@@ -236,6 +238,7 @@ extern "C" int cdfo_gram_partial(const float* q, int ldq, const float* k, int ld
 extern "C" int cdfo_mdta_fold(const float* partial, int nchunk, const float* temperature, const float* proj_w, int B,
                               float* wout, void* stream) {
   if (B <= 0 || nchunk <= 0) return CDFO_EINVAL;
+  CdfoProfScope prof(static_cast<hipStream_t>(stream), KID_FOLD, 0, 0);
   hipLaunchKernelGGL(mdta_fold_kernel, dim3(B), dim3(256), 0, static_cast<hipStream_t>(stream), partial, nchunk,
                      temperature, proj_w, wout);
   CDFO_LAUNCH_CHECK();
@@ -247,6 +250,7 @@ extern "C" int cdfo_align_fold(const float* gram_partial, int nchunk_g, const fl
                                const float* du0_b, const float* du2_w, const float* du2_b, const float* proj_w,
                                const float* fusion_w, int B, float* wout, void* stream) {
   if (B <= 0 || nchunk_g <= 0 || nchunk_s <= 0 || P <= 0) return CDFO_EINVAL;
+  CdfoProfScope prof(static_cast<hipStream_t>(stream), KID_FOLD, 0, 0);
   hipLaunchKernelGGL(align_fold_kernel, dim3(B), dim3(256), 0, static_cast<hipStream_t>(stream), gram_partial, nchunk_g,
                      sum_warp, sum_pred, nchunk_s, 1.0f / (float)P, temperature, du0_w, du0_b, du2_w, du2_b, proj_w,
                      fusion_w, wout);
@@ -258,6 +262,7 @@ extern "C" int cdfo_vec_mlp(const float* sum_partial, int nchunk, long long P, c
                             int act1, const float* w2, const float* b2, int c2, int act2, int B, float* out,
                             void* stream) {
   if (B <= 0 || nchunk <= 0 || c1 <= 0 || c1 > 64 || (w2 && (c2 <= 0 || c2 > 64))) return CDFO_EINVAL;
+  CdfoProfScope prof(static_cast<hipStream_t>(stream), KID_FOLD, 0, 0);
   hipLaunchKernelGGL(vec_mlp_kernel, dim3(B), dim3(64), 0, static_cast<hipStream_t>(stream), sum_partial, nchunk,
                      1.0f / (float)P, w1, b1, c1, act1, w2, b2, c2, act2, out);
   CDFO_LAUNCH_CHECK();

@@ -118,6 +118,11 @@ int cdfo_colconv9(const float* in, int ldi, const float* wH, const float* bH, in
 int cdfo_seq_attn(const float* q, int ldq, const float* v, int ldv, float* out, int ldo, int B, int H, int W, int mode,
                   void* stream);
 
+/* ---- optional per-launch HIP-event timing on the launch stream (bench.py's live roofline figures) ----------- */
+int cdfo_prof_begin(int max_records);
+int cdfo_prof_end(int* launches, double* ms, double* flops, double* bytes, int nkid);
+int cdfo_prof_kid_count(void);
+
 #ifdef __cplusplus
 }
 #endif

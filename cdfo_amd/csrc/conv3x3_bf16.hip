@@ -1,0 +1,257 @@
+// 3x3 stride-1 convolution on the bf16 matrix cores (v_mfma_f32_32x32x16_bf16) with fp32 accumulation.
+//
+//   PREC_BF16X3 : split-bf16 ("3-pass") arithmetic.  Every fp32 operand x is held as hi = bf16(x) and
+//                 lo = bf16(x - hi); a product is a_hi*w_hi + a_lo*w_hi + a_hi*w_lo (the lo*lo term, 2^-16 relative,
+//                 is dropped).  Max-abs error of the whole CVSR_V8 forward vs the fp32 reference stays ~1e-5, i.e.
+//                 inside the 1e-3 parity bound, at 16/3 of the exact-fp32 MFMA rate.
+//   PREC_BF16   : plain bf16 operands (one pass) -- the BASELINE "bf16" configuration; ~6e-3 max-abs on the forward.
+//
+// Structure (one 256-thread workgroup = 16x16 output pixels x 64 output channels, 2 workgroups per CU):
+//   per 16-input-channel chunk: the 18x18x16 input halo tile is fetched as fp32 float4s into REGISTERS while the
+//   previous chunk's MFMAs run (register-staged double buffering: global latency hides under the matrix pipe), then
+//   converted to bf16 hi/lo and written to LDS (80-byte pixel records: 32 B hi | 32 B lo | 16 B pad, conflict-free
+//   ds_read_b128); the pre-split bf16 weight slab [tap][k-half][cout][8] is copied the same way.  Each lane feeds
+//   12 MFMAs (2x2 register tile x 3 passes) from 8 ds_read_b128 per tap.  No im2col buffer, no HBM intermediates.
+//
+// Replaces F.conv2d for the 3x3 convolutions with >= 64 output channels on the CVSR_V8 path
+// (arch/SIDECVSR_our.py:383-387 Block_.body -- 89 % of the forward's FLOPs --, :435, :1447, :261-262, :4382).
+#include "common.h"
+
+namespace {
+
+constexpr int TH = 16, TW = 16, IW = 18, NPIX = 18 * 18;
+constexpr int PIXB = 80;                         // LDS bytes per staged pixel
+constexpr int A_BYTES = NPIX * PIXB;             // 25,920
+constexpr int W_HALF = 9 * 2 * 64 * 16;          // 18,432 B: [tap][h][64 cout][8 bf16]
+constexpr int NA = (NPIX * 4 + 255) / 256;       // 6 float4 per thread per chunk
+constexpr int NW_X3 = 2 * W_HALF / 16 / 256;     // 9 x 16 B per thread (hi + lo)
+constexpr int NW_X1 = W_HALF / 16 / 256;         // 4.5 -> handled as 5 with a guard
+
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ unsigned pack_bf16(float a, float b) {
+  const __bf16 ha = (__bf16)a, hb = (__bf16)b;
+  return (unsigned)__builtin_bit_cast(unsigned short, ha) | ((unsigned)__builtin_bit_cast(unsigned short, hb) << 16);
+}
+__device__ __forceinline__ float bf16_round(float a) { return (float)(__bf16)a; }
+
+template <bool X3>
+__global__ __launch_bounds__(256, 2) void conv3x3_bf16_kernel(cdfo_conv_args a) {
+  constexpr int LDS_W = X3 ? 2 * W_HALF : W_HALF;
+  constexpr int NWS = X3 ? NW_X3 : NW_X1 + 1;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[A_BYTES + LDS_W];
+  unsigned char* sA = smem;
+  unsigned char* sW = smem + A_BYTES;
+
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, h = lane >> 5, r = lane & 31;
+  const int tiles_x = (a.Wo + TW - 1) / TW;
+  const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
+  const int oy0 = ty * TH, ox0 = tx * TW, n0 = blockIdx.y * 64, b = blockIdx.z;
+  const unsigned short* wq = reinterpret_cast<const unsigned short*>(a.w);
+  const long long lo_off = (long long)(a.Cin / 16) * 18 * a.CoutP * 8;  // elements from the hi block to the lo block
+
+  // ---- per-thread staging descriptors (chunk independent)
+  int a_pix[NA];   // global pixel index or -1 (outside the image => conv zero padding)
+  int a_lds[NA];   // LDS byte offset of the hi half
+#pragma unroll
+  for (int s = 0; s < NA; ++s) {
+    const int idx = tid + 256 * s;
+    const int p = idx >> 2, q = idx & 3;
+    const int iy = p / IW, ix = p - iy * IW;
+    const int gy = oy0 - 1 + iy, gx = ox0 - 1 + ix;
+    const bool ok = idx < NPIX * 4 && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+    a_pix[s] = ok ? (b * a.H + gy) * a.W + gx : -1;
+    a_lds[s] = idx < NPIX * 4 ? p * PIXB + q * 8 : -1;
+  }
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[mi][ni][e] = 0.f;
+
+  int a_off[2];
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi) {
+    const int m = wave * 2 + mi;
+    a_off[mi] = ((2 * m + (r >> 4)) * IW + (r & 15)) * PIXB + h * 16;
+  }
+  const int b_off = (h * 64 + r) * 16;
+
+  f32x4 ra[NA];
+  u32x4 rw[NWS];
+  const int nchunks = a.Cin / 16;
+  int s_idx = 0, s_base = 0;
+
+  auto issue_loads = [&](int c) {
+    const int ch0 = c * 16;
+    while (ch0 >= s_base + a.cs[s_idx]) { s_base += a.cs[s_idx]; ++s_idx; }
+    const float* src = a.src[s_idx] + (ch0 - s_base);
+    const int ld = a.ld[s_idx];
+#pragma unroll
+    for (int s = 0; s < NA; ++s) {
+      const int q = (tid + 256 * s) & 3;
+      ra[s] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (a_pix[s] >= 0) ra[s] = *reinterpret_cast<const f32x4*>(src + (long long)a_pix[s] * ld + q * 4);
+    }
+#pragma unroll
+    for (int s = 0; s < NWS; ++s) {
+      const int idx = tid + 256 * s;          // 16-byte unit inside the [hi rows | lo rows] slab
+      const int row = idx >> 6, n = idx & 63;  // row = (tap*2+h) (+18 for lo)
+      if (X3 || idx < W_HALF / 16) {
+        const int rr = row >= 18 ? row - 18 : row;
+        const unsigned short* g = wq + (row >= 18 ? lo_off : 0) + ((long long)(c * 18 + rr) * a.CoutP + n0 + n) * 8;
+        rw[s] = *reinterpret_cast<const u32x4*>(g);
+      }
+    }
+  };
+  auto write_lds = [&]() {
+#pragma unroll
+    for (int s = 0; s < NA; ++s) {
+      if (a_lds[s] < 0) continue;
+      const f32x4 v = ra[s];
+      u32x2 hi, lo;
+      hi[0] = pack_bf16(v[0], v[1]);
+      hi[1] = pack_bf16(v[2], v[3]);
+      *reinterpret_cast<u32x2*>(sA + a_lds[s]) = hi;
+      if (X3) {
+        lo[0] = pack_bf16(v[0] - bf16_round(v[0]), v[1] - bf16_round(v[1]));
+        lo[1] = pack_bf16(v[2] - bf16_round(v[2]), v[3] - bf16_round(v[3]));
+        *reinterpret_cast<u32x2*>(sA + a_lds[s] + 32) = lo;
+      }
+    }
+#pragma unroll
+    for (int s = 0; s < NWS; ++s) {
+      const int idx = tid + 256 * s;
+      if (X3 || idx < W_HALF / 16) *reinterpret_cast<u32x4*>(sW + idx * 16) = rw[s];
+    }
+  };
+
+  issue_loads(0);
+  write_lds();
+  __syncthreads();
+  for (int c = 0; c < nchunks; ++c) {
+    if (c + 1 < nchunks) issue_loads(c + 1);  // in flight while the MFMAs below run
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      const int dy = t / 3, dx = t - dy * 3;
+      bf16x8_t ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi) {
+        ah[mi] = *reinterpret_cast<const bf16x8_t*>(sA + a_off[mi] + (dy * IW + dx) * PIXB);
+        if (X3) al[mi] = *reinterpret_cast<const bf16x8_t*>(sA + a_off[mi] + (dy * IW + dx) * PIXB + 32);
+      }
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni) {
+        bh[ni] = *reinterpret_cast<const bf16x8_t*>(sW + (t * 2 * 64 + ni * 32) * 16 + b_off);
+        if (X3) bl[ni] = *reinterpret_cast<const bf16x8_t*>(sW + W_HALF + (t * 2 * 64 + ni * 32) * 16 + b_off);
+      }
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) {
+          if (X3) {
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[mi], bh[ni], acc[mi][ni], 0, 0, 0);
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mi], bl[ni], acc[mi][ni], 0, 0, 0);
+          }
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mi], bh[ni], acc[mi][ni], 0, 0, 0);
+        }
+    }
+    __syncthreads();  // everyone is done reading this chunk's LDS image
+    if (c + 1 < nchunks) {
+      write_lds();
+      __syncthreads();
+    }
+  }
+
+  // ---- epilogue (identical contract to conv_igemm_f32): +bias -> act -> +res1 -> +res2 -> store
+#pragma unroll
+  for (int ni = 0; ni < 2; ++ni) {
+    const int n = n0 + ni * 32 + r;
+    if (n >= a.Cout) continue;
+    const float bias = a.bias ? a.bias[n] : 0.f;
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) {
+      const int m = wave * 2 + mi;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int i = (e & 3) + 8 * (e >> 2) + 4 * h;
+        const int oy = oy0 + 2 * m + (i >> 4), ox = ox0 + (i & 15);
+        if (oy >= a.Ho || ox >= a.Wo) continue;
+        const long long pix = (long long)(b * a.Ho + oy) * a.Wo + ox;
+        float v = act_apply(acc[mi][ni][e] + bias, a.act);
+        if (a.res1) v += a.res1[pix * a.ldr1 + n];
+        if (a.res2) v += a.res2[pix * a.ldr2 + n];
+        a.out[pix * a.ldo + n] = v;
+      }
+    }
+  }
+}
+
+// OIHW fp32 -> [hi | lo] bf16, each [Cin/16][9][2][CoutP][8]  (k = 16*chunk + 8*h + j)
+__global__ void pack_bf16_kernel(const float* __restrict__ w, unsigned short* __restrict__ p, int Cout, int Cin,
+                                 int CoutP) {
+  const long long half = (long long)(Cin / 16) * 18 * CoutP * 8;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < half;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int j = i & 7;
+    long long rest = i >> 3;
+    const int n = rest % CoutP; rest /= CoutP;
+    const int hh = rest & 1; rest >>= 1;
+    const int t = rest % 9;
+    const int c = rest / 9;
+    const int cin = c * 16 + hh * 8 + j;
+    float v = 0.f;
+    if (n < Cout) v = w[((long long)n * Cin + cin) * 9 + t];
+    const __bf16 hi = (__bf16)v;
+    const __bf16 lo = (__bf16)(v - (float)hi);
+    p[i] = __builtin_bit_cast(unsigned short, hi);
+    p[half + i] = __builtin_bit_cast(unsigned short, lo);
+  }
+}
+
+}  // namespace
+
+extern "C" int cdfo_conv3x3_bf16(const cdfo_conv_args* pa, void* stream) {
+  const cdfo_conv_args& a = *pa;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (a.nsrc < 1 || a.nsrc > CDFO_MAXSRC || a.B <= 0 || a.ks != 3 || a.stride != 1 || a.pad != 1) return CDFO_EINVAL;
+  int csum = 0;
+  for (int s = 0; s < a.nsrc; ++s) {
+    if (a.cs[s] <= 0 || a.cs[s] % 16 || a.ld[s] % 4 || a.ld[s] < a.cs[s]) return CDFO_EINVAL;
+    if (!aligned16(a.src[s])) return CDFO_EALIGN;
+    csum += a.cs[s];
+  }
+  if (csum != a.Cin || a.CoutP % 64 || a.CoutP < a.Cout || a.Cout <= 0 || a.Ho != a.H || a.Wo != a.W) return CDFO_EINVAL;
+  if (a.store_mode != CDFO_STORE_PLAIN || a.w_bstride != 0) return CDFO_EINVAL;
+  if (!aligned16(a.w)) return CDFO_EALIGN;
+  if ((long long)a.B * a.H * a.W >= (1ll << 31)) return CDFO_EINVAL;
+  dim3 grid(cdiv(a.Wo, TW) * cdiv(a.Ho, TH), a.CoutP / 64, a.B);
+  const double px = (double)a.B * a.Ho * a.Wo;
+  CdfoProfScope prof(st, KID_CONV3_WIDE, 2.0 * px * a.Cout * a.Cin * 9,
+                     4.0 * (px * a.Cout + px * a.Cin + 9.0 * a.Cin * a.Cout));
+  if (a.prec == CDFO_PREC_BF16X3)
+    hipLaunchKernelGGL(conv3x3_bf16_kernel<true>, grid, dim3(256), 0, st, a);
+  else if (a.prec == CDFO_PREC_BF16)
+    hipLaunchKernelGGL(conv3x3_bf16_kernel<false>, grid, dim3(256), 0, st, a);
+  else
+    return CDFO_EINVAL;
+  CDFO_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int cdfo_pack_conv3x3_bf16(const float* w_oihw, void* packed, int Cout, int Cin, void* stream) {
+  if (Cin % 16 || Cout <= 0) return CDFO_EINVAL;
+  const int CoutP = (Cout + 63) / 64 * 64;
+  const long long half = (long long)(Cin / 16) * 18 * CoutP * 8;
+  const int blocks = (int)((half + 255) / 256 < 2048 ? (half + 255) / 256 : 2048);
+  CdfoProfScope prof(static_cast<hipStream_t>(stream), KID_PACK, 0, 8.0 * half);
+  hipLaunchKernelGGL(pack_bf16_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream), w_oihw,
+                     static_cast<unsigned short*>(packed), Cout, Cin, CoutP);
+  CDFO_LAUNCH_CHECK();
+  return 0;
+}

@@ -11,6 +11,8 @@ Differences, all deliberate:
   * ``gumbel_uniform=`` (kwarg or attribute): the six uniform draws of ``LLongRangAttention.gumbel_softmax``
     (arch.py:2169) may be injected as six ``[B,64,H,W]`` tensors; default is to draw them with ``torch.rand`` like
     the reference.
+  * ``precision`` attribute: "f32" | "bf16x3" (default) | "bf16" selects the matrix-core arithmetic of the wide 3x3
+    convolutions; "f32" and "bf16x3" both meet the 1e-3 max-abs parity bound against the fp32 reference.
   * the debug side effects of the reference forward (``featuremap_visual`` PNG dumps, arch.py:4450-4475) are absent.
   * ``L1_fea`` is returned as a ``[B*7,64,H,W]`` tensor in channels-last memory format (a view of the kernels'
     pixel-major buffer); feeding it back as ``pre_L1_fea`` needs no conversion.  Plain NCHW tensors are accepted too.
@@ -120,6 +122,10 @@ class CVSR_V8(nn.Module):
             raise ValueError("the HIP path is specialised for nf=64, nframes=7 (the only configuration the reference runs)")
         self.nf, self.center, self.istraining, self.stride = nf, nframes // 2, istraining, 4
         self.gumbel_uniform: Optional[Sequence[torch.Tensor]] = None
+        # arithmetic of the wide 3x3 convolutions (89 % of the FLOPs):
+        #   "f32"    exact fp32 MFMA;  "bf16x3" split-bf16 3-pass MFMA (fp32-grade: ~1e-5 max-abs on the forward, default);
+        #   "bf16"   plain bf16 MFMA with fp32 accumulation (BASELINE's bf16 configuration, ~6e-3 max-abs).
+        self.precision = "bf16x3"
         for key, shape, fan_in, init in _param_spec():
             t = torch.empty(shape)
             if init == "default":
@@ -176,17 +182,23 @@ class CVSR_V8(nn.Module):
         self._packed, self._packed_sig = w, sig
         return w
 
+    # -- arithmetic of the 3x3 convolutions ---------------------------------------------------------------------
+    PRECISIONS = {"f32": K.PREC_F32, "bf16x3": K.PREC_BF16X3, "bf16": K.PREC_BF16}
+
+    def _conv(self, *args, **kw):
+        return K.conv(*args, prec=self.PRECISIONS[self.precision], **kw)
+
     # -- building blocks ------------------------------------------------------------------------------------------
     def _udsa(self, w, x2, res):
         raw = w["raw"]
         u = "transformer_feature_extraction.path1.side_to_feaoneUDSA.body."
-        t = K.conv(x2, w[u + "0"], pad=1, act=K.ACT_LRELU)
+        t = self._conv(x2, w[u + "0"], pad=1, act=K.ACT_LRELU)
         t = K.small_conv16(t, raw[u + "2.weight"], raw[u + "2.bias"], 2, 2, act=K.ACT_LRELU)
         t = K.small_conv16(t, raw[u + "4.weight"], raw[u + "4.bias"], 2, 2, act=K.ACT_LRELU)
         t = K.spatial_gate16(t, raw[u + "6.spatial.weight"], raw[u + "6.spatial.bias"])
         t = K.small_conv16(t, raw[u + "7.weight"], raw[u + "7.bias"], 2, 2, 0, True, K.ACT_LRELU)
         t = K.small_conv16(t, raw[u + "9.weight"], raw[u + "9.bias"], 2, 2, 1, True, K.ACT_LRELU)
-        return K.conv(t, w[u + "11"], pad=1, act=K.ACT_LRELU, res1=res)
+        return self._conv(t, w[u + "11"], pad=1, act=K.ACT_LRELU, res1=res)
 
     def _feature_extraction(self, w, x1, x2):
         raw = w["raw"]
@@ -194,67 +206,67 @@ class CVSR_V8(nn.Module):
         for rnd in range(3):
             x2 = self._udsa(w, x2, x1 if rnd == 0 else x2)
             ln = K.layernorm64(x1, raw[p + "norm1.body.weight"], raw[p + "norm1.body.bias"])
-            qkv = K.dwconv3x3(K.conv(ln, w[p + "attn.qkv"]), raw[p + "attn.qkv_dwconv.weight"])
+            qkv = K.dwconv3x3(self._conv(ln, w[p + "attn.qkv"]), raw[p + "attn.qkv_dwconv.weight"])
             part, n = K.gram_partial(qkv[..., 0:64], qkv[..., 64:128], 8)
             fold = K.mdta_fold(part, n, raw[p + "attn.temperature"], raw[p + "attn.project_out.weight"])
-            x1 = K.conv(qkv[..., 128:192], fold, res1=x1)
+            x1 = self._conv(qkv[..., 128:192], fold, res1=x1)
             ln = K.layernorm64(x1, raw[p + "norm2.body.weight"], raw[p + "norm2.body.bias"])
-            x1 = K.conv(ln, w[p + "conv"], pad=1, res1=x1, res2=x2)
+            x1 = self._conv(ln, w[p + "conv"], pad=1, res1=x1, res2=x2)
         return x1
 
     def _rdab(self, w, res, x, noise):
         raw = w["raw"]
         B, H, W, _ = x.shape
-        t = K.conv(res, w["RDAB.conv_du_re.0"], act=K.ACT_RELU)
-        t = K.conv(t, w["RDAB.conv_du_re.2"], stride=2, pad=2, act=K.ACT_RELU)
+        t = self._conv(res, w["RDAB.conv_du_re.0"], act=K.ACT_RELU)
+        t = self._conv(t, w["RDAB.conv_du_re.2"], stride=2, pad=2, act=K.ACT_RELU)
         part, n = K.chan_sum_partial(t)
         vmax = K.vec_mlp(part, n, t.shape[1] * t.shape[2], raw["RDAB.conv_du_re2.0.weight"],
                          raw["RDAB.conv_du_re2.0.bias"], 64, K.ACT_RELU)
-        xq = K.conv(x, w["RDAB.input_conv"])
+        xq = self._conv(x, w["RDAB.input_conv"])
         sq, vrow, qwin = K.rdab_prep(xq, vmax, noise, raw["RDAB.directW1_conv.weight"], raw["RDAB.directW1_conv.bias"])
         cat = K.empty_act(B, H, W, 128, x.device)
         rowo = K.seq_attn(sq, vrow, 0)
         qc = K.colconv9(sq, raw["RDAB.directH1_conv.weight"], raw["RDAB.directH1_conv.bias"])
         K.seq_attn(qc, rowo, 1, out=cat[..., 0:64])
         K.seq_attn(qwin, xq[..., 64:128], 2, out=cat[..., 64:128])
-        return K.conv(cat, w["RDAB.fuse"], res1=x)
+        return self._conv(cat, w["RDAB.fuse"], res1=x)
 
     def _align(self, w, xc, extra, pred, mv, mv_bstride, out):
         raw = w["raw"]
         a = "MV_deform_align."
         B, H, W, _ = xc.shape
         warped = K.flow_warp(extra, mv, mv_bstride)
-        kf = K.conv([warped, pred], w[a + "fusion_out.0"], act=K.ACT_RELU)
+        kf = self._conv([warped, pred], w[a + "fusion_out.0"], act=K.ACT_RELU)
         gp, ng = K.gram_partial(xc, kf, 16)
         sw, ns = K.chan_sum_partial(warped)
         sp, _ = K.chan_sum_partial(pred)
         fold = K.align_fold(gp, ng, sw, sp, ns, H * W, raw[a + "temperature"], raw[a + "conv_du.0.weight"],
                             raw[a + "conv_du.0.bias"], raw[a + "conv_du.2.weight"], raw[a + "conv_du.2.bias"],
                             raw[a + "project_out.weight"], raw[a + "fusion_out.0.weight"])
-        o = K.conv([warped, pred, xc], fold, act=K.ACT_RELU)
+        o = self._conv([warped, pred, xc], fold, act=K.ACT_RELU)
         part, n = K.chan_sum_partial(o)
         gate = K.vec_mlp(part, n, H * W, raw[a + "CALayer.conv_du.0.weight"], raw[a + "CALayer.conv_du.0.bias"], 64,
                          K.ACT_RELU, raw[a + "CALayer.conv_du.2.weight"], raw[a + "CALayer.conv_du.2.bias"], 64,
                          K.ACT_SIGMOID)
         o = K.scale_channels(o, gate)
-        r = K.conv(o, w[a + "ResidualBlock.conv1"], pad=1, act=K.ACT_RELU)
-        o = K.conv(r, w[a + "ResidualBlock.conv2"], pad=1, res1=o)
-        r = K.conv(o, w[a + "ResidualBlock1.conv1"], pad=1, act=K.ACT_RELU)
-        return K.conv(r, w[a + "ResidualBlock1.conv2"], pad=1, res1=o, res2=xc, out=out)
+        r = self._conv(o, w[a + "ResidualBlock.conv1"], pad=1, act=K.ACT_RELU)
+        o = self._conv(r, w[a + "ResidualBlock.conv2"], pad=1, res1=o)
+        r = self._conv(o, w[a + "ResidualBlock1.conv1"], pad=1, act=K.ACT_RELU)
+        return self._conv(r, w[a + "ResidualBlock1.conv2"], pad=1, res1=o, res2=xc, out=out)
 
     def _block(self, w, p, x):
         """Block_ (arch.py:378-406): x + body(x) + up(body(down(x))) + down(body(up(x))).
         The 1x1 convs commute with the (linear) resampling, so they run on the smaller side of it."""
         b0, b2, dn, up = w[p + "body.0"], w[p + "body.2"], w[p + "down.0"], w[p + "up.0"]
-        out = K.conv(K.conv(x, b0, pad=1, act=K.ACT_LRELU), b2, pad=1, res1=x)
+        out = self._conv(self._conv(x, b0, pad=1, act=K.ACT_LRELU), b2, pad=1, res1=x)
         # half-resolution branch
-        d = K.conv(K.resample2(x, up=False), dn)
-        d = K.conv(K.conv(d, b0, pad=1, act=K.ACT_LRELU), b2, pad=1)
-        K.resample2(K.conv(d, up), up=True, out=out, accumulate=True)
+        d = self._conv(K.resample2(x, up=False), dn)
+        d = self._conv(self._conv(d, b0, pad=1, act=K.ACT_LRELU), b2, pad=1)
+        K.resample2(self._conv(d, up), up=True, out=out, accumulate=True)
         # double-resolution branch
-        u = K.resample2(K.conv(x, up), up=True)
-        u = K.conv(K.conv(u, b0, pad=1, act=K.ACT_LRELU), b2, pad=1)
-        return K.conv(K.resample2(u, up=False), dn, res1=out)
+        u = K.resample2(self._conv(x, up), up=True)
+        u = self._conv(self._conv(u, b0, pad=1, act=K.ACT_LRELU), b2, pad=1)
+        return self._conv(K.resample2(u, up=False), dn, res1=out)
 
     def _trunk(self, w, fused):
         y = fused
@@ -262,7 +274,7 @@ class CVSR_V8(nn.Module):
             r = y
             for b in range(3):
                 r = self._block(w, f"recon_trunk.body.{g}.body.{b}.", r)
-            y = K.conv(r, w[f"recon_trunk.body.{g}.conv"], pad=1, res1=y, res2=fused if g == 6 else None)
+            y = self._conv(r, w[f"recon_trunk.body.{g}.conv"], pad=1, res1=y, res2=fused if g == 6 else None)
         return y
 
     # -- forward ---------------------------------------------------------------------------------------------------
@@ -328,18 +340,18 @@ class CVSR_V8(nn.Module):
             if self.debug_taps is not None:
                 self.debug_taps[f"rdab_{i}"] = x_n
                 self.debug_taps[f"align_{i}"] = al_ref = K.empty_act(B, H, W, NF, x.device)
-            fea_i = K.conv([Lf[i], x_n], w["conv_expand_fea_r"], pad=1)
+            fea_i = self._conv([Lf[i], x_n], w["conv_expand_fea_r"], pad=1)
             al = al_ref if self.debug_taps is not None else K.empty_act(B, H, W, NF, x.device)
             self._align(w, Lf[ctr], fea_i, ufs_prior, mvs1[:, i], N * 2 * P, al)
             aligned.append(al)
 
         # 3. temporal fusion, 4. reconstruction trunk, 5. upsampling + skip (arch.py:4463-4481)
-        fused = K.conv(aligned, w["tsa_fusion"], act=K.ACT_LRELU)
+        fused = self._conv(aligned, w["tsa_fusion"], act=K.ACT_LRELU)
         t = self._trunk(w, fused)
         if self.debug_taps is not None:
             self.debug_taps.update(L1_fea=L1, fused=fused, trunk=t)
-        t = K.conv(t, w["upconv1"], act=K.ACT_LRELU)
-        t = K.conv(t, w["upconv2"], act=K.ACT_LRELU)
+        t = self._conv(t, w["upconv1"], act=K.ACT_LRELU)
+        t = self._conv(t, w["upconv2"], act=K.ACT_LRELU)
         out = K.conv_last(t, raw["conv_last.weight"], raw["conv_last.bias"], x[:, ctr], N * P)
         return out, L1.permute(0, 3, 1, 2)
 

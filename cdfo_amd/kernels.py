@@ -15,6 +15,7 @@ from . import _lib
 from ._lib import ConvArgs, check
 
 ACT_NONE, ACT_LRELU, ACT_RELU, ACT_SIGMOID = 0, 1, 2, 3
+PREC_F32, PREC_BF16X3, PREC_BF16 = 0, 1, 2
 
 
 def _stream() -> C.c_void_p:
@@ -73,6 +74,7 @@ class PackedConv:
     CoutP: int
     shuffle2: bool = False
     w_bstride: int = 0
+    wq: Optional[torch.Tensor] = None   # split-bf16 packing for cdfo_conv3x3_bf16 (3x3, Cout % 64 == 0)
 
 
 def pack_conv(weight: torch.Tensor, bias: Optional[torch.Tensor], shuffle2: bool = False,
@@ -93,12 +95,18 @@ def pack_conv(weight: torch.Tensor, bias: Optional[torch.Tensor], shuffle2: bool
         if shuffle2:
             cq = Cout // 4
             b = b.view(cq, 4).t().contiguous().view(-1)
-    return PackedConv(packed, b, Cout, Cin, ks, CoutP, shuffle2)
+    pc = PackedConv(packed, b, Cout, Cin, ks, CoutP, shuffle2)
+    if ks == 3 and not transposed and not shuffle2 and Cout % 64 == 0 and Cin % 16 == 0:
+        wq = torch.empty(2 * (Cin // 16) * 18 * Cout * 8, dtype=torch.bfloat16, device=w.device)
+        check(_lib.lib().cdfo_pack_conv3x3_bf16(C.c_void_p(w.data_ptr()), C.c_void_p(wq.data_ptr()), Cout, Cin,
+                                                _stream()), "cdfo_pack_conv3x3_bf16")
+        pc.wq = wq
+    return pc
 
 
 def conv(srcs: Sequence[torch.Tensor], pc: PackedConv, *, stride: int = 1, pad: int = 0, act: int = ACT_NONE,
          res1: Optional[torch.Tensor] = None, res2: Optional[torch.Tensor] = None,
-         out: Optional[torch.Tensor] = None) -> torch.Tensor:
+         out: Optional[torch.Tensor] = None, prec: int = PREC_F32) -> torch.Tensor:
     if isinstance(srcs, torch.Tensor):
         srcs = [srcs]
     a = ConvArgs()
@@ -143,6 +151,11 @@ def conv(srcs: Sequence[torch.Tensor], pc: PackedConv, *, stride: int = 1, pad: 
                 raise ValueError(f"{nm} shape {tuple(r.shape)} does not match the conv output")
             setattr(a, nm, r.data_ptr())
             setattr(a, "ldr" + nm[-1], rld)
+    if (prec != PREC_F32 and pc.wq is not None and stride == 1 and pad == 1 and pc.w_bstride == 0):
+        a.prec = prec
+        a.w = pc.wq.data_ptr()
+        check(_lib.lib().cdfo_conv3x3_bf16(C.byref(a), _stream()), "cdfo_conv3x3_bf16")
+        return out
     a.prec = 0
     check(_lib.lib().cdfo_conv_igemm(C.byref(a), _stream()), "cdfo_conv_igemm")
     return out

@@ -57,6 +57,12 @@ int cdfo_conv_igemm(const cdfo_conv_args* a, void* stream);
 int cdfo_pack_conv_weight(const float* w_oihw, float* packed, int Cout, int Cin, int ks, int shuffle2,
                           int transposed, void* stream);
 
+/* 3x3 / stride 1 / pad 1 convolution on the bf16 matrix cores, fp32 accumulate; same argument block and epilogue as
+ * cdfo_conv_igemm.  a->prec = CDFO_PREC_BF16X3 (split-bf16, fp32-grade accuracy) or CDFO_PREC_BF16 (plain bf16);
+ * a->w = weights packed by cdfo_pack_conv3x3_bf16 ([hi|lo] x [Cin/16][9][2][CoutP][8] bf16, CoutP = Cout up to 64).  */
+int cdfo_conv3x3_bf16(const cdfo_conv_args* a, void* stream);
+int cdfo_pack_conv3x3_bf16(const float* w_oihw, void* packed, int Cout, int Cin, void* stream);
+
 /* Layout changes at the module boundary (reference tensors are NCHW).  */
 int cdfo_nchw_to_nhwc(const float* in, float* out, int B, int C, int H, int W, int ldo, void* stream);
 int cdfo_nhwc_to_nchw(const float* in, int ldi, float* out, int B, int C, int H, int W, void* stream);

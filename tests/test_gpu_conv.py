@@ -104,3 +104,25 @@ def test_layout_roundtrip():
     assert torch.equal(y.cpu(), x.permute(0, 2, 3, 1).contiguous())
     z = K.nhwc_to_nchw(y)
     assert torch.equal(z.cpu(), x)
+
+
+@pytest.mark.parametrize("Cin,Cout,H,W,B", [(64, 256, 24, 40, 1), (256, 64, 20, 18, 2), (128, 64, 16, 16, 1), (64, 64, 33, 17, 1)])
+@pytest.mark.parametrize("prec,tol", [(1, 3e-5), (2, 2e-2)])
+def test_conv3x3_bf16_family(Cin, Cout, H, W, B, prec, tol):
+    from cdfo_amd import kernels as K
+    g = torch.Generator().manual_seed(Cin + Cout + H + prec)
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / (Cin * 9) ** 0.5
+    b = torch.randn(Cout, generator=g)
+    r1 = torch.randn(B, Cout, H, W, generator=g)
+    ref = F.leaky_relu(F.conv2d(x, w, b, padding=1), 0.1) + r1
+    pc = K.pack_conv(w.cuda(), b.cuda())
+    assert pc.wq is not None
+    if Cin == 128:
+        xs = _nhwc(x).cuda()
+        srcs = [xs[..., :64].contiguous(), xs[..., 64:]]          # two sources, the second a strided slice
+    else:
+        srcs = [_nhwc(x).cuda()]
+    out = K.conv(srcs, pc, pad=1, act=K.ACT_LRELU, res1=_nhwc(r1).cuda(), prec=prec)
+    torch.cuda.synchronize()
+    _cmp(out, ref, tol, f"conv3x3 prec={prec}")

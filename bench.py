@@ -116,14 +116,8 @@ def main():
         raise SystemExit(f"cdfo_prof_end failed: {nrec}")
 
     # ---- the single collective: all_gather of per-rank metrics (time, checksum, parity)
-    mine = torch.tensor([elapsed, out.double().mean().item(), max_abs, psnr if psnr != float("inf") else 999.0],
-                        dtype=torch.float64, device=dev)
-    if world > 1:
-        allm = [torch.empty_like(mine) for _ in range(world)]
-        dist.all_gather(allm, mine)
-        allm = torch.stack(allm).cpu()
-    else:
-        allm = mine.cpu().unsqueeze(0)
+    from cdfo_amd.dist import gather_metrics
+    allm = gather_metrics([elapsed, out.double().mean().item(), max_abs, psnr if psnr != float("inf") else 999.0], dev)
     t_max = allm[:, 0].max().item()
 
     if rank == 0:

@@ -1,0 +1,160 @@
+// Fused deformable convolution forward (DCNv1 and modulated DCNv2) for gfx950.
+//
+// Replaces, in ONE kernel and without the `columns` [C*kh*kw, Ho*Wo] HBM round trip, what the reference does with
+//   deformable_im2col_gpu_kernel / modulated_deformable_im2col_gpu_kernel   (ops/dcn/src/deform_conv_cuda_kernel.cu:189-242, 569-632)
+//   + dmcn_im2col_bilinear (cu:466-496) + per-image, per-group addmm_ and bias add (ops/dcn/src/deform_conv_cuda.cpp:545-563, 151-258).
+//
+// Same tensor contract as the reference operator: NCHW input [B,C,H,W], offset [B, 2*dg*kh*kw, Ho, Wo] with (h,w)
+// interleaved per tap, mask [B, dg*kh*kw, Ho, Wo] (DCNv2 only), OIHW weight [Co, C/groups, kh, kw], NCHW output.
+//
+// One workgroup = 64 consecutive output pixels of one image x up to 256 output channels of one conv group.
+// Per chunk of 4 input channels: 256 threads bilinearly sample the 4*kh*kw modulated column values of the 64 pixels
+// straight into LDS (offset/mask reads are coalesced along the pixel axis; the 4-corner gathers hit L1/L2), the
+// matching weight rows are staged transposed, and the contraction runs on the fp32 matrix cores
+// (v_mfma_f32_32x32x2_f32: M = output channel, N = pixel), so the output tile is written coalesced in NCHW.
+#include "common.h"
+
+namespace {
+
+constexpr int CC = 4;      // input channels per K chunk
+constexpr int PIXT = 64;   // output pixels per workgroup
+constexpr int MAXJ = 4;    // up to 4 x 64 output channels per workgroup
+
+struct DcnArgs {
+  const float* in; const float* offset; const float* mask; const float* w; const float* bias; float* out;
+  int B, C, H, W, Co, Ho, Wo, kh, kw, sh, sw, ph, pw, dh, dw, groups, dg;
+};
+
+__device__ __forceinline__ float bilinear_zero(const float* __restrict__ plane, int H, int W, float h, float w) {
+  // dmcn_im2col_bilinear (cu:466-496): corners outside the image contribute 0
+  const int h_low = (int)floorf(h), w_low = (int)floorf(w);
+  const int h_high = h_low + 1, w_high = w_low + 1;
+  const float lh = h - (float)h_low, lw = w - (float)w_low;
+  const float hh = 1.f - lh, hw = 1.f - lw;
+  float v1 = 0.f, v2 = 0.f, v3 = 0.f, v4 = 0.f;
+  if (h_low >= 0 && w_low >= 0) v1 = plane[h_low * W + w_low];
+  if (h_low >= 0 && w_high <= W - 1) v2 = plane[h_low * W + w_high];
+  if (h_high <= H - 1 && w_low >= 0) v3 = plane[h_high * W + w_low];
+  if (h_high <= H - 1 && w_high <= W - 1) v4 = plane[h_high * W + w_high];
+  return (hh * hw) * v1 + (hh * lw) * v2 + (lh * hw) * v3 + (lh * lw) * v4;
+}
+
+__global__ __launch_bounds__(256) void dcn_fwd_kernel(DcnArgs a, int KCH /* = CC*kh*kw rounded up to even */) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* col = smem;               // [KCH][64]
+  float* wt = smem + KCH * PIXT;   // [KCH][256]
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, h = lane >> 5, r = lane & 31;
+  const int T = a.kh * a.kw;
+  const int Cg = a.C / a.groups, Cog = a.Co / a.groups, Cdg = a.C / a.dg;
+  const int P = a.Ho * a.Wo;
+  const int b = blockIdx.z, g = blockIdx.y / ((Cog + 255) / 256), coblk = blockIdx.y % ((Cog + 255) / 256);
+  const int co0 = coblk * 256;                                   // first output channel (within the group)
+  const int nco = (Cog - co0) < 256 ? (Cog - co0) : 256;
+  const int p0 = blockIdx.x * PIXT;
+  const int mt = wave >> 1, nt = wave & 1;                       // this wave's 32-cout / 32-pixel sub-tile
+
+  f32x16 acc[MAXJ];
+#pragma unroll
+  for (int j = 0; j < MAXJ; ++j)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
+
+  const float* in_b = a.in + (long long)b * a.C * a.H * a.W;
+  const float* off_b = a.offset + (long long)b * a.dg * 2 * T * P;
+  const float* msk_b = a.mask ? a.mask + (long long)b * a.dg * T * P : nullptr;
+
+  for (int c0 = 0; c0 < Cg; c0 += CC) {
+    __syncthreads();
+    // ---- sample: item = (k = cc*T + t, pixel i)
+    for (int item = tid; item < KCH * PIXT; item += 256) {
+      const int i = item & (PIXT - 1), k = item >> 6;
+      const int cc = k / T, t = k - cc * T;
+      const int p = p0 + i;
+      float val = 0.f;
+      if (cc < CC && c0 + cc < Cg && p < P) {
+        const int c = g * Cg + c0 + cc;                         // absolute input channel
+        const int d = c / Cdg;                                   // deformable group
+        const int ho = p / a.Wo, wo = p - ho * a.Wo;
+        const int ki = t / a.kw, kj = t - ki * a.kw;
+        const float oh = off_b[((long long)(d * T + t) * 2) * P + p];
+        const float ow = off_b[((long long)(d * T + t) * 2 + 1) * P + p];
+        const float h_im = (float)(ho * a.sh - a.ph + ki * a.dh) + oh;
+        const float w_im = (float)(wo * a.sw - a.pw + kj * a.dw) + ow;
+        if (h_im > -1.f && w_im > -1.f && h_im < (float)a.H && w_im < (float)a.W) {
+          val = bilinear_zero(in_b + (long long)c * a.H * a.W, a.H, a.W, h_im, w_im);
+          if (msk_b) val *= msk_b[(long long)(d * T + t) * P + p];
+        }
+      }
+      col[k * PIXT + i] = val;
+    }
+    // ---- weights of this chunk, transposed: wt[k][o] = W[g*Cog + co0 + o][c0*T + k]
+    for (int item = tid; item < KCH * 256; item += 256) {
+      const int k = item % KCH, o = item / KCH;
+      float v = 0.f;
+      if (o < nco && k < CC * T && c0 * T + k < Cg * T) v = a.w[((long long)(g * Cog + co0 + o) * Cg + c0) * T + k];
+      wt[k * 256 + o] = v;
+    }
+    __syncthreads();
+    for (int k = 0; k < KCH; k += 2) {
+      const float bv = col[(k + h) * PIXT + nt * 32 + r];
+#pragma unroll
+      for (int j = 0; j < MAXJ; ++j) {
+        if (j * 64 < nco) {
+          const float av = wt[(k + h) * 256 + j * 64 + mt * 32 + r];
+          acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[j], 0, 0, 0);
+        }
+      }
+    }
+  }
+  // ---- store: D[row = cout][col = pixel]
+  const int p = p0 + nt * 32 + r;
+  if (p < P) {
+#pragma unroll
+    for (int j = 0; j < MAXJ; ++j) {
+      if (j * 64 >= nco) continue;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int o = j * 64 + mt * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+        if (o < nco) {
+          const int oc = g * Cog + co0 + o;
+          a.out[((long long)b * a.Co + oc) * P + p] = acc[j][e] + (a.bias ? a.bias[oc] : 0.f);
+        }
+      }
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int cdfo_dcn_forward(const float* in, const float* offset, const float* mask, const float* weight,
+                                const float* bias, float* out, int B, int C, int H, int W, int Co, int kh, int kw, int sh,
+                                int sw, int ph, int pw, int dh, int dw, int groups, int deformable_groups, void* stream) {
+  if (B <= 0 || C <= 0 || Co <= 0 || kh <= 0 || kw <= 0 || sh <= 0 || sw <= 0 || dh <= 0 || dw <= 0 || groups <= 0 ||
+      deformable_groups <= 0)
+    return CDFO_EINVAL;
+  if (C % groups || Co % groups || C % deformable_groups) return CDFO_EINVAL;
+  const int Ho = (H + 2 * ph - (dh * (kh - 1) + 1)) / sh + 1;
+  const int Wo = (W + 2 * pw - (dw * (kw - 1) + 1)) / sw + 1;
+  if (Ho <= 0 || Wo <= 0) return CDFO_EINVAL;
+  DcnArgs a{in, offset, mask, weight, bias, out, B, C, H, W, Co, Ho, Wo, kh, kw, sh, sw, ph, pw, dh, dw, groups,
+            deformable_groups};
+  const int T = kh * kw;
+  const int KCH = (CC * T + 1) / 2 * 2;
+  const size_t lds = (size_t)KCH * (PIXT + 256) * sizeof(float);
+  if (lds > 160 * 1024) return CDFO_EINVAL;
+  static size_t attr = 0;
+  if (lds > attr) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dcn_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)lds);
+    attr = lds;
+  }
+  const int Cog = Co / groups;
+  dim3 grid(cdiv(Ho * Wo, PIXT), groups * cdiv(Cog, 256), B);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const double px = (double)B * Ho * Wo;
+  CdfoProfScope prof(st, KID_DCN, 2.0 * px * Co * (C / groups) * T,
+                     4.0 * (px * (Co + 3.0 * deformable_groups * T) + (double)B * C * H * W + (double)Co * (C / groups) * T));
+  hipLaunchKernelGGL(dcn_fwd_kernel, grid, dim3(256), lds, st, a, KCH);
+  CDFO_LAUNCH_CHECK();
+  return 0;
+}

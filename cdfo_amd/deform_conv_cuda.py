@@ -1,0 +1,80 @@
+"""Stand-in for the reference's pybind11 module ``deform_conv_cuda`` (ops/dcn/src/deform_conv_cuda.cpp:681-695):
+the same five entry points with the same positional signatures, backed by libcdfo_hip.so's ``cdfo_dcn_forward``.
+
+The out-parameter convention is kept (caller pre-allocates ``output``; ``columns``/``ones`` scratch tensors are
+accepted and ignored -- the HIP kernel fuses sampling and contraction).  The three backward entry points exist and
+raise ``NotImplementedError`` (forward-only hot path)."""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import _lib
+from .kernels import _stream
+
+
+def _check_cuda_f32(*ts):
+    for t in ts:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise NotImplementedError("deform_conv_cuda (HIP): CPU tensors are not supported")
+        if t.dtype != torch.float32:
+            raise NotImplementedError("deform_conv_cuda (HIP): fp32 only in this round")
+
+
+def _fwd(input, weight, bias, offset, mask, output, kh, kw, sh, sw, ph, pw, dh, dw, group, dg):
+    if not input.is_contiguous():
+        raise RuntimeError("input tensor has to be contiguous")      # cpp:493
+    if not weight.is_contiguous():
+        raise RuntimeError("weight tensor has to be contiguous")     # cpp:494
+    _check_cuda_f32(input, weight, bias, offset, mask, output)
+    B, Cc, H, W = input.shape
+    Co, Ck, kh_, kw_ = weight.shape
+    if (kh_, kw_) != (kh, kw):
+        raise RuntimeError(f"Input shape and kernel shape wont match: ({kh} x {kw} vs {kh_} x {kw_}).")
+    if Cc != Ck * group:
+        raise RuntimeError(f"Input shape and kernel channels wont match: ({Cc} vs {Ck * group}).")
+    Ho = (H + 2 * ph - (dh * (kh - 1) + 1)) // sh + 1
+    Wo = (W + 2 * pw - (dw * (kw - 1) + 1)) // sw + 1
+    if tuple(offset.shape) != (B, 2 * dg * kh * kw, Ho, Wo):
+        raise RuntimeError(f"invalid offset shape {tuple(offset.shape)}, expected {(B, 2 * dg * kh * kw, Ho, Wo)}")
+    if mask is not None and tuple(mask.shape) != (B, dg * kh * kw, Ho, Wo):
+        raise RuntimeError(f"invalid mask shape {tuple(mask.shape)}")
+    if output.numel() != B * Co * Ho * Wo or not output.is_contiguous():
+        raise RuntimeError("output must be a contiguous tensor of B*Co*Ho*Wo elements")
+    offset = offset.contiguous()
+    mask = None if mask is None else mask.contiguous()
+    p = lambda t: C.c_void_p(None if t is None else t.data_ptr())  # noqa: E731
+    _lib.check(_lib.lib().cdfo_dcn_forward(p(input), p(offset), p(mask), p(weight), p(bias), p(output), B, Cc, H, W,
+                                           Co, kh, kw, sh, sw, ph, pw, dh, dw, group, dg, _stream()),
+               "cdfo_dcn_forward")
+
+
+def deform_conv_forward_cuda(input, weight, offset, output, columns, ones, kW, kH, dW, dH, padW, padH, dilationW,
+                             dilationH, group, deformable_group, im2col_step):
+    """ops/dcn/src/deform_conv_cuda.cpp:151-156.  Returns 1 like the reference (cpp:257)."""
+    _fwd(input, weight, None, offset, None, output, kH, kW, dH, dW, padH, padW, dilationH, dilationW, group,
+         deformable_group)
+    return 1
+
+
+def modulated_deform_conv_cuda_forward(input, weight, bias, ones, offset, mask, output, columns, kernel_h, kernel_w,
+                                       stride_h, stride_w, pad_h, pad_w, dilation_h, dilation_w, group,
+                                       deformable_group, with_bias):
+    """ops/dcn/src/deform_conv_cuda.cpp:486-492."""
+    _fwd(input, weight, bias if with_bias else None, offset, mask, output, kernel_h, kernel_w, stride_h, stride_w,
+         pad_h, pad_w, dilation_h, dilation_w, group, deformable_group)
+
+
+def deform_conv_backward_input_cuda(*args, **kw):
+    raise NotImplementedError("deform_conv_backward_input_cuda: backward kernels are not part of this path yet")
+
+
+def deform_conv_backward_parameters_cuda(*args, **kw):
+    raise NotImplementedError("deform_conv_backward_parameters_cuda: backward kernels are not part of this path yet")
+
+
+def modulated_deform_conv_cuda_backward(*args, **kw):
+    raise NotImplementedError("modulated_deform_conv_cuda_backward: backward kernels are not part of this path yet")

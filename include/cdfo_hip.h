@@ -124,6 +124,17 @@ int cdfo_colconv9(const float* in, int ldi, const float* wH, const float* bH, in
 int cdfo_seq_attn(const float* q, int ldq, const float* v, int ldv, float* out, int ldo, int B, int H, int W, int mode,
                   void* stream);
 
+/* ---- deformable convolution forward (dcn.hip) --------------------------------------------------------------
+ * Replaces deform_conv_forward_cuda (ops/dcn/src/deform_conv_cuda.cpp:151-156; mask == NULL, bias == NULL) and
+ * modulated_deform_conv_cuda_forward (ops/dcn/src/deform_conv_cuda.cpp:486-492) of the pybind module
+ * `deform_conv_cuda` (cpp:681-695).  NCHW fp32 contiguous tensors exactly as the reference passes them:
+ * in [B,C,H,W], offset [B,2*dg*kh*kw,Ho,Wo], mask [B,dg*kh*kw,Ho,Wo] or NULL, weight [Co,C/groups,kh,kw],
+ * bias [Co] or NULL, out [B,Co,Ho,Wo] (written, not accumulated).  The reference's `columns`/`ones` scratch tensors
+ * have no counterpart: sampling and contraction are fused.  */
+int cdfo_dcn_forward(const float* in, const float* offset, const float* mask, const float* weight, const float* bias,
+                     float* out, int B, int C, int H, int W, int Co, int kh, int kw, int sh, int sw, int ph, int pw,
+                     int dh, int dw, int groups, int deformable_groups, void* stream);
+
 /* ---- optional per-launch HIP-event timing on the launch stream (bench.py's live roofline figures) ----------- */
 int cdfo_prof_begin(int max_records);
 int cdfo_prof_end(int* launches, double* ms, double* flops, double* bytes, int nkid);

@@ -6,8 +6,10 @@
 //                 inside the 1e-3 parity bound, at 16/3 of the exact-fp32 MFMA rate.
 //   PREC_BF16   : plain bf16 operands (one pass) -- the BASELINE "bf16" configuration; ~6e-3 max-abs on the forward.
 //
-// Structure (one 256-thread workgroup = 16x16 output pixels x 64 output channels, 2 workgroups per CU):
-//   per 16-input-channel chunk: the 18x18x16 input halo tile is fetched as fp32 float4s into REGISTERS while the
+// Structure (one 256-thread workgroup = 8 rows x 32 columns of output pixels x 64 output channels, 2 workgroups/CU;
+// a 32-pixel MFMA M tile is ONE image row, which with the 80-byte pixel record makes every ds_read_b128 lane group hit
+// 16 distinct 16-byte slots):
+//   per 16-input-channel chunk: the 10x34x16 input halo tile is fetched as fp32 float4s into REGISTERS while the
 //   previous chunk's MFMAs run (register-staged double buffering: global latency hides under the matrix pipe), then
 //   converted to bf16 hi/lo and written to LDS (80-byte pixel records: 32 B hi | 32 B lo | 16 B pad, conflict-free
 //   ds_read_b128); the pre-split bf16 weight slab [tap][k-half][cout][8] is copied the same way.  Each lane feeds
@@ -16,12 +18,13 @@
 // Replaces F.conv2d for the 3x3 convolutions with >= 64 output channels on the CVSR_V8 path
 // (arch/SIDECVSR_our.py:383-387 Block_.body -- 89 % of the forward's FLOPs --, :435, :1447, :261-262, :4382).
 #include "common.h"
+#include "conv_epilogue.h"
 
 namespace {
 
-constexpr int TH = 16, TW = 16, IW = 18, NPIX = 18 * 18;
+constexpr int TH = 8, TW = 32, IW = 34, NPIX = 34 * 10;   // a 32-pixel M tile = one image row: conflict-free b128 reads
 constexpr int PIXB = 80;                         // LDS bytes per staged pixel
-constexpr int A_BYTES = NPIX * PIXB;             // 25,920
+constexpr int A_BYTES = NPIX * PIXB;             // 27,200
 constexpr int W_HALF = 9 * 2 * 64 * 16;          // 18,432 B: [tap][h][64 cout][8 bf16]
 constexpr int NA = (NPIX * 4 + 255) / 256;       // 6 float4 per thread per chunk
 constexpr int NW_X3 = 2 * W_HALF / 16 / 256;     // 9 x 16 B per thread (hi + lo)
@@ -37,7 +40,8 @@ __device__ __forceinline__ unsigned pack_bf16(float a, float b) {
 }
 __device__ __forceinline__ float bf16_round(float a) { return (float)(__bf16)a; }
 
-template <bool X3>
+// DBG (developer ablations, never used by the product path): 1 = skip the MFMAs, 2 = skip the per-chunk global loads
+template <bool X3, int DBG = 0>
 __global__ __launch_bounds__(256, 2) void conv3x3_bf16_kernel(cdfo_conv_args a) {
   constexpr int LDS_W = X3 ? 2 * W_HALF : W_HALF;
   constexpr int NWS = X3 ? NW_X3 : NW_X1 + 1;
@@ -46,9 +50,16 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bf16_kernel(cdfo_conv_args a) 
   unsigned char* sW = smem + A_BYTES;
 
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, h = lane >> 5, r = lane & 31;
-  const int tiles_x = (a.Wo + TW - 1) / TW;
-  const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
-  const int oy0 = ty * TH, ox0 = tx * TW, n0 = blockIdx.y * 64, b = blockIdx.z;
+  // XCD-aware block order: workgroups are dealt round-robin over the 8 XCDs (private L2 each), so the nco
+  // output-channel blocks that read the SAME input tile are given consecutive slots on ONE XCD (speed only).
+  const int tiles_x = (a.Wo + TW - 1) / TW, tiles = tiles_x * ((a.Ho + TH - 1) / TH);
+  const int nco = a.CoutP / 64;
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int pt = (slot / nco) * 8 + xcd;            // pixel tile (over all images)
+  if (pt >= tiles * a.B) return;                    // padding blocks of the last group
+  const int b = pt / tiles, tile = pt - b * tiles;
+  const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
+  const int oy0 = ty * TH, ox0 = tx * TW, n0 = (slot % nco) * 64;
   const unsigned short* wq = reinterpret_cast<const unsigned short*>(a.w);
   const long long lo_off = (long long)(a.Cin / 16) * 18 * a.CoutP * 8;  // elements from the hi block to the lo block
 
@@ -76,10 +87,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bf16_kernel(cdfo_conv_args a) 
 
   int a_off[2];
 #pragma unroll
-  for (int mi = 0; mi < 2; ++mi) {
-    const int m = wave * 2 + mi;
-    a_off[mi] = ((2 * m + (r >> 4)) * IW + (r & 15)) * PIXB + h * 16;
-  }
+  for (int mi = 0; mi < 2; ++mi) a_off[mi] = ((wave * 2 + mi) * IW + r) * PIXB + h * 16;
   const int b_off = (h * 64 + r) * 16;
 
   f32x4 ra[NA];
@@ -135,30 +143,45 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bf16_kernel(cdfo_conv_args a) 
   write_lds();
   __syncthreads();
   for (int c = 0; c < nchunks; ++c) {
-    if (c + 1 < nchunks) issue_loads(c + 1);  // in flight while the MFMAs below run
-#pragma unroll
-    for (int t = 0; t < 9; ++t) {
+    if (c + 1 < nchunks && !(DBG & 2)) issue_loads(c + 1);  // in flight while the MFMAs below run
+    bf16x8_t fah[2][2], fal[2][2], fbh[2][2], fbl[2][2];     // [parity][tile]: fragments are read one tap ahead
+    auto load_frags = [&](int t, int par) {
       const int dy = t / 3, dx = t - dy * 3;
-      bf16x8_t ah[2], al[2], bh[2], bl[2];
 #pragma unroll
       for (int mi = 0; mi < 2; ++mi) {
-        ah[mi] = *reinterpret_cast<const bf16x8_t*>(sA + a_off[mi] + (dy * IW + dx) * PIXB);
-        if (X3) al[mi] = *reinterpret_cast<const bf16x8_t*>(sA + a_off[mi] + (dy * IW + dx) * PIXB + 32);
+        fah[par][mi] = *reinterpret_cast<const bf16x8_t*>(sA + a_off[mi] + (dy * IW + dx) * PIXB);
+        if (X3) fal[par][mi] = *reinterpret_cast<const bf16x8_t*>(sA + a_off[mi] + (dy * IW + dx) * PIXB + 32);
       }
 #pragma unroll
       for (int ni = 0; ni < 2; ++ni) {
-        bh[ni] = *reinterpret_cast<const bf16x8_t*>(sW + (t * 2 * 64 + ni * 32) * 16 + b_off);
-        if (X3) bl[ni] = *reinterpret_cast<const bf16x8_t*>(sW + W_HALF + (t * 2 * 64 + ni * 32) * 16 + b_off);
+        fbh[par][ni] = *reinterpret_cast<const bf16x8_t*>(sW + (t * 2 * 64 + ni * 32) * 16 + b_off);
+        if (X3) fbl[par][ni] = *reinterpret_cast<const bf16x8_t*>(sW + W_HALF + (t * 2 * 64 + ni * 32) * 16 + b_off);
+      }
+    };
+    load_frags(0, 0);
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      const int par = t & 1;
+      if (t < 8) load_frags(t + 1, par ^ 1);
+      if (DBG & 1) {
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < 2; ++ni) {
+            acc[mi][ni][0] += (float)fah[par][mi][0] * (float)fbh[par][ni][0];
+            if (X3) acc[mi][ni][1] += (float)fal[par][mi][0] * (float)fbl[par][ni][0];
+          }
+        continue;
       }
 #pragma unroll
       for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
         for (int ni = 0; ni < 2; ++ni) {
           if (X3) {
-            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[mi], bh[ni], acc[mi][ni], 0, 0, 0);
-            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mi], bl[ni], acc[mi][ni], 0, 0, 0);
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fal[par][mi], fbh[par][ni], acc[mi][ni], 0, 0, 0);
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fah[par][mi], fbl[par][ni], acc[mi][ni], 0, 0, 0);
           }
-          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mi], bh[ni], acc[mi][ni], 0, 0, 0);
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fah[par][mi], fbh[par][ni], acc[mi][ni], 0, 0, 0);
         }
     }
     __syncthreads();  // everyone is done reading this chunk's LDS image
@@ -168,29 +191,13 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bf16_kernel(cdfo_conv_args a) 
     }
   }
 
-  // ---- epilogue (identical contract to conv_igemm_f32): +bias -> act -> +res1 -> +res2 -> store
+  // ---- epilogue (identical contract to conv_igemm_f32) through a wave-private LDS transpose; the loop above ends
+  // with a __syncthreads(), so the staged operands are dead
+  float* wl = reinterpret_cast<float*>(smem) + wave * ConvEpi<2>::WAVE_FLOATS;
 #pragma unroll
-  for (int ni = 0; ni < 2; ++ni) {
-    const int n = n0 + ni * 32 + r;
-    if (n >= a.Cout) continue;
-    const float bias = a.bias ? a.bias[n] : 0.f;
-#pragma unroll
-    for (int mi = 0; mi < 2; ++mi) {
-      const int m = wave * 2 + mi;
-#pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int i = (e & 3) + 8 * (e >> 2) + 4 * h;
-        const int oy = oy0 + 2 * m + (i >> 4), ox = ox0 + (i & 15);
-        if (oy >= a.Ho || ox >= a.Wo) continue;
-        const long long pix = (long long)(b * a.Ho + oy) * a.Wo + ox;
-        float v = act_apply(acc[mi][ni][e] + bias, a.act);
-        if (a.res1) v += a.res1[pix * a.ldr1 + n];
-        if (a.res2) v += a.res2[pix * a.ldr2 + n];
-        a.out[pix * a.ldo + n] = v;
-      }
-    }
-  }
+  for (int mi = 0; mi < 2; ++mi) conv_tile_epilogue_row32<2>(a, wl, acc[mi], lane, b, oy0 + wave * 2 + mi, ox0, n0);
 }
+
 
 // OIHW fp32 -> [hi | lo] bf16, each [Cin/16][9][2][CoutP][8]  (k = 16*chunk + 8*h + j)
 __global__ void pack_bf16_kernel(const float* __restrict__ w, unsigned short* __restrict__ p, int Cout, int Cin,
@@ -228,13 +235,18 @@ extern "C" int cdfo_conv3x3_bf16(const cdfo_conv_args* pa, void* stream) {
   }
   if (csum != a.Cin || a.CoutP % 64 || a.CoutP < a.Cout || a.Cout <= 0 || a.Ho != a.H || a.Wo != a.W) return CDFO_EINVAL;
   if (a.store_mode != CDFO_STORE_PLAIN || a.w_bstride != 0) return CDFO_EINVAL;
-  if (!aligned16(a.w)) return CDFO_EALIGN;
+  if (!aligned16(a.w) || a.Cout % 4 || a.ldo % 4 || !aligned16(a.out) || (a.bias && !aligned16(a.bias))) return CDFO_EALIGN;
+  if ((a.res1 && (a.ldr1 % 4 || !aligned16(a.res1))) || (a.res2 && (a.ldr2 % 4 || !aligned16(a.res2)))) return CDFO_EALIGN;
   if ((long long)a.B * a.H * a.W >= (1ll << 31)) return CDFO_EINVAL;
-  dim3 grid(cdiv(a.Wo, TW) * cdiv(a.Ho, TH), a.CoutP / 64, a.B);
+  dim3 grid(cdiv(cdiv(a.Wo, TW) * cdiv(a.Ho, TH) * a.B, 8) * 8 * (a.CoutP / 64));
   const double px = (double)a.B * a.Ho * a.Wo;
   CdfoProfScope prof(st, KID_CONV3_WIDE, 2.0 * px * a.Cout * a.Cin * 9,
                      4.0 * (px * a.Cout + px * a.Cin + 9.0 * a.Cin * a.Cout));
-  if (a.prec == CDFO_PREC_BF16X3)
+  if (a.prec == CDFO_PREC_BF16X3 + 256)
+    hipLaunchKernelGGL((conv3x3_bf16_kernel<true, 1>), grid, dim3(256), 0, st, a);
+  else if (a.prec == CDFO_PREC_BF16X3 + 512)
+    hipLaunchKernelGGL((conv3x3_bf16_kernel<true, 2>), grid, dim3(256), 0, st, a);
+  else if (a.prec == CDFO_PREC_BF16X3)
     hipLaunchKernelGGL(conv3x3_bf16_kernel<true>, grid, dim3(256), 0, st, a);
   else if (a.prec == CDFO_PREC_BF16)
     hipLaunchKernelGGL(conv3x3_bf16_kernel<false>, grid, dim3(256), 0, st, a);

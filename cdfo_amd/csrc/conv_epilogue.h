@@ -1,0 +1,69 @@
+// Shared epilogue of the MFMA convolution kernels: accumulator tiles -> wave-private LDS transpose -> 16-byte rows.
+//
+// A 32x32 MFMA accumulator holds ONE output channel per lane (column) and 16 pixels in its registers, so storing it
+// directly means 4-byte scattered stores (256 B per wave-instruction) -- store-issue bound.  Each wave instead parks a
+// 32-pixel x (32*NT)-channel tile in its own LDS slice and reads it back as float4 along the channel axis: every
+// global store / residual load then moves 1 KiB per wave-instruction (4 whole pixels when the pitch is 64 channels).
+#pragma once
+#include "common.h"
+
+template <int NT>
+struct ConvEpi {
+  static constexpr int RS = 32 * NT + 4;          // floats per staged pixel row (+4: keeps b128 reads conflict-free)
+  static constexpr int WAVE_FLOATS = 32 * RS;     // per-wave LDS slice
+  static constexpr int BLOCK_BYTES = 4 * WAVE_FLOATS * 4;
+};
+
+// acc[ni][e]: row(pixel) = (e&3) + 8*(e>>2) + 4*(lane>>5), col(channel) = ni*32 + (lane&31).
+// Pixel i of the tile sits at (oy_base + (i>>4), ox0 + (i&15)).  Epilogue: +bias -> act -> +res1 -> +res2 -> store.
+template <int NT, int LOG2_ROW>   // the tile's 32 pixels are 32 >> LOG2_ROW rows of (1 << LOG2_ROW) pixels
+__device__ __forceinline__ void conv_tile_epilogue_impl(const cdfo_conv_args& a, float* wl, const f32x16* acc, int lane,
+                                                        int b, int oy_base, int ox0, int n0) {
+  constexpr int RS = ConvEpi<NT>::RS;
+  const int h = lane >> 5, r = lane & 31;
+#pragma unroll
+  for (int ni = 0; ni < NT; ++ni)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) wl[((e & 3) + 8 * (e >> 2) + 4 * h) * RS + ni * 32 + r] = acc[ni][e];
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  constexpr int C4 = 8 * NT, RPI = 64 / C4;       // float4 columns per row, rows per wave-instruction
+  const int c4 = lane % C4, pr = lane / C4;
+  const int n = n0 + c4 * 4;
+  const bool nok = n < a.Cout;                    // Cout % 4 == 0 is enforced by the launcher
+  f32x4 bias = {0.f, 0.f, 0.f, 0.f};
+  if (a.bias && nok) bias = *reinterpret_cast<const f32x4*>(a.bias + n);
+#pragma unroll
+  for (int it = 0; it < 32 / RPI; ++it) {
+    const int i = it * RPI + pr;
+    const int oy = oy_base + (i >> LOG2_ROW), ox = ox0 + (i & ((1 << LOG2_ROW) - 1));
+    f32x4 v = *reinterpret_cast<const f32x4*>(wl + i * RS + c4 * 4) + bias;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v[k] = act_apply(v[k], a.act);
+    if (!nok || oy >= a.Ho || ox >= a.Wo) continue;
+    const long long pix = (long long)(b * a.Ho + oy) * a.Wo + ox;
+    if (a.store_mode == CDFO_STORE_PLAIN) {
+      if (a.res1) v += *reinterpret_cast<const f32x4*>(a.res1 + pix * a.ldr1 + n);
+      if (a.res2) v += *reinterpret_cast<const f32x4*>(a.res2 + pix * a.ldr2 + n);
+      *reinterpret_cast<f32x4*>(a.out + pix * a.ldo + n) = v;
+    } else {  // 2x pixel shuffle; packed channel order is (dy,dx,c), 4 consecutive c stay together
+      const int cq = a.Cout >> 2, sub = n / cq, cc = n - sub * cq;
+      const long long opix = (long long)(b * 2 * a.Ho + 2 * oy + (sub >> 1)) * (2 * a.Wo) + 2 * ox + (sub & 1);
+      *reinterpret_cast<f32x4*>(a.out + opix * a.ldo + cc) = v;
+    }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
+
+template <int NT>
+__device__ __forceinline__ void conv_tile_epilogue(const cdfo_conv_args& a, float* wl, const f32x16* acc, int lane,
+                                                   int b, int oy_base, int ox0, int n0) {
+  conv_tile_epilogue_impl<NT, 4>(a, wl, acc, lane, b, oy_base, ox0, n0);     // 2 rows x 16 pixels
+}
+template <int NT>
+__device__ __forceinline__ void conv_tile_epilogue_row32(const cdfo_conv_args& a, float* wl, const f32x16* acc, int lane,
+                                                         int b, int oy, int ox0, int n0) {
+  conv_tile_epilogue_impl<NT, 5>(a, wl, acc, lane, b, oy, ox0, n0);          // 1 row x 32 pixels
+}

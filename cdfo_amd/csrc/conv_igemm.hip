@@ -10,6 +10,7 @@
 // (arch/SIDECVSR_our.py:383-387, 4382, 4386, 4390-4391, ...), torch.cat in front of it (multi-source K loop),
 // the bias / LeakyReLU / ReLU / residual adds behind it, and PixelShuffle(2) (arch.py:4473-4474).
 #include "common.h"
+#include "conv_epilogue.h"
 
 namespace {
 
@@ -26,7 +27,8 @@ struct Geo {
   static constexpr int NPIX = IH * IW;
   static constexpr int A_FLOATS = ((NPIX * AST + 3) / 4) * 4;
   static constexpr int W_FLOATS = KS * KS * (KC / 4) * BN * 4;
-  static constexpr int LDS_BYTES = (A_FLOATS + W_FLOATS) * 4;
+  static constexpr int MAIN_BYTES = (A_FLOATS + W_FLOATS) * 4;
+  static constexpr int LDS_BYTES = MAIN_BYTES > ConvEpi<NT>::BLOCK_BYTES ? MAIN_BYTES : ConvEpi<NT>::BLOCK_BYTES;
 };
 
 template <int KS, int S, int TH, int NT>
@@ -38,9 +40,15 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(cdfo_conv_args a) {
   float* sW = smem + G::A_FLOATS;
 
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, h = lane >> 5, r = lane & 31;
-  const int tiles_x = (a.Wo + TW - 1) / TW;
-  const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
-  const int oy0 = ty * TH, ox0 = tx * TW, n0 = blockIdx.y * BN, b = blockIdx.z;
+  // XCD-aware block order (see conv3x3_bf16.hip): the output-channel blocks of one input tile share an XCD's L2
+  const int tiles_x = (a.Wo + TW - 1) / TW, tiles = tiles_x * ((a.Ho + TH - 1) / TH);
+  const int nco = a.CoutP / BN;
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int pt = (slot / nco) * 8 + xcd;
+  if (pt >= tiles * a.B) return;
+  const int b = pt / tiles, tile = pt - b * tiles;
+  const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
+  const int oy0 = ty * TH, ox0 = tx * TW, n0 = (slot % nco) * BN;
   const int iy0 = oy0 * S - a.pad, ix0 = ox0 * S - a.pad;
   const float* wbase = a.w + (long long)b * a.w_bstride;
   const int cin4 = a.Cin >> 2;
@@ -113,34 +121,12 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(cdfo_conv_args a) {
     }
   }
 
-  // ---- epilogue: lane r owns output channel n0+ni*32+r for 16 pixels of each M tile
+  // ---- epilogue through a wave-private LDS transpose (conv_epilogue.h)
+  __syncthreads();  // all waves are done with the staged operands
+  float* wl = smem + wave * ConvEpi<NT>::WAVE_FLOATS;
 #pragma unroll
-  for (int ni = 0; ni < NT; ++ni) {
-    const int n = n0 + ni * 32 + r;
-    if (n >= a.Cout) continue;
-    const float bias = a.bias ? a.bias[n] : 0.f;
-#pragma unroll
-    for (int mi = 0; mi < MT; ++mi) {
-      const int m = wave * MT + mi;
-#pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int i = (e & 3) + 8 * (e >> 2) + 4 * h;
-        const int oy = oy0 + 2 * m + (i >> 4), ox = ox0 + (i & 15);
-        if (oy >= a.Ho || ox >= a.Wo) continue;
-        const long long pix = (long long)(b * a.Ho + oy) * a.Wo + ox;
-        float v = act_apply(acc[mi][ni][e] + bias, a.act);
-        if (a.store_mode == CDFO_STORE_PLAIN) {
-          if (a.res1) v += a.res1[pix * a.ldr1 + n];
-          if (a.res2) v += a.res2[pix * a.ldr2 + n];
-          a.out[pix * a.ldo + n] = v;
-        } else {  // 2x pixel shuffle; packed channel order is (dy,dx,c)
-          const int cq = a.Cout >> 2, sub = n / cq, cc = n - sub * cq;
-          const long long opix = (long long)(b * 2 * a.Ho + 2 * oy + (sub >> 1)) * (2 * a.Wo) + 2 * ox + (sub & 1);
-          a.out[opix * a.ldo + cc] = v;
-        }
-      }
-    }
-  }
+  for (int mi = 0; mi < MT; ++mi)
+    conv_tile_epilogue<NT>(a, wl, acc[mi], lane, b, oy0 + 2 * (wave * MT + mi), ox0, n0);
 }
 
 __global__ void pack_weight_kernel(const float* __restrict__ w, float* __restrict__ p, int Cout, int Cin, int ks,
@@ -175,7 +161,7 @@ int launch(const cdfo_conv_args& a, hipStream_t st) {
                         hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES);
     attr_set = true;
   }
-  dim3 grid(cdiv(a.Wo, TW) * cdiv(a.Ho, TH), a.CoutP / G::BN, a.B);
+  dim3 grid(cdiv(cdiv(a.Wo, TW) * cdiv(a.Ho, TH) * a.B, 8) * 8 * (a.CoutP / G::BN));
   const int kid = KS == 1 ? KID_CONV1 : (S == 2 ? KID_CONV3_S2 : (NT == 2 ? KID_CONV3_WIDE : KID_CONV3_NARROW));
   const double px = (double)a.B * a.Ho * a.Wo;
   CdfoProfScope prof(st, kid, 2.0 * px * a.Cout * a.Cin * KS * KS,
@@ -201,7 +187,9 @@ extern "C" int cdfo_conv_igemm(const cdfo_conv_args* pa, void* stream) {
   if (!aligned16(a.w) || a.w_bstride % 4) return CDFO_EALIGN;
   if (a.Ho != (a.H + 2 * a.pad - a.ks) / a.stride + 1 || a.Wo != (a.W + 2 * a.pad - a.ks) / a.stride + 1)
     return CDFO_EINVAL;
-  if (a.store_mode == CDFO_STORE_SHUFFLE2 && (a.Cout % 4 || a.res1 || a.res2)) return CDFO_EINVAL;
+  if (a.store_mode == CDFO_STORE_SHUFFLE2 && (a.Cout % 16 || a.res1 || a.res2)) return CDFO_EINVAL;
+  if (a.Cout % 4 || a.ldo % 4 || !aligned16(a.out) || (a.bias && !aligned16(a.bias))) return CDFO_EALIGN;
+  if ((a.res1 && (a.ldr1 % 4 || !aligned16(a.res1))) || (a.res2 && (a.ldr2 % 4 || !aligned16(a.res2)))) return CDFO_EALIGN;
   if (a.prec != CDFO_PREC_F32) return CDFO_EINVAL;
   const bool wide = (a.CoutP % 64) == 0;
   if (a.ks == 3 && a.stride == 1) return wide ? launch<3, 1, 16, 2>(a, st) : launch<3, 1, 16, 1>(a, st);

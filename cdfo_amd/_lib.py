@@ -35,6 +35,7 @@ class ConvArgs(C.Structure):
         ("res2", C.c_void_p), ("ldr2", C.c_int),
         ("out", C.c_void_p), ("ldo", C.c_int), ("store_mode", C.c_int),
         ("prec", C.c_int),
+        ("ln_gamma", C.c_void_p), ("ln_beta", C.c_void_p),
     ]
 
 

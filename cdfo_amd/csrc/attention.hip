@@ -203,6 +203,138 @@ __global__ __launch_bounds__(64) void seq_attn_kernel(const float* __restrict__ 
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// Row / column attention on the fp32 matrix cores (exact fp32, v_mfma_f32_32x32x2_f32), flash style.
+// One wave owns 32 queries; 4 waves (128 queries of ONE sequence) share the key/value tiles staged in LDS.
+//   S^T[key][query] = K Q^T : A = K (rows = keys), B = Q^T.  Lane (r, h) keeps Q[r][32h .. 32h+31] in registers and reads
+//                     K[r][32h .. 32h+31] from LDS (the k order inside the dot product is free, so each lane takes a
+//                     contiguous half row: 8 ds_read_b128, conflict-free at the 272-byte row pitch).
+//   softmax          : the accumulator holds, per lane, 16 keys of ITS query (column) -> the running max needs one
+//                     cross-half shuffle, the exponentials are lane-local.
+//   O^T[ch][query]  += V^T P^T : the probabilities are already the B operand (register e of half h is key
+//                     (e&3)+8(e>>2)+4h of query r): no data movement between the two products; A = V[that key][ch].
+template <int MODE>   // 0: sequence = image row, 1: image column
+__global__ __launch_bounds__(256) void seq_attn_mfma_kernel(const float* __restrict__ q, int ldq,
+                                                            const float* __restrict__ v, int ldv,
+                                                            float* __restrict__ out, int ldo, int B, int H, int W) {
+  constexpr int KS_ = 68;                                   // floats per staged key row (272 B)
+  __shared__ __attribute__((aligned(16))) float sK[2][32 * KS_];
+  __shared__ __attribute__((aligned(16))) float sV[2][32 * 64];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, h = lane >> 5, r = lane & 31;
+  const int L = MODE == 0 ? W : H;
+  const int nb = (L + 127) / 128;
+  const int blk = blockIdx.x % nb;
+  const long long seq = blockIdx.x / nb;
+  long long kbase, kstep;
+  if (MODE == 0) { kbase = seq * W; kstep = 1; }            // seq = b*H + y
+  else { const long long b = seq / W, x = seq - b * W; kbase = b * H * W + x; kstep = W; }
+  const int q0 = blk * 128 + wave * 32;                     // this wave's first query
+  const bool wave_active = q0 < L;
+  int qi = q0 + r;
+  const bool q_ok = qi < L;
+  if (!q_ok) qi = L - 1;
+  const long long qpix = kbase + (long long)qi * kstep;
+
+  float qr[32];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const f32x4 t = *reinterpret_cast<const f32x4*>(q + qpix * ldq + 32 * h + 4 * i);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) qr[4 * i + e] = t[e];
+  }
+  f32x16 o0, o1;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) { o0[e] = 0.f; o1[e] = 0.f; }
+  float m = -INFINITY, l = 0.f;
+
+  // staging: 32 keys x 16 float4 per tensor = 512 float4 -> 2 per thread per tensor
+  const int skey = tid >> 4, sc4 = tid & 15;
+  f32x4 rk[2], rv[2];
+  auto load_tile = [&](int t0) {
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      int key = t0 + skey + 16 * s;
+      key = key < L ? key : L - 1;                          // clamped (masked below), always loaded
+      const long long kp = kbase + (long long)key * kstep;
+      rk[s] = *reinterpret_cast<const f32x4*>(q + kp * ldq + sc4 * 4);
+      rv[s] = *reinterpret_cast<const f32x4*>(v + kp * ldv + sc4 * 4);
+    }
+  };
+  auto write_tile = [&](int buf) {
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      *reinterpret_cast<f32x4*>(&sK[buf][(skey + 16 * s) * KS_ + sc4 * 4]) = rk[s];
+      *reinterpret_cast<f32x4*>(&sV[buf][(skey + 16 * s) * 64 + sc4 * 4]) = rv[s];
+    }
+  };
+
+  const int ntiles = (L + 31) / 32;
+  load_tile(0);
+  write_tile(0);
+  __syncthreads();
+  for (int t = 0; t < ntiles; ++t) {
+    const int buf = t & 1;
+    if (t + 1 < ntiles) load_tile((t + 1) * 32);
+    if (wave_active) {
+      // ---- S^T = K Q^T
+      f32x16 sacc;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) sacc[e] = 0.f;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const f32x4 kf = *reinterpret_cast<const f32x4*>(&sK[buf][r * KS_ + 32 * h + 4 * i]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[e], qr[4 * i + e], sacc, 0, 0, 0);
+      }
+      // ---- online softmax over this tile's 32 keys (16 here, 16 in the partner half-wave)
+      const int kv_left = L - t * 32;                       // keys beyond L are masked
+      float tmax = -INFINITY;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int key = (e & 3) + 8 * (e >> 2) + 4 * h;
+        if (key >= kv_left) sacc[e] = -INFINITY;
+        tmax = fmaxf(tmax, sacc[e]);
+      }
+      tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+      const float mn = fmaxf(m, tmax);
+      const float alpha = expf(m - mn);
+      m = mn;
+      float psum = 0.f;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) { sacc[e] = expf(sacc[e] - mn); psum += sacc[e]; }
+      l = l * alpha + psum;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) { o0[e] *= alpha; o1[e] *= alpha; }
+      // ---- O^T += V^T P^T
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int key = (e & 3) + 8 * (e >> 2) + 4 * h;
+        const float v0 = sV[buf][key * 64 + r], v1 = sV[buf][key * 64 + 32 + r];
+        o0 = __builtin_amdgcn_mfma_f32_32x32x2f32(v0, sacc[e], o0, 0, 0, 0);
+        o1 = __builtin_amdgcn_mfma_f32_32x32x2f32(v1, sacc[e], o1, 0, 0, 0);
+      }
+    }
+    if (t + 1 < ntiles) write_tile(buf ^ 1);
+    __syncthreads();
+  }
+  if (wave_active) {
+    l += __shfl_xor(l, 32, 64);
+    const float inv = 1.f / l;
+    if (q_ok) {
+      float* po = out + qpix * ldo;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {                          // rows 8g+4h .. +3 of each 32-channel tile
+        f32x4 a0, a1;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { a0[e] = o0[4 * g + e] * inv; a1[e] = o1[4 * g + e] * inv; }
+        *reinterpret_cast<f32x4*>(po + 8 * g + 4 * h) = a0;
+        *reinterpret_cast<f32x4*>(po + 32 + 8 * g + 4 * h) = a1;
+      }
+    }
+  }
+}
+
 }  // namespace
 
 extern "C" int cdfo_rdab_prep(const float* xq, int ldx, const float* vmax, const float* noise, const float* wW,
@@ -235,11 +367,17 @@ extern "C" int cdfo_seq_attn(const float* q, int ldq, const float* v, int ldv, f
   if (B <= 0 || H <= 0 || W <= 0 || ldq % 4 || ldv % 4 || ldo % 4) return CDFO_EINVAL;
   if (!aligned16(q) || !aligned16(v) || !aligned16(out)) return CDFO_EALIGN;
   hipStream_t st = static_cast<hipStream_t>(stream);
-  CdfoProfScope prof(static_cast<hipStream_t>(stream), mode==0?KID_ATTN_ROW:(mode==1?KID_ATTN_COL:KID_ATTN_WIN), 4.0*64*(double)B*H*W*(mode==0?W:(mode==1?H:64)), 4.0*192*(double)B*H*W);
+  CdfoProfScope prof(static_cast<hipStream_t>(stream), (mode%10)==0?KID_ATTN_ROW:((mode%10)==1?KID_ATTN_COL:KID_ATTN_WIN), 4.0*64*(double)B*H*W*((mode%10)==0?W:((mode%10)==1?H:64)), 4.0*192*(double)B*H*W);
   if (mode == 0) {
+    hipLaunchKernelGGL(seq_attn_mfma_kernel<0>, dim3((unsigned)((long long)B * H * cdiv(W, 128))), dim3(256), 0, st, q,
+                       ldq, v, ldv, out, ldo, B, H, W);
+  } else if (mode == 1) {
+    hipLaunchKernelGGL(seq_attn_mfma_kernel<1>, dim3((unsigned)((long long)B * W * cdiv(H, 128))), dim3(256), 0, st, q,
+                       ldq, v, ldv, out, ldo, B, H, W);
+  } else if (mode == 10) {   // VALU reference forms of modes 0 / 1 (kept for A/B tests)
     hipLaunchKernelGGL(seq_attn_kernel<0>, dim3((unsigned)((long long)B * H * cdiv(W, 64))), dim3(64), 0, st, q, ldq, v,
                        ldv, out, ldo, B, H, W);
-  } else if (mode == 1) {
+  } else if (mode == 11) {
     hipLaunchKernelGGL(seq_attn_kernel<1>, dim3((unsigned)((long long)B * W * cdiv(H, 64))), dim3(64), 0, st, q, ldq, v,
                        ldv, out, ldo, B, H, W);
   } else if (mode == 2) {

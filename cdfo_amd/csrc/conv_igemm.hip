@@ -14,12 +14,11 @@
 
 namespace {
 
-constexpr int KC = 16;       // input channels per K chunk
-constexpr int AST = KC + 4;  // LDS floats per staged pixel (80 B pitch)
 constexpr int TW = 16;       // tile width in output pixels
 
-template <int KS, int S, int TH, int NT>
+template <int KS, int S, int TH, int NT, int KC>   // KC = input channels per K chunk (16, or 64 for 1x1)
 struct Geo {
+  static constexpr int AST = KC + 4;  // LDS floats per staged pixel (+16 B: conflict-free ds_read_b128)
   static constexpr int MT = TH / 8;  // 32-pixel M tiles per wave (4 waves)
   static constexpr int BN = 32 * NT;
   static constexpr int IH = (TH - 1) * S + KS;
@@ -31,10 +30,10 @@ struct Geo {
   static constexpr int LDS_BYTES = MAIN_BYTES > ConvEpi<NT>::BLOCK_BYTES ? MAIN_BYTES : ConvEpi<NT>::BLOCK_BYTES;
 };
 
-template <int KS, int S, int TH, int NT>
+template <int KS, int S, int TH, int NT, int KC>
 __global__ __launch_bounds__(256) void conv_igemm_f32(cdfo_conv_args a) {
-  using G = Geo<KS, S, TH, NT>;
-  constexpr int MT = G::MT, BN = G::BN, IW = G::IW, NPIX = G::NPIX, T = KS * KS, KG = KC / 4;
+  using G = Geo<KS, S, TH, NT, KC>;
+  constexpr int MT = G::MT, BN = G::BN, IW = G::IW, NPIX = G::NPIX, T = KS * KS, KG = KC / 4, AST = G::AST;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* sA = smem;
   float* sW = smem + G::A_FLOATS;
@@ -79,20 +78,60 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(cdfo_conv_args a) {
     const int ld = a.ld[s_idx];
     const int coff = ch0 - s_base;
     __syncthreads();
-    // ---- stage the input halo tile: NPIX pixels x 16 channels, zero outside the image (= conv padding)
-    for (int idx = tid; idx < NPIX * KG; idx += 256) {
-      const int p = idx >> 2, q = idx & 3;
-      const int iy = p / IW, ix = p - iy * IW;
-      const int gy = iy0 + iy, gx = ix0 + ix;
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W)
-        v = *reinterpret_cast<const f32x4*>(src + ((long long)(b * a.H + gy) * a.W + gx) * ld + coff + q * 4);
-      *reinterpret_cast<f32x4*>(sA + p * AST + q * 4) = v;
+    // ---- stage the input tile, zero outside the image (= conv padding)
+    if constexpr (KS == 1 && KC == 64) {
+      // 1x1 streaming form: all of this thread's 16-byte loads are issued back to back (8 in flight), then the
+      // optional per-pixel LayerNorm (16 lanes x float4 = one pixel's 64 channels; arch.py:1169-1185), then LDS
+      constexpr int NL = NPIX * KG / 256;
+      static_assert(NPIX * KG % 256 == 0, "tile must divide evenly");
+      f32x4 v[NL];
+      bool inside[NL];
+#pragma unroll
+      for (int s = 0; s < NL; ++s) {
+        const int idx = tid + 256 * s;
+        const int p = idx / KG, q = idx - p * KG;
+        const int iy = p / IW, ix = p - iy * IW;
+        const int gy = iy0 + iy, gx = ix0 + ix;
+        inside[s] = gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+        const long long pix = inside[s] ? ((long long)(b * a.H + gy) * a.W + gx) : 0ll;   // clamped, always loaded
+        v[s] = *reinterpret_cast<const f32x4*>(src + pix * ld + coff + q * 4);
+      }
+      const bool do_ln = a.ln_gamma != nullptr;
+#pragma unroll
+      for (int s = 0; s < NL; ++s) {
+        const int idx = tid + 256 * s;
+        const int p = idx / KG, q = idx - p * KG;
+        f32x4 t = v[s];
+        if (do_ln) {
+          float sm = (t[0] + t[1]) + (t[2] + t[3]);
+#pragma unroll
+          for (int o = 8; o > 0; o >>= 1) sm += __shfl_xor(sm, o, 64);
+          const f32x4 d = t - sm * (1.f / 64.f);
+          float sq = (d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3]);
+#pragma unroll
+          for (int o = 8; o > 0; o >>= 1) sq += __shfl_xor(sq, o, 64);
+          const float rstd = 1.f / sqrtf(sq * (1.f / 64.f) + 1e-5f);
+          t = d * rstd * *reinterpret_cast<const f32x4*>(a.ln_gamma + q * 4) +
+              *reinterpret_cast<const f32x4*>(a.ln_beta + q * 4);
+        }
+        if (!inside[s]) t = f32x4{0.f, 0.f, 0.f, 0.f};
+        *reinterpret_cast<f32x4*>(sA + p * AST + q * 4) = t;
+      }
+    } else {
+      for (int idx = tid; idx < NPIX * KG; idx += 256) {
+        const int p = idx / KG, q = idx - p * KG;
+        const int iy = p / IW, ix = p - iy * IW;
+        const int gy = iy0 + iy, gx = ix0 + ix;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W)
+          v = *reinterpret_cast<const f32x4*>(src + ((long long)(b * a.H + gy) * a.W + gx) * ld + coff + q * 4);
+        *reinterpret_cast<f32x4*>(sA + p * AST + q * 4) = v;
+      }
     }
     // ---- stage the weight slab [tap][kg][BN][4]
     for (int idx = tid; idx < T * KG * BN; idx += 256) {
       const int n = idx % BN, tk = idx / BN;
-      const int kg = tk & 3, t = tk >> 2;
+      const int kg = tk % KG, t = tk / KG;
       const f32x4 v = *reinterpret_cast<const f32x4*>(
           wbase + ((long long)(t * cin4 + (ch0 >> 2) + kg) * a.CoutP + n0 + n) * 4);
       *reinterpret_cast<f32x4*>(sW + idx * 4) = v;
@@ -152,12 +191,12 @@ __global__ void pack_weight_kernel(const float* __restrict__ w, float* __restric
   }
 }
 
-template <int KS, int S, int TH, int NT>
+template <int KS, int S, int TH, int NT, int KC>
 int launch(const cdfo_conv_args& a, hipStream_t st) {
-  using G = Geo<KS, S, TH, NT>;
+  using G = Geo<KS, S, TH, NT, KC>;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_f32<KS, S, TH, NT>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_f32<KS, S, TH, NT, KC>),
                         hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES);
     attr_set = true;
   }
@@ -166,7 +205,7 @@ int launch(const cdfo_conv_args& a, hipStream_t st) {
   const double px = (double)a.B * a.Ho * a.Wo;
   CdfoProfScope prof(st, kid, 2.0 * px * a.Cout * a.Cin * KS * KS,
                      4.0 * (px * a.Cout + (double)a.B * a.H * a.W * a.Cin + (double)KS * KS * a.Cin * a.Cout));
-  hipLaunchKernelGGL((conv_igemm_f32<KS, S, TH, NT>), grid, dim3(256), G::LDS_BYTES, st, a);
+  hipLaunchKernelGGL((conv_igemm_f32<KS, S, TH, NT, KC>), grid, dim3(256), G::LDS_BYTES, st, a);
   CDFO_LAUNCH_CHECK();
   return 0;
 }
@@ -179,7 +218,7 @@ extern "C" int cdfo_conv_igemm(const cdfo_conv_args* pa, void* stream) {
   if (a.nsrc < 1 || a.nsrc > CDFO_MAXSRC || a.B <= 0 || a.H <= 0 || a.W <= 0) return CDFO_EINVAL;
   int csum = 0;
   for (int s = 0; s < a.nsrc; ++s) {
-    if (a.cs[s] <= 0 || a.cs[s] % KC || a.ld[s] % 4 || a.ld[s] < a.cs[s]) return CDFO_EINVAL;
+    if (a.cs[s] <= 0 || a.cs[s] % 16 || a.ld[s] % 4 || a.ld[s] < a.cs[s]) return CDFO_EINVAL;
     if (!aligned16(a.src[s])) return CDFO_EALIGN;
     csum += a.cs[s];
   }
@@ -192,9 +231,14 @@ extern "C" int cdfo_conv_igemm(const cdfo_conv_args* pa, void* stream) {
   if ((a.res1 && (a.ldr1 % 4 || !aligned16(a.res1))) || (a.res2 && (a.ldr2 % 4 || !aligned16(a.res2)))) return CDFO_EALIGN;
   if (a.prec != CDFO_PREC_F32) return CDFO_EINVAL;
   const bool wide = (a.CoutP % 64) == 0;
-  if (a.ks == 3 && a.stride == 1) return wide ? launch<3, 1, 16, 2>(a, st) : launch<3, 1, 16, 1>(a, st);
-  if (a.ks == 1 && a.stride == 1) return wide ? launch<1, 1, 16, 2>(a, st) : launch<1, 1, 16, 1>(a, st);
-  if (a.ks == 3 && a.stride == 2) return wide ? launch<3, 2, 8, 2>(a, st) : launch<3, 2, 8, 1>(a, st);
+  bool k64 = a.ks == 1 && a.stride == 1 && wide;       // 1x1: stage whole 64-channel pixels (HBM-bound streaming)
+  for (int s = 0; s < a.nsrc; ++s) k64 = k64 && (a.cs[s] % 64 == 0);
+  if (a.ln_gamma && !(k64 && a.nsrc == 1 && a.cs[0] == 64 && a.ln_beta)) return CDFO_EINVAL;
+  if (a.ln_gamma && (!aligned16(a.ln_gamma) || !aligned16(a.ln_beta))) return CDFO_EALIGN;
+  if (k64) return launch<1, 1, 8, 2, 64>(a, st);
+  if (a.ks == 3 && a.stride == 1) return wide ? launch<3, 1, 16, 2, 16>(a, st) : launch<3, 1, 16, 1, 16>(a, st);
+  if (a.ks == 1 && a.stride == 1) return wide ? launch<1, 1, 16, 2, 16>(a, st) : launch<1, 1, 16, 1, 16>(a, st);
+  if (a.ks == 3 && a.stride == 2) return wide ? launch<3, 2, 8, 2, 16>(a, st) : launch<3, 2, 8, 1, 16>(a, st);
   return CDFO_EINVAL;
 }
 

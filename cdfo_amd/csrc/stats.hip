@@ -14,19 +14,30 @@
 namespace {
 
 // partial[b][chunk][c] = sum over the chunk's pixels of in[b][p][c]          (C == 64)
+// 16 lanes (a float4 each) cover one pixel, 16 pixel sub-streams per workgroup, fixed-order tree at the end.
 __global__ __launch_bounds__(256) void chan_sum_partial_kernel(const float* __restrict__ in, int ldi, long long P,
                                                                int nchunk, float* __restrict__ partial) {
-  __shared__ float red[4][64];
+  __shared__ f32x4 red[16][16];
   const int b = blockIdx.y, chunk = blockIdx.x;
-  const int c = threadIdx.x & 63, sub = threadIdx.x >> 6;
+  const int c4 = threadIdx.x & 15, sub = threadIdx.x >> 4;
   const long long per = (P + nchunk - 1) / nchunk;
   const long long p0 = chunk * per, p1 = (p0 + per < P) ? p0 + per : P;
-  const float* base = in + (long long)b * P * ldi + c;
-  float s = 0.f;
-  for (long long p = p0 + sub; p < p1; p += 4) s += base[p * ldi];
-  red[sub][c] = s;
+  const float* base = in + (long long)b * P * ldi + c4 * 4;
+  f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0;
+  long long p = p0 + sub;
+  for (; p + 16 < p1; p += 32) {
+    s0 += *reinterpret_cast<const f32x4*>(base + p * ldi);
+    s1 += *reinterpret_cast<const f32x4*>(base + (p + 16) * ldi);
+  }
+  if (p < p1) s0 += *reinterpret_cast<const f32x4*>(base + p * ldi);
+  red[sub][c4] = s0 + s1;
   __syncthreads();
-  if (sub == 0) partial[((long long)b * nchunk + chunk) * 64 + c] = (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);
+  if (sub == 0) {
+    f32x4 t = red[0][c4];
+#pragma unroll
+    for (int k = 1; k < 16; ++k) t += red[k][c4];
+    *reinterpret_cast<f32x4*>(partial + ((long long)b * nchunk + chunk) * 64 + c4 * 4) = t;
+  }
 }
 
 // partial[b][chunk][c*(CH+2) + j]: j<CH: sum_p q[p][c]*k[p][head(c)*CH+j];  j==CH: sum q^2;  j==CH+1: sum k[.][c]^2
@@ -73,6 +84,7 @@ __device__ void reduce_and_softmax(const float* __restrict__ partial, int nchunk
   constexpr int N = 64 * (CH + 2);
   for (int i = threadIdx.x; i < N; i += blockDim.x) {
     float s = 0.f;
+#pragma unroll 8
     for (int ch = 0; ch < nchunk; ++ch) s += partial[(long long)ch * N + i];
     stats[i] = s;
   }
@@ -141,6 +153,7 @@ __global__ __launch_bounds__(256) void align_fold_kernel(const float* __restrict
     const int which = threadIdx.x >> 6, c = threadIdx.x & 63;
     const float* sp = (which ? sum_pred : sum_warp) + (long long)b * nchunk_s * 64;
     float s = 0.f;
+#pragma unroll 8
     for (int ch = 0; ch < nchunk_s; ++ch) s += sp[ch * 64 + c];
     mean[which][c] = s * inv_P;
   }
@@ -187,6 +200,7 @@ __global__ __launch_bounds__(64) void vec_mlp_kernel(const float* __restrict__ s
   __shared__ float mean[64], hid[64];
   const int b = blockIdx.x, t = threadIdx.x;
   float s = 0.f;
+#pragma unroll 8
   for (int ch = 0; ch < nchunk; ++ch) s += sum_partial[((long long)b * nchunk + ch) * 64 + t];
   mean[t] = s * inv_P;
   __syncthreads();
@@ -211,7 +225,8 @@ __global__ __launch_bounds__(64) void vec_mlp_kernel(const float* __restrict__ s
 
 extern "C" int cdfo_chan_sum_partial(const float* in, int ldi, int B, long long P, int nchunk, float* partial,
                                      void* stream) {
-  if (B <= 0 || P <= 0 || nchunk <= 0) return CDFO_EINVAL;
+  if (B <= 0 || P <= 0 || nchunk <= 0 || ldi % 4) return CDFO_EINVAL;
+  if (!aligned16(in) || !aligned16(partial)) return CDFO_EALIGN;
   CdfoProfScope prof(static_cast<hipStream_t>(stream), KID_CHAN_SUM, 0, 4.0*64*(double)B*P);
   hipLaunchKernelGGL(chan_sum_partial_kernel, dim3(nchunk, B), dim3(256), 0, static_cast<hipStream_t>(stream), in, ldi,
                      P, nchunk, partial);

@@ -205,8 +205,8 @@ class CVSR_V8(nn.Module):
         p = "transformer_feature_extraction.path1."
         for rnd in range(3):
             x2 = self._udsa(w, x2, x1 if rnd == 0 else x2)
-            ln = K.layernorm64(x1, raw[p + "norm1.body.weight"], raw[p + "norm1.body.bias"])
-            qkv = K.dwconv3x3(self._conv(ln, w[p + "attn.qkv"]), raw[p + "attn.qkv_dwconv.weight"])
+            qkv = self._conv(x1, w[p + "attn.qkv"], ln=(raw[p + "norm1.body.weight"], raw[p + "norm1.body.bias"]))
+            qkv = K.dwconv3x3(qkv, raw[p + "attn.qkv_dwconv.weight"])
             part, n = K.gram_partial(qkv[..., 0:64], qkv[..., 64:128], 8)
             fold = K.mdta_fold(part, n, raw[p + "attn.temperature"], raw[p + "attn.project_out.weight"])
             x1 = self._conv(qkv[..., 128:192], fold, res1=x1)

@@ -106,7 +106,8 @@ def pack_conv(weight: torch.Tensor, bias: Optional[torch.Tensor], shuffle2: bool
 
 def conv(srcs: Sequence[torch.Tensor], pc: PackedConv, *, stride: int = 1, pad: int = 0, act: int = ACT_NONE,
          res1: Optional[torch.Tensor] = None, res2: Optional[torch.Tensor] = None,
-         out: Optional[torch.Tensor] = None, prec: int = PREC_F32) -> torch.Tensor:
+         out: Optional[torch.Tensor] = None, prec: int = PREC_F32,
+         ln: Optional[tuple] = None) -> torch.Tensor:
     if isinstance(srcs, torch.Tensor):
         srcs = [srcs]
     a = ConvArgs()
@@ -157,6 +158,8 @@ def conv(srcs: Sequence[torch.Tensor], pc: PackedConv, *, stride: int = 1, pad: 
         check(_lib.lib().cdfo_conv3x3_bf16(C.byref(a), _stream()), "cdfo_conv3x3_bf16")
         return out
     a.prec = 0
+    if ln is not None:
+        a.ln_gamma, a.ln_beta = ln[0].data_ptr(), ln[1].data_ptr()
     check(_lib.lib().cdfo_conv_igemm(C.byref(a), _stream()), "cdfo_conv_igemm")
     return out
 
@@ -269,7 +272,7 @@ def spatial_gate16(x: torch.Tensor, w: torch.Tensor, bias: torch.Tensor) -> torc
 
 # ----------------------------------------------------------------------------------------------- reductions / folds
 def nchunks_for(P: int) -> int:
-    return max(1, min(128, P // 2048))
+    return max(1, min(128, P // 1024))
 
 
 def chan_sum_partial(x: torch.Tensor):

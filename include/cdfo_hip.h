@@ -47,6 +47,7 @@ typedef struct {
   const float* res2; int ldr2;
   float* out; int ldo; int store_mode;
   int prec;
+  const float* ln_gamma; const float* ln_beta;   /* optional fused per-pixel LayerNorm of a single 64-channel source (1x1 only) */
 } cdfo_conv_args;
 int cdfo_conv_igemm(const cdfo_conv_args* a, void* stream);
 

@@ -126,3 +126,28 @@ def test_conv3x3_bf16_family(Cin, Cout, H, W, B, prec, tol):
     out = K.conv(srcs, pc, pad=1, act=K.ACT_LRELU, res1=_nhwc(r1).cuda(), prec=prec)
     torch.cuda.synchronize()
     _cmp(out, ref, tol, f"conv3x3 prec={prec}")
+
+
+def test_conv1x1_fused_layernorm_and_wide_sources():
+    from cdfo_amd import kernels as K
+    g = torch.Generator().manual_seed(11)
+    B, H, W = 2, 24, 40
+    x = torch.randn(B, 64, H, W, generator=g) * 3 + 1
+    gamma, beta = torch.randn(64, generator=g), torch.randn(64, generator=g)
+    w = torch.randn(192, 64, 1, 1, generator=g) / 8.0
+    mu = x.mean(1, keepdim=True)
+    var = x.var(1, keepdim=True, unbiased=False)
+    ln = (x - mu) / torch.sqrt(var + 1e-5) * gamma.view(1, -1, 1, 1) + beta.view(1, -1, 1, 1)
+    ref = F.conv2d(ln, w)
+    pc = K.pack_conv(w.cuda(), None)
+    out = K.conv([_nhwc(x).cuda()], pc, ln=(gamma.cuda(), beta.cuda()))
+    torch.cuda.synchronize()
+    _cmp(out, ref, 3e-5, "ln+1x1")
+    # 7 x 64-channel sources (tsa_fusion shape) through the 64-channel-chunk path
+    xs = [torch.randn(1, 64, 9, 21, generator=g) for _ in range(7)]
+    w2 = torch.randn(64, 448, 1, 1, generator=g) / 21.0
+    b2 = torch.randn(64, generator=g)
+    ref2 = F.leaky_relu(F.conv2d(torch.cat(xs, 1), w2, b2), 0.1)
+    out2 = K.conv([_nhwc(t).cuda() for t in xs], K.pack_conv(w2.cuda(), b2.cuda()), act=K.ACT_LRELU)
+    torch.cuda.synchronize()
+    _cmp(out2, ref2, 2e-5, "7-source 1x1")

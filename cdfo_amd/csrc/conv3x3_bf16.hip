@@ -40,7 +40,8 @@ __device__ __forceinline__ unsigned pack_bf16(float a, float b) {
 }
 __device__ __forceinline__ float bf16_round(float a) { return (float)(__bf16)a; }
 
-// DBG (developer ablations, never used by the product path): 1 = skip the MFMAs, 2 = skip the per-chunk global loads
+// DBG (developer ablations, never used by the product path): 1 = skip the MFMAs, 2 = skip the per-chunk global loads,
+// 4 = skip the per-chunk convert + LDS writes, 8 = skip the epilogue (store one value), 16 = skip the barriers
 template <bool X3, int DBG = 0>
 __global__ __launch_bounds__(256, 2) void conv3x3_bf16_kernel(cdfo_conv_args a) {
   constexpr int LDS_W = X3 ? 2 * W_HALF : W_HALF;
@@ -184,19 +185,31 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bf16_kernel(cdfo_conv_args a) 
           acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fah[par][mi], fbh[par][ni], acc[mi][ni], 0, 0, 0);
         }
     }
-    __syncthreads();  // everyone is done reading this chunk's LDS image
+    if (!(DBG & 16)) __syncthreads();  // everyone is done reading this chunk's LDS image
     if (c + 1 < nchunks) {
-      write_lds();
-      __syncthreads();
+      if (!(DBG & 4)) write_lds();
+      if (!(DBG & 16)) __syncthreads();
     }
   }
 
   // ---- epilogue (identical contract to conv_igemm_f32) through a wave-private LDS transpose; the loop above ends
   // with a __syncthreads(), so the staged operands are dead
+  if (DBG & 8) {
+    float t = 0.f;
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) t += acc[mi][ni][e];
+    if (t == 123.456f) a.out[0] = t;
+    return;
+  }
   float* wl = reinterpret_cast<float*>(smem) + wave * ConvEpi<2>::WAVE_FLOATS;
 #pragma unroll
   for (int mi = 0; mi < 2; ++mi) conv_tile_epilogue_row32<2>(a, wl, acc[mi], lane, b, oy0 + wave * 2 + mi, ox0, n0);
 }
+
 
 
 // OIHW fp32 -> [hi | lo] bf16, each [Cin/16][9][2][CoutP][8]  (k = 16*chunk + 8*h + j)
@@ -227,6 +240,7 @@ extern "C" int cdfo_conv3x3_bf16(const cdfo_conv_args* pa, void* stream) {
   const cdfo_conv_args& a = *pa;
   hipStream_t st = static_cast<hipStream_t>(stream);
   if (a.nsrc < 1 || a.nsrc > CDFO_MAXSRC || a.B <= 0 || a.ks != 3 || a.stride != 1 || a.pad != 1) return CDFO_EINVAL;
+  if (a.act == CDFO_ACT_SIGMOID) return CDFO_EINVAL;   // conv epilogues support none / LeakyReLU / ReLU
   int csum = 0;
   for (int s = 0; s < a.nsrc; ++s) {
     if (a.cs[s] <= 0 || a.cs[s] % 16 || a.ld[s] % 4 || a.ld[s] < a.cs[s]) return CDFO_EINVAL;
@@ -242,10 +256,16 @@ extern "C" int cdfo_conv3x3_bf16(const cdfo_conv_args* pa, void* stream) {
   const double px = (double)a.B * a.Ho * a.Wo;
   CdfoProfScope prof(st, KID_CONV3_WIDE, 2.0 * px * a.Cout * a.Cin * 9,
                      4.0 * (px * a.Cout + px * a.Cin + 9.0 * a.Cin * a.Cout));
-  if (a.prec == CDFO_PREC_BF16X3 + 256)
-    hipLaunchKernelGGL((conv3x3_bf16_kernel<true, 1>), grid, dim3(256), 0, st, a);
-  else if (a.prec == CDFO_PREC_BF16X3 + 512)
-    hipLaunchKernelGGL((conv3x3_bf16_kernel<true, 2>), grid, dim3(256), 0, st, a);
+  const int dbg = a.prec >> 8;
+  if ((a.prec & 255) == CDFO_PREC_BF16X3 && dbg) {
+#define CDFO_DBG_CASE(D) case D: hipLaunchKernelGGL((conv3x3_bf16_kernel<true, D>), grid, dim3(256), 0, st, a); break;
+    switch (dbg) {
+      CDFO_DBG_CASE(1) CDFO_DBG_CASE(2) CDFO_DBG_CASE(3) CDFO_DBG_CASE(4) CDFO_DBG_CASE(7) CDFO_DBG_CASE(8)
+      CDFO_DBG_CASE(9) CDFO_DBG_CASE(15) CDFO_DBG_CASE(16) CDFO_DBG_CASE(31) CDFO_DBG_CASE(23) CDFO_DBG_CASE(6)
+      default: return CDFO_EINVAL;
+    }
+#undef CDFO_DBG_CASE
+  }
   else if (a.prec == CDFO_PREC_BF16X3)
     hipLaunchKernelGGL(conv3x3_bf16_kernel<true>, grid, dim3(256), 0, st, a);
   else if (a.prec == CDFO_PREC_BF16)

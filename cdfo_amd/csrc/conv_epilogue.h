@@ -29,28 +29,37 @@ __device__ __forceinline__ void conv_tile_epilogue_impl(const cdfo_conv_args& a,
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   constexpr int C4 = 8 * NT, RPI = 64 / C4;       // float4 columns per row, rows per wave-instruction
+  constexpr int ROWW = 1 << LOG2_ROW, NROWS = 32 >> LOG2_ROW;
   const int c4 = lane % C4, pr = lane / C4;
   const int n = n0 + c4 * 4;
   const bool nok = n < a.Cout;                    // Cout % 4 == 0 is enforced by the launcher
   f32x4 bias = {0.f, 0.f, 0.f, 0.f};
   if (a.bias && nok) bias = *reinterpret_cast<const f32x4*>(a.bias + n);
+  // activation as one branch-free form: v > 0 ? v : slope * v   (none: 1, LeakyReLU: 0.1, ReLU: 0)
+  const float slope = a.act == CDFO_ACT_NONE ? 1.f : (a.act == CDFO_ACT_LRELU ? 0.1f : 0.f);
+  const bool plain = a.store_mode == CDFO_STORE_PLAIN;
+  const int cq = a.Cout >> 2, sub = plain ? 0 : n / cq, cc = n - sub * cq;
 #pragma unroll
-  for (int it = 0; it < 32 / RPI; ++it) {
-    const int i = it * RPI + pr;
-    const int oy = oy_base + (i >> LOG2_ROW), ox = ox0 + (i & ((1 << LOG2_ROW) - 1));
-    f32x4 v = *reinterpret_cast<const f32x4*>(wl + i * RS + c4 * 4) + bias;
+  for (int row = 0; row < NROWS; ++row) {
+    const int oy = oy_base + row;
+    if (oy >= a.Ho) break;
+    // 64-bit base once per image row of the tile; 32-bit steps inside it
+    const long long pixrow = (long long)(b * a.Ho + oy) * a.Wo + ox0;
+    float* orow = plain ? a.out + pixrow * a.ldo + n
+                        : a.out + ((long long)(b * 2 * a.Ho + 2 * oy + (sub >> 1)) * (2 * a.Wo) + 2 * ox0 + (sub & 1)) * a.ldo + cc;
+    const float* r1row = a.res1 ? a.res1 + pixrow * a.ldr1 + n : nullptr;
+    const float* r2row = a.res2 ? a.res2 + pixrow * a.ldr2 + n : nullptr;
+    const int ostep = plain ? a.ldo : 2 * a.ldo;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) v[k] = act_apply(v[k], a.act);
-    if (!nok || oy >= a.Ho || ox >= a.Wo) continue;
-    const long long pix = (long long)(b * a.Ho + oy) * a.Wo + ox;
-    if (a.store_mode == CDFO_STORE_PLAIN) {
-      if (a.res1) v += *reinterpret_cast<const f32x4*>(a.res1 + pix * a.ldr1 + n);
-      if (a.res2) v += *reinterpret_cast<const f32x4*>(a.res2 + pix * a.ldr2 + n);
-      *reinterpret_cast<f32x4*>(a.out + pix * a.ldo + n) = v;
-    } else {  // 2x pixel shuffle; packed channel order is (dy,dx,c), 4 consecutive c stay together
-      const int cq = a.Cout >> 2, sub = n / cq, cc = n - sub * cq;
-      const long long opix = (long long)(b * 2 * a.Ho + 2 * oy + (sub >> 1)) * (2 * a.Wo) + 2 * ox + (sub & 1);
-      *reinterpret_cast<f32x4*>(a.out + opix * a.ldo + cc) = v;
+    for (int it = 0; it < ROWW / RPI; ++it) {
+      const int xi = it * RPI + pr;               // pixel inside this row of the tile
+      f32x4 v = *reinterpret_cast<const f32x4*>(wl + (row * ROWW + xi) * RS + c4 * 4) + bias;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) v[k] = fmaxf(v[k], 0.f) + slope * fminf(v[k], 0.f);
+      if (!nok || ox0 + xi >= a.Wo) continue;
+      if (r1row) v += *reinterpret_cast<const f32x4*>(r1row + xi * a.ldr1);
+      if (r2row) v += *reinterpret_cast<const f32x4*>(r2row + xi * a.ldr2);
+      *reinterpret_cast<f32x4*>(orow + xi * ostep) = v;
     }
   }
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");

@@ -36,6 +36,7 @@ class ConvArgs(C.Structure):
         ("out", C.c_void_p), ("ldo", C.c_int), ("store_mode", C.c_int),
         ("prec", C.c_int),
         ("ln_gamma", C.c_void_p), ("ln_beta", C.c_void_p),
+        ("tap_mask", C.c_void_p),
     ]
 
 

@@ -159,6 +159,25 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bf16_kernel(cdfo_conv_args a) 
         if (X3) fbl[par][ni] = *reinterpret_cast<const bf16x8_t*>(sW + W_HALF + (t * 2 * 64 + ni * 32) * 16 + b_off);
       }
     };
+    if (a.tap_mask) {
+      // sparse taps (stride-2-composed conv in space-to-depth form: 4 of the 9 taps carry weights per chunk)
+      const unsigned tm = a.tap_mask[c];
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        if (!((tm >> t) & 1u)) continue;
+        load_frags(t, 0);
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < 2; ++ni) {
+            if (X3) {
+              acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fal[0][mi], fbh[0][ni], acc[mi][ni], 0, 0, 0);
+              acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fah[0][mi], fbl[0][ni], acc[mi][ni], 0, 0, 0);
+            }
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fah[0][mi], fbh[0][ni], acc[mi][ni], 0, 0, 0);
+          }
+      }
+    } else {
     load_frags(0, 0);
 #pragma unroll
     for (int t = 0; t < 9; ++t) {
@@ -184,6 +203,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bf16_kernel(cdfo_conv_args a) 
           }
           acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fah[par][mi], fbh[par][ni], acc[mi][ni], 0, 0, 0);
         }
+    }
     }
     if (!(DBG & 16)) __syncthreads();  // everyone is done reading this chunk's LDS image
     if (c + 1 < nchunks) {
@@ -248,7 +268,8 @@ extern "C" int cdfo_conv3x3_bf16(const cdfo_conv_args* pa, void* stream) {
     csum += a.cs[s];
   }
   if (csum != a.Cin || a.CoutP % 64 || a.CoutP < a.Cout || a.Cout <= 0 || a.Ho != a.H || a.Wo != a.W) return CDFO_EINVAL;
-  if (a.store_mode != CDFO_STORE_PLAIN || a.w_bstride != 0) return CDFO_EINVAL;
+  if ((a.store_mode != CDFO_STORE_PLAIN && a.store_mode != CDFO_STORE_S2D) || a.w_bstride != 0) return CDFO_EINVAL;
+  if (a.store_mode == CDFO_STORE_S2D && ((a.Ho | a.Wo) & 1 || a.res1 || a.res2)) return CDFO_EINVAL;
   if (!aligned16(a.w) || a.Cout % 4 || a.ldo % 4 || !aligned16(a.out) || (a.bias && !aligned16(a.bias))) return CDFO_EALIGN;
   if ((a.res1 && (a.ldr1 % 4 || !aligned16(a.res1))) || (a.res2 && (a.ldr2 % 4 || !aligned16(a.res2)))) return CDFO_EALIGN;
   if ((long long)a.B * a.H * a.W >= (1ll << 31)) return CDFO_EINVAL;

@@ -38,17 +38,22 @@ __device__ __forceinline__ void conv_tile_epilogue_impl(const cdfo_conv_args& a,
   // activation as one branch-free form: v > 0 ? v : slope * v   (none: 1, LeakyReLU: 0.1, ReLU: 0)
   const float slope = a.act == CDFO_ACT_NONE ? 1.f : (a.act == CDFO_ACT_LRELU ? 0.1f : 0.f);
   const bool plain = a.store_mode == CDFO_STORE_PLAIN;
-  const int cq = a.Cout >> 2, sub = plain ? 0 : n / cq, cc = n - sub * cq;
+  const int cq = a.Cout >> 2, sub = a.store_mode == CDFO_STORE_SHUFFLE2 ? n / cq : 0, cc = n - sub * cq;
 #pragma unroll
   for (int row = 0; row < NROWS; ++row) {
     const int oy = oy_base + row;
     if (oy >= a.Ho) break;
     // 64-bit base once per image row of the tile; 32-bit steps inside it
     const long long pixrow = (long long)(b * a.Ho + oy) * a.Wo + ox0;
-    float* orow = plain ? a.out + pixrow * a.ldo + n
-                        : a.out + ((long long)(b * 2 * a.Ho + 2 * oy + (sub >> 1)) * (2 * a.Wo) + 2 * ox0 + (sub & 1)) * a.ldo + cc;
+    float* orow;
+    if (plain) orow = a.out + pixrow * a.ldo + n;
+    else if (a.store_mode == CDFO_STORE_SHUFFLE2)
+      orow = a.out + ((long long)(b * 2 * a.Ho + 2 * oy + (sub >> 1)) * (2 * a.Wo) + 2 * ox0 + (sub & 1)) * a.ldo + cc;
+    else  // space-to-depth: pixel (oy>>1, x>>1), phase (oy&1, x&1); ox0 is even, so x&1 == xi&1
+      orow = a.out + ((long long)(b * (a.Ho >> 1) + (oy >> 1)) * (a.Wo >> 1) + (ox0 >> 1)) * a.ldo + (oy & 1) * 2 * a.Cout + n;
     const float* r1row = a.res1 ? a.res1 + pixrow * a.ldr1 + n : nullptr;
     const float* r2row = a.res2 ? a.res2 + pixrow * a.ldr2 + n : nullptr;
+    const bool s2d = a.store_mode == CDFO_STORE_S2D;
     const int ostep = plain ? a.ldo : 2 * a.ldo;
 #pragma unroll
     for (int it = 0; it < ROWW / RPI; ++it) {
@@ -59,7 +64,8 @@ __device__ __forceinline__ void conv_tile_epilogue_impl(const cdfo_conv_args& a,
       if (!nok || ox0 + xi >= a.Wo) continue;
       if (r1row) v += *reinterpret_cast<const f32x4*>(r1row + xi * a.ldr1);
       if (r2row) v += *reinterpret_cast<const f32x4*>(r2row + xi * a.ldr2);
-      *reinterpret_cast<f32x4*>(orow + xi * ostep) = v;
+      if (s2d) *reinterpret_cast<f32x4*>(orow + (xi >> 1) * a.ldo + (xi & 1) * a.Cout) = v;
+      else *reinterpret_cast<f32x4*>(orow + xi * ostep) = v;
     }
   }
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");

@@ -176,6 +176,41 @@ class CVSR_V8(nn.Module):
             for b in range(3):
                 for leaf in ("body.0", "body.2", "down.0", "up.0"):
                     pc(f"recon_trunk.body.{g}.body.{b}.{leaf}")
+        # Block_'s double-resolution branch ends in  down(body.2(.)) = 1x1(mean2x2(conv3x3(.))).  All three are linear, so
+        # they compose into ONE 4x4 stride-2 convolution (16 taps instead of 4*9 per low-res output: 2.25x fewer FLOPs),
+        # expressed here as a 3x3 convolution over the space-to-depth image [H,W,4*256] in which each input phase has
+        # weights on 4 of the 9 taps only (tap_mask), with down.0 folded in.
+        masks = []
+        for ph in range(4):
+            pa, pb = ph >> 1, ph & 1
+            m = 0
+            for dy in range(3):
+                for dx in range(3):
+                    if 0 <= 2 * dy + pa - 1 <= 3 and 0 <= 2 * dx + pb - 1 <= 3:
+                        m |= 1 << (dy * 3 + dx)
+            masks += [m] * 16
+        tap_mask = torch.tensor(masks, dtype=torch.int32, device=sd["conv_first.weight"].device)
+        for g in range(7):
+            for b in range(3):
+                bp = f"recon_trunk.body.{g}.body.{b}."
+                w3, b2 = sd[bp + "body.2.weight"], sd[bp + "body.2.bias"]
+                wdn, bdn = sd[bp + "down.0.weight"][:, :, 0, 0], sd[bp + "down.0.bias"]
+                w4 = w3.new_zeros(64, 256, 4, 4)
+                for pa in range(2):
+                    for pb in range(2):
+                        w4[:, :, pa:pa + 3, pb:pb + 3] += 0.25 * w3
+                wp = w3.new_zeros(64, 4, 256, 3, 3)
+                for ph in range(4):
+                    pa, pb = ph >> 1, ph & 1
+                    for dy in range(3):
+                        for dx in range(3):
+                            u, v = 2 * dy + pa - 1, 2 * dx + pb - 1
+                            if 0 <= u <= 3 and 0 <= v <= 3:
+                                wp[:, ph, :, dy, dx] = w4[:, :, u, v]
+                wf = torch.einsum("po,ocyx->pcyx", wdn, wp.view(64, 1024, 3, 3)).contiguous()
+                fused = K.pack_conv(wf, wdn @ b2 + bdn)
+                fused.tap_mask = tap_mask
+                w[bp + "down_fused"] = fused
         pc("upconv1", shuffle2=True)
         pc("upconv2", shuffle2=True)
         w["raw"] = {k: v.contiguous() for k, v in sd.items()}
@@ -263,10 +298,11 @@ class CVSR_V8(nn.Module):
         d = self._conv(K.resample2(x, up=False), dn)
         d = self._conv(self._conv(d, b0, pad=1, act=K.ACT_LRELU), b2, pad=1)
         K.resample2(self._conv(d, up), up=True, out=out, accumulate=True)
-        # double-resolution branch
+        # double-resolution branch: conv1 writes its 256 channels space-to-depth; conv2 + 2x2 mean + down.0 are one
+        # composed sparse-tap convolution at the block's own resolution (see _weights)
         u = K.resample2(self._conv(x, up), up=True)
-        u = self._conv(self._conv(u, b0, pad=1, act=K.ACT_LRELU), b2, pad=1)
-        return self._conv(K.resample2(u, up=False), dn, res1=out)
+        t = self._conv(u, b0, pad=1, act=K.ACT_LRELU, s2d=True)
+        return self._conv(t, w[p + "down_fused"], pad=1, res1=out)
 
     def _trunk(self, w, fused):
         y = fused

@@ -75,6 +75,7 @@ class PackedConv:
     shuffle2: bool = False
     w_bstride: int = 0
     wq: Optional[torch.Tensor] = None   # split-bf16 packing for cdfo_conv3x3_bf16 (3x3, Cout % 64 == 0)
+    tap_mask: Optional[torch.Tensor] = None   # int32 [Cin/16]: bit t set = tap t of that chunk has weights
 
 
 def pack_conv(weight: torch.Tensor, bias: Optional[torch.Tensor], shuffle2: bool = False,
@@ -107,7 +108,7 @@ def pack_conv(weight: torch.Tensor, bias: Optional[torch.Tensor], shuffle2: bool
 def conv(srcs: Sequence[torch.Tensor], pc: PackedConv, *, stride: int = 1, pad: int = 0, act: int = ACT_NONE,
          res1: Optional[torch.Tensor] = None, res2: Optional[torch.Tensor] = None,
          out: Optional[torch.Tensor] = None, prec: int = PREC_F32,
-         ln: Optional[tuple] = None) -> torch.Tensor:
+         ln: Optional[tuple] = None, s2d: bool = False) -> torch.Tensor:
     if isinstance(srcs, torch.Tensor):
         srcs = [srcs]
     a = ConvArgs()
@@ -139,6 +140,10 @@ def conv(srcs: Sequence[torch.Tensor], pc: PackedConv, *, stride: int = 1, pad: 
         if out is None:
             out = empty_act(B, 2 * Ho, 2 * Wo, pc.Cout // 4, srcs[0].device)
         a.store_mode = 1
+    elif s2d:
+        if out is None:
+            out = empty_act(B, Ho // 2, Wo // 2, 4 * pc.Cout, srcs[0].device)
+        a.store_mode = 2
     else:
         if out is None:
             out = empty_act(B, Ho, Wo, pc.Cout, srcs[0].device)
@@ -155,6 +160,7 @@ def conv(srcs: Sequence[torch.Tensor], pc: PackedConv, *, stride: int = 1, pad: 
     if (prec != PREC_F32 and pc.wq is not None and stride == 1 and pad == 1 and pc.w_bstride == 0):
         a.prec = prec
         a.w = pc.wq.data_ptr()
+        a.tap_mask = _p(pc.tap_mask)
         check(_lib.lib().cdfo_conv3x3_bf16(C.byref(a), _stream()), "cdfo_conv3x3_bf16")
         return out
     a.prec = 0

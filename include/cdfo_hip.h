@@ -24,7 +24,7 @@ extern "C" {
 #define CDFO_MAXSRC 8
 
 enum { CDFO_ACT_NONE = 0, CDFO_ACT_LRELU = 1, CDFO_ACT_RELU = 2, CDFO_ACT_SIGMOID = 3 };
-enum { CDFO_STORE_PLAIN = 0, CDFO_STORE_SHUFFLE2 = 1 };
+enum { CDFO_STORE_PLAIN = 0, CDFO_STORE_SHUFFLE2 = 1, CDFO_STORE_S2D = 2 };
 enum { CDFO_PREC_F32 = 0, CDFO_PREC_BF16X3 = 1, CDFO_PREC_BF16 = 2 };
 
 /* ABI version / build info.  */
@@ -35,7 +35,9 @@ const char* cdfo_build_info(void);
  * arch/SIDECVSR_our.py e.g. :383-387 Block_.body, :4382, :4386, :4390-4391).
  * Input = channel-concatenation of up to CDFO_MAXSRC sources (replaces torch.cat(...,1) in front of a conv).
  * w: packed by cdfo_pack_conv_weight(); optional per-image weights (w_bstride != 0).
- * Epilogue: +bias -> act -> +res1 -> +res2 -> store (plain or 2x pixel-shuffle, arch.py:4473-4474).  */
+ * Epilogue: +bias -> act -> +res1 -> +res2 -> store (plain or 2x pixel-shuffle, arch.py:4473-4474).
+ * CDFO_STORE_S2D writes output pixel (y,x), channel n to pixel (y/2,x/2), channel ((y&1)*2+(x&1))*Cout+n of a
+ * [B,Ho/2,Wo/2,4*Cout] tensor (space-to-depth), the input format of the stride-2-composed conv of Block_'s 2x branch.  */
 typedef struct {
   const float* src[CDFO_MAXSRC]; int ld[CDFO_MAXSRC]; int cs[CDFO_MAXSRC]; int nsrc;
   int B, H, W, Ho, Wo;
@@ -48,6 +50,7 @@ typedef struct {
   float* out; int ldo; int store_mode;
   int prec;
   const float* ln_gamma; const float* ln_beta;   /* optional fused per-pixel LayerNorm of a single 64-channel source (1x1 only) */
+  const unsigned* tap_mask;   /* optional, cdfo_conv3x3_bf16 only: per 16-channel chunk, bit t set = tap t has non-zero weights */
 } cdfo_conv_args;
 int cdfo_conv_igemm(const cdfo_conv_args* a, void* stream);
 

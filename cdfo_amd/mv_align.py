@@ -1,0 +1,96 @@
+"""``MVDualAttAlignment`` -- the motion-vector-guided deformable alignment of the reference's ``CVSR_V7``
+(arch/SIDECVSR_our.py:3265-3352, instantiated at :4242 as ``MVDualAttAlignment(64, 64, 3, padding=1,
+deformable_groups=16, max_residue_magnitude=10)``): same constructor, parameter names and
+``forward(x, extra_feat, pred_feat, flow_1)``; NCHW tensors in and out like the reference.  Everything runs in
+libcdfo_hip.so: MV warp, the shared 8-head channel attention folded into a per-image 64x64 matrix, the 64->64->432
+offset/mask head on the MFMA conv kernels, offset assembly (10*tanh + flipped MV) and the fused DCNv2
+(``torchvision.ops.deform_conv2d`` in the reference, arch.py:3352).  Forward only, no CPU fallback."""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+import torch.nn as nn
+
+from . import _lib, deform_conv_cuda
+from . import kernels as K
+from ._lib import check
+from .dcn import ModulatedDeformConvPack
+
+
+class MVDualAttAlignment(ModulatedDeformConvPack):
+    def __init__(self, *args, **kwargs):
+        self.max_residue_magnitude = kwargs.pop('max_residue_magnitude', 10)
+        super().__init__(*args, **kwargs)
+        self.conv_offset = nn.Sequential(
+            nn.Conv2d(self.out_channels, self.out_channels, 3, 1, 1),
+            nn.LeakyReLU(negative_slope=0.1, inplace=True),
+            nn.Conv2d(self.out_channels, 27 * self.deformable_groups, 3, 1, 1),
+        )
+        dim = 64
+        self.num_heads = 8
+        self.avg_pool = nn.AdaptiveAvgPool2d(1)
+        self.conv_du = nn.Sequential(
+            nn.Conv2d(self.out_channels, self.out_channels // 16, 1, padding=0, bias=True), nn.ReLU(inplace=True),
+            nn.Conv2d(self.out_channels // 16, self.out_channels, 1, padding=0, bias=True), nn.Sigmoid())
+        self.fusion_out = nn.Conv2d(dim * 2, dim, kernel_size=1, bias=False)
+        self.temperature = nn.Parameter(torch.ones(self.num_heads, 1, 1))
+        self.project_out = nn.Conv2d(dim, dim, kernel_size=1, bias=False)
+        self.sigmoid = nn.Sigmoid()
+        nn.init.constant_(self.conv_offset[-1].weight, 0)
+        nn.init.constant_(self.conv_offset[-1].bias, 0)
+        self._packed = None
+        self._sig = None
+
+    def _weights(self):
+        sig = tuple((p.data_ptr(), p._version) for p in self.parameters())
+        if self._packed is None or sig != self._sig:
+            d = lambda t: t.detach().contiguous()  # noqa: E731
+            self._packed = dict(
+                fusion=K.pack_conv(d(self.fusion_out.weight), None),
+                off0=K.pack_conv(d(self.conv_offset[0].weight), d(self.conv_offset[0].bias)),
+                off2=K.pack_conv(d(self.conv_offset[2].weight), d(self.conv_offset[2].bias)))
+            self._sig = sig
+        return self._packed
+
+    def forward(self, x, extra_feat, pred_feat, flow_1):
+        if not x.is_cuda:
+            raise NotImplementedError("MVDualAttAlignment (HIP): CPU tensors are not supported")
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            raise NotImplementedError("MVDualAttAlignment (HIP): forward only -- wrap the call in torch.no_grad()")
+        if self.in_channels != 64 or self.out_channels != 64:
+            raise NotImplementedError("MVDualAttAlignment (HIP): specialised for 64 channels (arch.py:4242)")
+        w = self._weights()
+        B, _, H, W = x.shape
+        P = H * W
+        x = x.contiguous().float()
+        flow = flow_1.contiguous().float()
+        xq = K.nchw_to_nhwc(x)
+        extra = K.nchw_to_nhwc(extra_feat.float())
+        pred = K.nchw_to_nhwc(pred_feat.float())
+        d = lambda t: t.detach().contiguous()  # noqa: E731
+        warped = K.flow_warp(extra, flow, 2 * P)
+        fused = K.conv([warped, pred], w["fusion"])                      # no activation here (arch.py:3305)
+        gp, ng = K.gram_partial(xq, fused, 8)
+        fold = K.mdta_fold(gp, ng, d(self.temperature), d(self.project_out.weight))   # P . blockdiag(softmax)
+        outs = []
+        for v in (warped, pred):
+            part, n = K.chan_sum_partial(v)
+            gate = K.vec_mlp(part, n, P, d(self.conv_du[0].weight), d(self.conv_du[0].bias), self.out_channels // 16,
+                             K.ACT_RELU, d(self.conv_du[2].weight), d(self.conv_du[2].bias), 64, K.ACT_SIGMOID)
+            o = K.conv(K.scale_channels(v, gate), fold)                   # project_out(attn @ (v * gate))
+            o = K.conv(o, w["off0"], pad=1, act=K.ACT_LRELU)            # exact fp32: offsets are scaled by 10
+            outs.append(K.conv(o, w["off2"], pad=1))                      # [B,H,W,27*dg]
+        third = 9 * self.deformable_groups
+        offset = torch.empty((B, 2 * third, H, W), dtype=torch.float32, device=x.device)
+        mask = torch.empty((B, third, H, W), dtype=torch.float32, device=x.device)
+        vp = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
+        check(_lib.lib().cdfo_mv_offset_mask(vp(outs[0]), vp(outs[1]), outs[0].stride(2), vp(flow), C.c_longlong(2 * P),
+                                             B, C.c_longlong(P), third, float(self.max_residue_magnitude), vp(offset),
+                                             vp(mask), K._stream()), "cdfo_mv_offset_mask")
+        out = torch.empty((B, self.out_channels, H, W), dtype=torch.float32, device=x.device)
+        deform_conv_cuda.modulated_deform_conv_cuda_forward(
+            x, d(self.weight), None if self.bias is None else d(self.bias), None, offset, mask, out, None,
+            self.kernel_size[0], self.kernel_size[1], self.stride, self.stride, self.padding, self.padding,
+            self.dilation, self.dilation, self.groups, self.deformable_groups, self.bias is not None)
+        return out

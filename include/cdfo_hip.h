@@ -139,6 +139,22 @@ int cdfo_dcn_forward(const float* in, const float* offset, const float* mask, co
                      float* out, int B, int C, int H, int W, int Co, int kh, int kw, int sh, int sw, int ph, int pw,
                      int dh, int dw, int groups, int deformable_groups, void* stream);
 
+/* ---- small NCHW operators of the DCN consumer modules DSTA (ops/attentionlayer.py:86-156) and MVDualAttAlignment
+ * (arch/SIDECVSR_our.py:3265-3352); contiguous NCHW fp32, one thread per output (nchw_ops.hip) ------------------ */
+int cdfo_conv2d_nchw(const float* in, const float* w, const float* bias, int B, int C, int H, int W, int Co, int kh,
+                     int kw, int stride, int pad, int act, float* out, void* stream);
+int cdfo_maxpool_nchw(const float* in, int BC, int H, int W, int k, int stride, float* out, void* stream);
+int cdfo_resize_bilinear_nchw(const float* in, int BC, int H, int W, int Ho, int Wo, int accumulate, float* out,
+                              void* stream);
+int cdfo_avgpool_nchw(const float* in, int BC, long long P, float* out, void* stream);
+/* mode 0: a+b; 1: relu(a); 2: sigmoid(a); 3: x*sigmoid(a)*y[b][c] (P = H*W). */
+int cdfo_ew_nchw(const float* a, const float* b, const float* x, const float* y, long long n, long long P, int mode,
+                 float* out, void* stream);
+/* arch.py:3336-3350: offset = mag*tanh(o1[:2/3]) + mag*tanh(o2[:2/3]) + flow.flip(1) tiled, mask = sigmoid(o1[2/3:]+o2[2/3:]);
+ * o1,o2 pixel-major [B,H,W,3*third] (pitch ld), flow [B][2][H*W] planes, outputs NCHW. */
+int cdfo_mv_offset_mask(const float* o1, const float* o2, int ld, const float* flow, long long flow_bstride, int B,
+                        long long P, int third, float mag, float* offset, float* mask, void* stream);
+
 /* ---- optional per-launch HIP-event timing on the launch stream (bench.py's live roofline figures) ----------- */
 int cdfo_prof_begin(int max_records);
 int cdfo_prof_end(int* launches, double* ms, double* flops, double* bytes, int nkid);

@@ -55,12 +55,31 @@ def load_reference():
         sys.modules[name] = m
         return m
 
-    class _PackStub(nn.Module):  # only so that dead subclasses at arch.py:3103-3352,3653 can be defined
-        def __init__(self, *a, **k):
+    class _PackStub(nn.Module):
+        """Parameter/attribute container standing in for the non-existent ``arch.ops.dcn.ModulatedDeformConvPack``
+        (arch.py:9): lets the subclasses at arch.py:3103-3352,3653 be defined and gives ``MVDualAttAlignment`` the
+        attributes its forward reads (ops/dcn/deform_conv.py:264-337 layout).  No forward: never called."""
+        def __init__(self, in_channels=64, out_channels=64, kernel_size=3, stride=1, padding=0, dilation=1, groups=1,
+                     deformable_groups=1, bias=True):
             super().__init__()
+            self.in_channels, self.out_channels = in_channels, out_channels
+            self.kernel_size = (kernel_size, kernel_size)
+            self.stride, self.padding, self.dilation = stride, padding, dilation
+            self.groups, self.deformable_groups, self.with_bias = groups, deformable_groups, bias
+            self.weight = nn.Parameter(torch.zeros(out_channels, in_channels // groups, kernel_size, kernel_size))
+            self.bias = nn.Parameter(torch.zeros(out_channels)) if bias else None
+            self.conv_offset_mask = nn.Conv2d(in_channels, deformable_groups * 3 * kernel_size * kernel_size,
+                                              kernel_size, stride, padding)
 
     saved = {k: sys.modules.get(k) for k in ("arch", "arch.ops", "arch.ops.dcn")}
-    stub("torchvision"); stub("torchvision.ops"); stub("torchvision.datasets")
+    from oracle.dcn_modules_ref import dcn_torch
+
+    def _deform_conv2d(input, offset, weight, bias=None, stride=1, padding=0, dilation=1, mask=None):
+        # stand-in for the un-vendored torchvision.ops.deform_conv2d (arch.py:3352): the C oracle of the DCN forward
+        dg = offset.shape[1] // (2 * weight.shape[2] * weight.shape[3])
+        return dcn_torch(input, offset, mask, weight, bias, stride, padding, dilation, 1, dg)
+
+    stub("torchvision"); stub("torchvision.ops", deform_conv2d=_deform_conv2d); stub("torchvision.datasets")
     stub("torchvision.transforms"); stub("torchvision.utils", save_image=lambda *a, **k: None)
     sys.modules["torchvision"].datasets = sys.modules["torchvision.datasets"]
     sys.modules["torchvision"].transforms = sys.modules["torchvision.transforms"]
@@ -148,6 +167,69 @@ def run_case(ref, name, B, H, W, wseed, iseed, layout, cached):
     print(f"{name}: out {tuple(out.shape)} mean {out.mean():.6f} -> {path} ({os.path.getsize(path)/1024:.0f} KiB)")
 
 
+def load_reference_dsta():
+    """ops/attentionlayer.py of the reference, with ``ops.dcn.deform_conv.ModulatedDeformConv`` (needs the stripped
+    CUDA extension) replaced by a parameter-compatible module whose forward is the C oracle."""
+    from oracle.dcn_modules_ref import dcn_torch
+
+    class _MDC(nn.Module):
+        def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1, groups=1,
+                     deformable_groups=1, bias=True):
+            super().__init__()
+            self.stride, self.padding, self.dilation, self.groups, self.dg = stride, padding, dilation, groups, deformable_groups
+            self.weight = nn.Parameter(torch.zeros(out_channels, in_channels // groups, kernel_size, kernel_size))
+            self.bias = nn.Parameter(torch.zeros(out_channels)) if bias else None
+
+        def forward(self, x, offset, mask):
+            return dcn_torch(x, offset, mask, self.weight, self.bias, self.stride, self.padding, self.dilation,
+                             self.groups, self.dg)
+
+    saved = {k: sys.modules.get(k) for k in ("ops", "ops.dcn", "ops.dcn.deform_conv")}
+    for name in ("ops", "ops.dcn"):
+        m = types.ModuleType(name)
+        m.__path__ = []
+        sys.modules[name] = m
+    m = types.ModuleType("ops.dcn.deform_conv")
+    m.ModulatedDeformConv = _MDC
+    sys.modules["ops.dcn.deform_conv"] = m
+    spec = importlib.util.spec_from_file_location("_cdfo_reference_attentionlayer", os.path.join(REF, "ops", "attentionlayer.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    for k, v in saved.items():
+        if v is None:
+            sys.modules.pop(k, None)
+        else:
+            sys.modules[k] = v
+    return mod
+
+
+MODULE_CASES = {   # name: (kind, B, H, W, weight seed, input seed)
+    "dsta_b2_48x64": ("dsta", 2, 48, 64, 41, 141),
+    "dsta_b1_40x56": ("dsta", 1, 40, 56, 42, 142),
+    "mvalign_b2_16x24": ("mvalign", 2, 16, 24, 43, 143),
+    "mvalign_b1_24x40": ("mvalign", 1, 24, 40, 44, 144),
+}
+
+
+def run_module_case(ref, ref_att, name, kind, B, H, W, wseed, iseed):
+    from oracle.dcn_modules_ref import seeded_inputs_dsta, seeded_inputs_mvalign, seeded_state
+    if kind == "dsta":
+        model = ref_att.DSTA(64)
+        inputs = (seeded_inputs_dsta(B, H, W, iseed),)
+    else:
+        model = ref.MVDualAttAlignment(64, 64, 3, padding=1, deformable_groups=16, max_residue_magnitude=10)
+        inputs = seeded_inputs_mvalign(B, H, W, iseed)
+    sd = seeded_state({k: v.shape for k, v in model.state_dict().items()}, wseed)
+    model.load_state_dict(sd, strict=True)
+    model.eval()
+    with torch.no_grad():
+        out = model(*inputs)
+    path = os.path.join(REPO, "tests", "golden", f"{name}.npz")
+    np.savez_compressed(path, kind=kind, B=B, H=H, W=W, wseed=wseed, iseed=iseed, out=out.numpy(),
+                        keys=np.array(sorted(sd)), shapes=np.array([str(tuple(sd[k].shape)) for k in sorted(sd)]))
+    print(f"{name}: out {tuple(out.shape)} absmean {out.abs().mean():.5f} -> {path} ({os.path.getsize(path)/1024:.0f} KiB)")
+
+
 def main():
     ref = load_reference()
     only = sys.argv[1:]
@@ -155,6 +237,11 @@ def main():
         if only and name not in only:
             continue
         run_case(ref, name, *cfg)
+    ref_att = load_reference_dsta()
+    for name, cfg in MODULE_CASES.items():
+        if only and name not in only:
+            continue
+        run_module_case(ref, ref_att, name, *cfg)
 
 
 if __name__ == "__main__":

@@ -26,8 +26,8 @@ sys.path.insert(0, ROOT)
 # algorithmic FLOPs per clip-forward, counted on the reference itself: F = P*(73.55e6 + 1536*(W+H))
 EXACT_FLOPS = {(272, 480): 9_753_744_609_072, (120, 240): 2_134_302_625_536, (64, 64): 302_119_013_712,
                (544, 960): 39_617_571_644_688}
-PEAK_TFLOPS = {"f32": 157.3, "bf16x3": 2500.0, "bf16": 2500.0}   # /opt/skills/guides/MI355X_MICROARCH.md dense MFMA peaks
-MFMA_PASSES = {"f32": 1, "bf16x3": 3, "bf16": 1}                    # bf16 MFMA MACs issued per algorithmic MAC
+PEAK_TFLOPS = {"f32": 157.3, "bf16x3": 2500.0, "bf16": 2500.0, "fp16x2": 2500.0}   # /opt/skills/guides/MI355X_MICROARCH.md dense MFMA peaks
+MFMA_PASSES = {"f32": 1, "bf16x3": 3, "bf16": 1, "fp16x2": 2}                    # bf16 MFMA MACs issued per algorithmic MAC
 KID_NAMES = ["conv3x3_wide", "conv3x3_narrow", "conv1x1", "conv3x3_s2", "stem", "layernorm", "dwconv", "flow_warp",
              "resample", "scale", "conv_last", "small_conv", "spatial_gate", "chan_sum", "gram", "fold", "rdab_prep",
              "colconv9", "attn_row", "attn_col", "attn_win", "layout", "pack", "dcn"]
@@ -47,7 +47,7 @@ def main():
     ap.add_argument("--width", type=int, default=480)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true", help="skip the c1 parity spot-check (profiling runs: keeps every launch at the workload's size)")
-    ap.add_argument("--precision", default="bf16x3", choices=["f32", "bf16x3", "bf16"])
+    ap.add_argument("--precision", default="fp16x2", choices=["f32", "bf16x3", "bf16", "fp16x2"])
     ap.add_argument("--breakdown", type=str, default="", help="write the per-kernel-family event timings to this file")
     args = ap.parse_args()
 
@@ -159,7 +159,7 @@ def main():
             "metric": "x4 SR frames/sec, 7-frame 270x480->1080p", "value": round(value, 4), "unit": "frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * t_max / args.steps, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": {"f32": "f32", "bf16x3": "bf16x3 (split-bf16 MFMA, fp32 accumulate; fp32-grade: <= 1.2e-5 max-abs vs the fp32 reference)", "bf16": "bf16"}[args.precision],
+            "dtype": {"f32": "f32", "bf16x3": "bf16x3 (split-bf16 MFMA, fp32 accumulate; fp32-grade: <= 1.2e-5 max-abs vs the fp32 reference)", "bf16": "bf16", "fp16x2": "fp16x2 (fp16 hi+lo activations x fp16 weights, 2-pass MFMA, fp32 accumulate; 3-5e-4 max-abs vs the fp32 reference)"}[args.precision],
             "data": "synthetic",
             "config": {"workload": f"JCT-VC ClassB-shape synthetic clips: {B} clips/GPU x 7x1x{args.height}x{args.width} "
                                    f"luma (padded to {Hp}x{Wp}) + MV/residual/partition/unfiltered priors -> "

@@ -1,52 +1,89 @@
-// 3x3 stride-1 convolution on the bf16 matrix cores (v_mfma_f32_32x32x16_bf16) with fp32 accumulation.
+// 3x3 stride-1 convolution on the 16-bit matrix cores (v_mfma_f32_32x32x16_{bf16,f16}) with fp32 accumulation.
 //
-//   PREC_BF16X3 : split-bf16 ("3-pass") arithmetic.  Every fp32 operand x is held as hi = bf16(x) and
-//                 lo = bf16(x - hi); a product is a_hi*w_hi + a_lo*w_hi + a_hi*w_lo (the lo*lo term, 2^-16 relative,
-//                 is dropped).  Max-abs error of the whole CVSR_V8 forward vs the fp32 reference stays ~1e-5, i.e.
-//                 inside the 1e-3 parity bound, at 16/3 of the exact-fp32 MFMA rate.
-//   PREC_BF16   : plain bf16 operands (one pass) -- the BASELINE "bf16" configuration; ~6e-3 max-abs on the forward.
+//   PREC_BF16X3 : split-bf16, three passes.  Every fp32 operand x is held as hi = bf16(x), lo = bf16(x - hi); a product is
+//                 a_hi*w_hi + a_lo*w_hi + a_hi*w_lo (the lo*lo term, 2^-16 relative, is dropped).  Whole-forward max-abs
+//                 error vs the fp32 reference ~1e-5: fp32-grade, at 16/3 of the exact-fp32 MFMA rate.
+//   PREC_FP16X2 : activations split into fp16 hi + fp16 lo (22 significant bits), weights rounded ONCE to fp16 (11 bits):
+//                 two passes a_hi*w + a_lo*w.  Whole-forward max-abs error 3-5e-4 (inside the 1e-3 parity bound with a
+//                 2x margin), 2/3 of the MFMAs of bf16x3, half the weight bytes in LDS -> three workgroups per CU.
+//   PREC_BF16   : plain bf16 operands, one pass -- BASELINE's "bf16" configuration; ~6e-3 max-abs on the forward.
 //
-// Structure (one 256-thread workgroup = 8 rows x 32 columns of output pixels x 64 output channels, 2 workgroups/CU;
-// a 32-pixel MFMA M tile is ONE image row, which with the 80-byte pixel record makes every ds_read_b128 lane group hit
-// 16 distinct 16-byte slots):
+// Structure (one 256-thread workgroup = 8 rows x 32 columns of output pixels x 64 output channels; a 32-pixel MFMA M tile
+// is ONE image row, which with the 80-byte pixel record makes every ds_read_b128 lane group hit 16 distinct 16-byte
+// slots):
 //   per 16-input-channel chunk: the 10x34x16 input halo tile is fetched as fp32 float4s into REGISTERS while the
-//   previous chunk's MFMAs run (register-staged double buffering: global latency hides under the matrix pipe), then
-//   converted to bf16 hi/lo and written to LDS (80-byte pixel records: 32 B hi | 32 B lo | 16 B pad, conflict-free
-//   ds_read_b128); the pre-split bf16 weight slab [tap][k-half][cout][8] is copied the same way.  Each lane feeds
-//   12 MFMAs (2x2 register tile x 3 passes) from 8 ds_read_b128 per tap.  No im2col buffer, no HBM intermediates.
+//   previous chunk's MFMAs run (register-staged double buffering), then converted to 16-bit hi/lo and written to LDS
+//   (80-byte pixel records: 32 B hi | 32 B lo | 16 B pad); the pre-packed 16-bit weight slab [tap][k-half][cout][8] is
+//   copied the same way.  Operand fragments are read one tap ahead of the MFMAs that use them.  The epilogue goes
+//   through a wave-private LDS transpose (conv_epilogue.h).  Workgroups are ordered so that the output-channel blocks of
+//   one input tile share an XCD's L2.  Optional tap_mask skips (chunk, tap) pairs whose weights are all zero (the
+//   stride-2-composed convolution of Block_'s double-resolution branch).  No im2col buffer, no HBM intermediates.
 //
 // Replaces F.conv2d for the 3x3 convolutions with >= 64 output channels on the CVSR_V8 path
 // (arch/SIDECVSR_our.py:383-387 Block_.body -- 89 % of the forward's FLOPs --, :435, :1447, :261-262, :4382).
+//
+// Measured and rejected this round (all correct, none faster; numbers in profiles/r01_pmc_conv3x3.txt): LDS double
+// buffering with one workgroup per CU and the next chunk's staging interleaved into the MFMA stream; the same as a
+// strip-persistent (tile, chunk) stream with two-chunk-deep prefetch (compiler waits, then inline-asm loads with
+// hand-counted vmcnt); a wave-specialised producer/consumer workgroup.  The ablation of the last one isolates the cause:
+// the bare ds_read + MFMA stream of one wave per SIMD already takes 1.9x its 2.4 GHz issue time (the chip holds a lower
+// clock under the matrix load, MI355X_MICROARCH.md "DVFS give-back"), and the 4.3 GB of epilogue stores add their
+// full HBM time unless another workgroup's MFMAs cover them.
 #include "common.h"
 #include "conv_epilogue.h"
 
 namespace {
 
-constexpr int TH = 8, TW = 32, IW = 34, NPIX = 34 * 10;   // a 32-pixel M tile = one image row: conflict-free b128 reads
+constexpr int TH = 8, TW = 32, IW = 34, NPIX = 34 * 10;
 constexpr int PIXB = 80;                         // LDS bytes per staged pixel
 constexpr int A_BYTES = NPIX * PIXB;             // 27,200
-constexpr int W_HALF = 9 * 2 * 64 * 16;          // 18,432 B: [tap][h][64 cout][8 bf16]
+constexpr int W_HALF = 9 * 2 * 64 * 16;          // 18,432 B: [tap][h][64 cout][8 x 16-bit]
 constexpr int NA = (NPIX * 4 + 255) / 256;       // 6 float4 per thread per chunk
-constexpr int NW_X3 = 2 * W_HALF / 16 / 256;     // 9 x 16 B per thread (hi + lo)
-constexpr int NW_X1 = W_HALF / 16 / 256;         // 4.5 -> handled as 5 with a guard
+
+enum { M_BF16X3 = CDFO_PREC_BF16X3, M_BF16 = CDFO_PREC_BF16, M_FP16X2 = CDFO_PREC_FP16X2 };
 
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
-__device__ __forceinline__ unsigned pack_bf16(float a, float b) {
+template <int MODE> struct Fmt;
+template <> struct Fmt<M_BF16X3> { using frag = bf16x8_t; static constexpr bool ALO = true, WLO = true; };
+template <> struct Fmt<M_BF16> { using frag = bf16x8_t; static constexpr bool ALO = false, WLO = false; };
+template <> struct Fmt<M_FP16X2> { using frag = f16x8_t; static constexpr bool ALO = true, WLO = false; };
+
+__device__ __forceinline__ f32x16 mma(bf16x8_t a, bf16x8_t b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x16 mma(f16x8_t a, f16x8_t b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+}
+
+template <bool F16>
+__device__ __forceinline__ unsigned pack16(float a, float b) {
+  if (F16) {
+    const _Float16 ha = (_Float16)a, hb = (_Float16)b;
+    return (unsigned)__builtin_bit_cast(unsigned short, ha) | ((unsigned)__builtin_bit_cast(unsigned short, hb) << 16);
+  }
   const __bf16 ha = (__bf16)a, hb = (__bf16)b;
   return (unsigned)__builtin_bit_cast(unsigned short, ha) | ((unsigned)__builtin_bit_cast(unsigned short, hb) << 16);
 }
-__device__ __forceinline__ float bf16_round(float a) { return (float)(__bf16)a; }
+template <bool F16>
+__device__ __forceinline__ float round16(float a) { return F16 ? (float)(_Float16)a : (float)(__bf16)a; }
 
 // DBG (developer ablations, never used by the product path): 1 = skip the MFMAs, 2 = skip the per-chunk global loads,
 // 4 = skip the per-chunk convert + LDS writes, 8 = skip the epilogue (store one value), 16 = skip the barriers
-template <bool X3, int DBG = 0>
-__global__ __launch_bounds__(256, 2) void conv3x3_bf16_kernel(cdfo_conv_args a) {
-  constexpr int LDS_W = X3 ? 2 * W_HALF : W_HALF;
-  constexpr int NWS = X3 ? NW_X3 : NW_X1 + 1;
-  __shared__ __attribute__((aligned(16))) unsigned char smem[A_BYTES + LDS_W];
+template <int MODE, int WAVES_PER_SIMD, int DBG>
+__global__ __launch_bounds__(256, WAVES_PER_SIMD) void conv3x3_mma16_kernel(cdfo_conv_args a) {
+  using F = Fmt<MODE>;
+  using frag_t = typename F::frag;
+  constexpr bool F16 = MODE == M_FP16X2;
+  constexpr int LDS_W = F::WLO ? 2 * W_HALF : W_HALF;
+  constexpr int NWU = LDS_W / 16;                 // 16-byte units in the weight slab
+  constexpr int NWS = (NWU + 255) / 256;          // per-thread weight loads per chunk (9 or 5)
+  constexpr int EPI = ConvEpi<2>::BLOCK_BYTES;
+  constexpr int SMEM = (A_BYTES + LDS_W) > EPI ? (A_BYTES + LDS_W) : EPI;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM];
   unsigned char* sA = smem;
   unsigned char* sW = smem + A_BYTES;
 
@@ -111,7 +148,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bf16_kernel(cdfo_conv_args a) 
     for (int s = 0; s < NWS; ++s) {
       const int idx = tid + 256 * s;          // 16-byte unit inside the [hi rows | lo rows] slab
       const int row = idx >> 6, n = idx & 63;  // row = (tap*2+h) (+18 for lo)
-      if (X3 || idx < W_HALF / 16) {
+      if (idx < NWU) {
         const int rr = row >= 18 ? row - 18 : row;
         const unsigned short* g = wq + (row >= 18 ? lo_off : 0) + ((long long)(c * 18 + rr) * a.CoutP + n0 + n) * 8;
         rw[s] = *reinterpret_cast<const u32x4*>(g);
@@ -124,41 +161,61 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bf16_kernel(cdfo_conv_args a) 
       if (a_lds[s] < 0) continue;
       const f32x4 v = ra[s];
       u32x2 hi, lo;
-      hi[0] = pack_bf16(v[0], v[1]);
-      hi[1] = pack_bf16(v[2], v[3]);
+      hi[0] = pack16<F16>(v[0], v[1]);
+      hi[1] = pack16<F16>(v[2], v[3]);
       *reinterpret_cast<u32x2*>(sA + a_lds[s]) = hi;
-      if (X3) {
-        lo[0] = pack_bf16(v[0] - bf16_round(v[0]), v[1] - bf16_round(v[1]));
-        lo[1] = pack_bf16(v[2] - bf16_round(v[2]), v[3] - bf16_round(v[3]));
+      if (F::ALO) {
+        lo[0] = pack16<F16>(v[0] - round16<F16>(v[0]), v[1] - round16<F16>(v[1]));
+        lo[1] = pack16<F16>(v[2] - round16<F16>(v[2]), v[3] - round16<F16>(v[3]));
         *reinterpret_cast<u32x2*>(sA + a_lds[s] + 32) = lo;
       }
     }
 #pragma unroll
     for (int s = 0; s < NWS; ++s) {
       const int idx = tid + 256 * s;
-      if (X3 || idx < W_HALF / 16) *reinterpret_cast<u32x4*>(sW + idx * 16) = rw[s];
+      if (idx < NWU) *reinterpret_cast<u32x4*>(sW + idx * 16) = rw[s];
     }
+  };
+
+  frag_t fah[2][2], fal[2][2], fbh[2][2], fbl[2][2];     // [parity][tile]: fragments are read one tap ahead
+  auto load_frags = [&](int t, int par) {
+    const int dy = t / 3, dx = t - dy * 3;
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) {
+      fah[par][mi] = *reinterpret_cast<const frag_t*>(sA + a_off[mi] + (dy * IW + dx) * PIXB);
+      if (F::ALO) fal[par][mi] = *reinterpret_cast<const frag_t*>(sA + a_off[mi] + (dy * IW + dx) * PIXB + 32);
+    }
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) {
+      fbh[par][ni] = *reinterpret_cast<const frag_t*>(sW + (t * 2 * 64 + ni * 32) * 16 + b_off);
+      if (F::WLO) fbl[par][ni] = *reinterpret_cast<const frag_t*>(sW + W_HALF + (t * 2 * 64 + ni * 32) * 16 + b_off);
+    }
+  };
+  auto mma_tap = [&](int par) {
+    if (DBG & 1) {
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) acc[mi][ni][0] += (float)fah[par][mi][0] * (float)fbh[par][ni][0];
+      return;
+    }
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni) {
+        if (F::ALO) acc[mi][ni] = mma(fal[par][mi], fbh[par][ni], acc[mi][ni]);
+        if (F::WLO) acc[mi][ni] = mma(fah[par][mi], fbl[par][ni], acc[mi][ni]);
+        acc[mi][ni] = mma(fah[par][mi], fbh[par][ni], acc[mi][ni]);
+      }
   };
 
   issue_loads(0);
   write_lds();
   __syncthreads();
   for (int c = 0; c < nchunks; ++c) {
-    if (c + 1 < nchunks && !(DBG & 2)) issue_loads(c + 1);  // in flight while the MFMAs below run
-    bf16x8_t fah[2][2], fal[2][2], fbh[2][2], fbl[2][2];     // [parity][tile]: fragments are read one tap ahead
-    auto load_frags = [&](int t, int par) {
-      const int dy = t / 3, dx = t - dy * 3;
-#pragma unroll
-      for (int mi = 0; mi < 2; ++mi) {
-        fah[par][mi] = *reinterpret_cast<const bf16x8_t*>(sA + a_off[mi] + (dy * IW + dx) * PIXB);
-        if (X3) fal[par][mi] = *reinterpret_cast<const bf16x8_t*>(sA + a_off[mi] + (dy * IW + dx) * PIXB + 32);
-      }
-#pragma unroll
-      for (int ni = 0; ni < 2; ++ni) {
-        fbh[par][ni] = *reinterpret_cast<const bf16x8_t*>(sW + (t * 2 * 64 + ni * 32) * 16 + b_off);
-        if (X3) fbl[par][ni] = *reinterpret_cast<const bf16x8_t*>(sW + W_HALF + (t * 2 * 64 + ni * 32) * 16 + b_off);
-      }
-    };
+    // two waves per SIMD: next chunk's operands travel in registers while the MFMAs below run; with three waves per
+    // SIMD the registers are not there (168 budget) and the other workgroups cover the latency instead
+    if (WAVES_PER_SIMD <= 2 && c + 1 < nchunks && !(DBG & 2)) issue_loads(c + 1);
     if (a.tap_mask) {
       // sparse taps (stride-2-composed conv in space-to-depth form: 4 of the 9 taps carry weights per chunk)
       const unsigned tm = a.tap_mask[c];
@@ -166,47 +223,27 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bf16_kernel(cdfo_conv_args a) 
       for (int t = 0; t < 9; ++t) {
         if (!((tm >> t) & 1u)) continue;
         load_frags(t, 0);
-#pragma unroll
-        for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-          for (int ni = 0; ni < 2; ++ni) {
-            if (X3) {
-              acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fal[0][mi], fbh[0][ni], acc[mi][ni], 0, 0, 0);
-              acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fah[0][mi], fbl[0][ni], acc[mi][ni], 0, 0, 0);
-            }
-            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fah[0][mi], fbh[0][ni], acc[mi][ni], 0, 0, 0);
-          }
+        mma_tap(0);
       }
     } else {
-    load_frags(0, 0);
+      if (WAVES_PER_SIMD <= 2) {   // two waves per SIMD: read the fragments one tap ahead
+        load_frags(0, 0);
 #pragma unroll
-    for (int t = 0; t < 9; ++t) {
-      const int par = t & 1;
-      if (t < 8) load_frags(t + 1, par ^ 1);
-      if (DBG & 1) {
-#pragma unroll
-        for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-          for (int ni = 0; ni < 2; ++ni) {
-            acc[mi][ni][0] += (float)fah[par][mi][0] * (float)fbh[par][ni][0];
-            if (X3) acc[mi][ni][1] += (float)fal[par][mi][0] * (float)fbl[par][ni][0];
-          }
-        continue;
-      }
-#pragma unroll
-      for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-        for (int ni = 0; ni < 2; ++ni) {
-          if (X3) {
-            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fal[par][mi], fbh[par][ni], acc[mi][ni], 0, 0, 0);
-            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fah[par][mi], fbl[par][ni], acc[mi][ni], 0, 0, 0);
-          }
-          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fah[par][mi], fbh[par][ni], acc[mi][ni], 0, 0, 0);
+        for (int t = 0; t < 9; ++t) {
+          if (t < 8) load_frags(t + 1, (t & 1) ^ 1);
+          mma_tap(t & 1);
         }
-    }
+      } else {                     // three waves per SIMD: the other waves hide the LDS latency.  The tap loop is
+#pragma unroll 1                   // kept rolled so that hipcc cannot hoist nine taps of fragments (216 VGPRs) at once
+        for (int t = 0; t < 9; ++t) {
+          load_frags(t, 0);
+          mma_tap(0);
+        }
+      }
     }
     if (!(DBG & 16)) __syncthreads();  // everyone is done reading this chunk's LDS image
     if (c + 1 < nchunks) {
+      if (WAVES_PER_SIMD > 2) issue_loads(c + 1);
       if (!(DBG & 4)) write_lds();
       if (!(DBG & 16)) __syncthreads();
     }
@@ -230,11 +267,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bf16_kernel(cdfo_conv_args a) 
   for (int mi = 0; mi < 2; ++mi) conv_tile_epilogue_row32<2>(a, wl, acc[mi], lane, b, oy0 + wave * 2 + mi, ox0, n0);
 }
 
-
-
-// OIHW fp32 -> [hi | lo] bf16, each [Cin/16][9][2][CoutP][8]  (k = 16*chunk + 8*h + j)
-__global__ void pack_bf16_kernel(const float* __restrict__ w, unsigned short* __restrict__ p, int Cout, int Cin,
-                                 int CoutP) {
+// OIHW fp32 -> 16-bit weights [Cin/16][9][2][CoutP][8]  (k = 16*chunk + 8*h + j):
+//   bf16: [hi block | lo block];  fp16: one block (single rounding)
+template <bool F16>
+__global__ void pack16_kernel(const float* __restrict__ w, unsigned short* __restrict__ p, int Cout, int Cin, int CoutP) {
   const long long half = (long long)(Cin / 16) * 18 * CoutP * 8;
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < half;
        i += (long long)gridDim.x * blockDim.x) {
@@ -247,10 +283,13 @@ __global__ void pack_bf16_kernel(const float* __restrict__ w, unsigned short* __
     const int cin = c * 16 + hh * 8 + j;
     float v = 0.f;
     if (n < Cout) v = w[((long long)n * Cin + cin) * 9 + t];
-    const __bf16 hi = (__bf16)v;
-    const __bf16 lo = (__bf16)(v - (float)hi);
-    p[i] = __builtin_bit_cast(unsigned short, hi);
-    p[half + i] = __builtin_bit_cast(unsigned short, lo);
+    if (F16) {
+      p[i] = __builtin_bit_cast(unsigned short, (_Float16)v);
+    } else {
+      const __bf16 hi = (__bf16)v;
+      p[i] = __builtin_bit_cast(unsigned short, hi);
+      p[half + i] = __builtin_bit_cast(unsigned short, (__bf16)(v - (float)hi));
+    }
   }
 }
 
@@ -277,34 +316,48 @@ extern "C" int cdfo_conv3x3_bf16(const cdfo_conv_args* pa, void* stream) {
   const double px = (double)a.B * a.Ho * a.Wo;
   CdfoProfScope prof(st, KID_CONV3_WIDE, 2.0 * px * a.Cout * a.Cin * 9,
                      4.0 * (px * a.Cout + px * a.Cin + 9.0 * a.Cin * a.Cout));
-  const int dbg = a.prec >> 8;
-  if ((a.prec & 255) == CDFO_PREC_BF16X3 && dbg) {
-#define CDFO_DBG_CASE(D) case D: hipLaunchKernelGGL((conv3x3_bf16_kernel<true, D>), grid, dim3(256), 0, st, a); break;
+  const int dbg = a.prec >> 8, prec = a.prec & 255;
+  if (dbg) {   // developer ablations of the split-bf16 kernel (tools/bench_conv.py)
+    if (prec != CDFO_PREC_BF16X3) return CDFO_EINVAL;
+#define CDFO_DBG_CASE(D) case D: hipLaunchKernelGGL((conv3x3_mma16_kernel<M_BF16X3, 2, D>), grid, dim3(256), 0, st, a); break;
     switch (dbg) {
       CDFO_DBG_CASE(1) CDFO_DBG_CASE(2) CDFO_DBG_CASE(3) CDFO_DBG_CASE(4) CDFO_DBG_CASE(7) CDFO_DBG_CASE(8)
-      CDFO_DBG_CASE(9) CDFO_DBG_CASE(15) CDFO_DBG_CASE(16) CDFO_DBG_CASE(31) CDFO_DBG_CASE(23) CDFO_DBG_CASE(6)
+      CDFO_DBG_CASE(15) CDFO_DBG_CASE(16) CDFO_DBG_CASE(31)
       default: return CDFO_EINVAL;
     }
 #undef CDFO_DBG_CASE
-  }
-  else if (a.prec == CDFO_PREC_BF16X3)
-    hipLaunchKernelGGL(conv3x3_bf16_kernel<true>, grid, dim3(256), 0, st, a);
-  else if (a.prec == CDFO_PREC_BF16)
-    hipLaunchKernelGGL(conv3x3_bf16_kernel<false>, grid, dim3(256), 0, st, a);
-  else
+  } else if (prec == CDFO_PREC_BF16X3) {
+    hipLaunchKernelGGL((conv3x3_mma16_kernel<M_BF16X3, 2, 0>), grid, dim3(256), 0, st, a);
+  } else if (prec == CDFO_PREC_BF16) {
+    hipLaunchKernelGGL((conv3x3_mma16_kernel<M_BF16, 2, 0>), grid, dim3(256), 0, st, a);
+  } else if (prec == CDFO_PREC_FP16X2) {
+    hipLaunchKernelGGL((conv3x3_mma16_kernel<M_FP16X2, 2, 0>), grid, dim3(256), 0, st, a);
+  } else {
     return CDFO_EINVAL;
+  }
   CDFO_LAUNCH_CHECK();
   return 0;
 }
 
-extern "C" int cdfo_pack_conv3x3_bf16(const float* w_oihw, void* packed, int Cout, int Cin, void* stream) {
+static int pack16_launch(const float* w, void* packed, int Cout, int Cin, bool f16, void* stream) {
   if (Cin % 16 || Cout <= 0) return CDFO_EINVAL;
   const int CoutP = (Cout + 63) / 64 * 64;
   const long long half = (long long)(Cin / 16) * 18 * CoutP * 8;
   const int blocks = (int)((half + 255) / 256 < 2048 ? (half + 255) / 256 : 2048);
   CdfoProfScope prof(static_cast<hipStream_t>(stream), KID_PACK, 0, 8.0 * half);
-  hipLaunchKernelGGL(pack_bf16_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream), w_oihw,
-                     static_cast<unsigned short*>(packed), Cout, Cin, CoutP);
+  if (f16)
+    hipLaunchKernelGGL(pack16_kernel<true>, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream), w,
+                       static_cast<unsigned short*>(packed), Cout, Cin, CoutP);
+  else
+    hipLaunchKernelGGL(pack16_kernel<false>, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream), w,
+                       static_cast<unsigned short*>(packed), Cout, Cin, CoutP);
   CDFO_LAUNCH_CHECK();
   return 0;
+}
+
+extern "C" int cdfo_pack_conv3x3_bf16(const float* w_oihw, void* packed, int Cout, int Cin, void* stream) {
+  return pack16_launch(w_oihw, packed, Cout, Cin, false, stream);
+}
+extern "C" int cdfo_pack_conv3x3_f16(const float* w_oihw, void* packed, int Cout, int Cin, void* stream) {
+  return pack16_launch(w_oihw, packed, Cout, Cin, true, stream);
 }

@@ -15,7 +15,7 @@ from . import _lib
 from ._lib import ConvArgs, check
 
 ACT_NONE, ACT_LRELU, ACT_RELU, ACT_SIGMOID = 0, 1, 2, 3
-PREC_F32, PREC_BF16X3, PREC_BF16 = 0, 1, 2
+PREC_F32, PREC_BF16X3, PREC_BF16, PREC_FP16X2 = 0, 1, 2, 3
 
 
 def _stream() -> C.c_void_p:
@@ -76,6 +76,7 @@ class PackedConv:
     w_bstride: int = 0
     wq: Optional[torch.Tensor] = None   # split-bf16 packing for cdfo_conv3x3_bf16 (3x3, Cout % 64 == 0)
     tap_mask: Optional[torch.Tensor] = None   # int32 [Cin/16]: bit t set = tap t of that chunk has weights
+    wh: Optional[torch.Tensor] = None   # fp16 packing (single block) for PREC_FP16X2
 
 
 def pack_conv(weight: torch.Tensor, bias: Optional[torch.Tensor], shuffle2: bool = False,
@@ -102,6 +103,10 @@ def pack_conv(weight: torch.Tensor, bias: Optional[torch.Tensor], shuffle2: bool
         check(_lib.lib().cdfo_pack_conv3x3_bf16(C.c_void_p(w.data_ptr()), C.c_void_p(wq.data_ptr()), Cout, Cin,
                                                 _stream()), "cdfo_pack_conv3x3_bf16")
         pc.wq = wq
+        wh = torch.empty((Cin // 16) * 18 * Cout * 8, dtype=torch.float16, device=w.device)
+        check(_lib.lib().cdfo_pack_conv3x3_f16(C.c_void_p(w.data_ptr()), C.c_void_p(wh.data_ptr()), Cout, Cin, _stream()),
+              "cdfo_pack_conv3x3_f16")
+        pc.wh = wh
     return pc
 
 
@@ -159,7 +164,7 @@ def conv(srcs: Sequence[torch.Tensor], pc: PackedConv, *, stride: int = 1, pad: 
             setattr(a, "ldr" + nm[-1], rld)
     if (prec != PREC_F32 and pc.wq is not None and stride == 1 and pad == 1 and pc.w_bstride == 0):
         a.prec = prec
-        a.w = pc.wq.data_ptr()
+        a.w = (pc.wh if prec == PREC_FP16X2 else pc.wq).data_ptr()
         a.tap_mask = _p(pc.tap_mask)
         check(_lib.lib().cdfo_conv3x3_bf16(C.byref(a), _stream()), "cdfo_conv3x3_bf16")
         return out

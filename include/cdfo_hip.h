@@ -25,7 +25,7 @@ extern "C" {
 
 enum { CDFO_ACT_NONE = 0, CDFO_ACT_LRELU = 1, CDFO_ACT_RELU = 2, CDFO_ACT_SIGMOID = 3 };
 enum { CDFO_STORE_PLAIN = 0, CDFO_STORE_SHUFFLE2 = 1, CDFO_STORE_S2D = 2 };
-enum { CDFO_PREC_F32 = 0, CDFO_PREC_BF16X3 = 1, CDFO_PREC_BF16 = 2 };
+enum { CDFO_PREC_F32 = 0, CDFO_PREC_BF16X3 = 1, CDFO_PREC_BF16 = 2, CDFO_PREC_FP16X2 = 3 };
 
 /* ABI version / build info.  */
 int cdfo_abi_version(void);
@@ -62,10 +62,12 @@ int cdfo_pack_conv_weight(const float* w_oihw, float* packed, int Cout, int Cin,
                           int transposed, void* stream);
 
 /* 3x3 / stride 1 / pad 1 convolution on the bf16 matrix cores, fp32 accumulate; same argument block and epilogue as
- * cdfo_conv_igemm.  a->prec = CDFO_PREC_BF16X3 (split-bf16, fp32-grade accuracy) or CDFO_PREC_BF16 (plain bf16);
- * a->w = weights packed by cdfo_pack_conv3x3_bf16 ([hi|lo] x [Cin/16][9][2][CoutP][8] bf16, CoutP = Cout up to 64).  */
+ * cdfo_conv_igemm.  a->prec = CDFO_PREC_BF16X3 (split-bf16, 3 passes, fp32-grade), CDFO_PREC_BF16 (plain bf16) -- both
+ * with a->w packed by cdfo_pack_conv3x3_bf16 ([hi|lo] x [Cin/16][9][2][CoutP][8] bf16, CoutP = Cout up to 64) -- or
+ * CDFO_PREC_FP16X2 (fp16 hi+lo activations x fp16 weights, 2 passes; a->w packed by cdfo_pack_conv3x3_f16, one block).  */
 int cdfo_conv3x3_bf16(const cdfo_conv_args* a, void* stream);
 int cdfo_pack_conv3x3_bf16(const float* w_oihw, void* packed, int Cout, int Cin, void* stream);
+int cdfo_pack_conv3x3_f16(const float* w_oihw, void* packed, int Cout, int Cin, void* stream);
 
 /* Layout changes at the module boundary (reference tensors are NCHW).  */
 int cdfo_nchw_to_nhwc(const float* in, float* out, int B, int C, int H, int W, int ldo, void* stream);

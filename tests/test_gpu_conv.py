@@ -107,7 +107,7 @@ def test_layout_roundtrip():
 
 
 @pytest.mark.parametrize("Cin,Cout,H,W,B", [(64, 256, 24, 40, 1), (256, 64, 20, 18, 2), (128, 64, 16, 16, 1), (64, 64, 33, 17, 1)])
-@pytest.mark.parametrize("prec,tol", [(1, 3e-5), (2, 2e-2)])
+@pytest.mark.parametrize("prec,tol", [(1, 3e-5), (2, 2e-2), (3, 1e-3)])
 def test_conv3x3_bf16_family(Cin, Cout, H, W, B, prec, tol):
     from cdfo_amd import kernels as K
     g = torch.Generator().manual_seed(Cin + Cout + H + prec)

@@ -33,3 +33,16 @@ def test_seq_attn(H, W, mode):
     torch.cuda.synchronize()
     err = (out.cpu() - ref).abs().max().item()
     assert err < 2e-5 * max(1.0, ref.abs().max().item()), err
+
+
+@pytest.mark.parametrize("C,H,W", [(192, 16, 24), (192, 9, 13), (64, 8, 8)])
+def test_dwconv3x3(C, H, W):
+    import torch.nn.functional as F
+    from cdfo_amd import kernels as K
+    g = torch.Generator().manual_seed(C + H + W)
+    x = torch.randn(2, C, H, W, generator=g)
+    w = torch.randn(C, 1, 3, 3, generator=g)
+    ref = F.conv2d(x, w, padding=1, groups=C)
+    out = K.dwconv3x3(x.permute(0, 2, 3, 1).contiguous().cuda(), w.cuda())
+    torch.cuda.synchronize()
+    assert (out.permute(0, 3, 1, 2).cpu() - ref).abs().max().item() < 1e-5

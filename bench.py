@@ -48,6 +48,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true", help="skip the c1 parity spot-check (profiling runs: keeps every launch at the workload's size)")
     ap.add_argument("--precision", default="fp16x2", choices=["f32", "bf16x3", "bf16", "fp16x2"])
+    ap.add_argument("--streaming", action="store_true", help="time the cached-feature path (pre_L1_fea given: one new frame per clip, test_LD_22_FPS.py:183-189) instead of the fresh path")
     ap.add_argument("--breakdown", type=str, default="", help="write the per-kernel-family event timings to this file")
     args = ap.parse_args()
 
@@ -93,9 +94,14 @@ def main():
     d = {k: v.to(dev) for k, v in inp.items() if k != "gumbel_u"}
     noise = [u.to(dev) for u in inp["gumbel_u"]]
 
+    pre = None
+    if args.streaming:
+        with torch.no_grad():
+            _, pre = model(d["x"], d["mvs0"], d["mvs1"], d["pms"], d["rms"], d["ufs"], gumbel_uniform=noise)
+
     def step():
         with torch.no_grad():
-            return model(d["x"], d["mvs0"], d["mvs1"], d["pms"], d["rms"], d["ufs"], gumbel_uniform=noise)
+            return model(d["x"], d["mvs0"], d["mvs1"], d["pms"], d["rms"], d["ufs"], pre, gumbel_uniform=noise)
 
     for _ in range(args.warmup):
         step()
@@ -163,7 +169,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"JCT-VC ClassB-shape synthetic clips: {B} clips/GPU x 7x1x{args.height}x{args.width} "
                                    f"luma (padded to {Hp}x{Wp}) + MV/residual/partition/unfiltered priors -> "
-                                   f"{4 * args.height}x{4 * args.width}, fresh path (pre_L1_fea=None), precision={args.precision}",
+                                   f"{4 * args.height}x{4 * args.width}, " + ("streaming path (pre_L1_fea cache hit)" if args.streaming else "fresh path (pre_L1_fea=None)") + f", precision={args.precision}",
                        "clips_per_gpu": B, "lr_padded": [Hp, Wp], "parallelism": f"batch-shard x{world}",
                        "weights": "random init (seed 0)"},
             "parity": {"config": "c1 64x64 B=1 vs CPU oracle", "max_abs": max_abs, "psnr_y_db": psnr,

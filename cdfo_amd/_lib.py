@@ -37,6 +37,7 @@ class ConvArgs(C.Structure):
         ("prec", C.c_int),
         ("ln_gamma", C.c_void_p), ("ln_beta", C.c_void_p),
         ("tap_mask", C.c_void_p),
+        ("src_f16", C.c_int), ("out_f16", C.c_int),
     ]
 
 

@@ -32,15 +32,14 @@
 #include "common.h"
 #include "conv_epilogue.h"
 
+constexpr int PIXB_F32SRC = 80;   // LDS bytes per staged pixel when converting from fp32: 32 B hi | 32 B lo | 16 B pad
+
 namespace {
 
 constexpr int TH = 8, TW = 32, IW = 34, NPIX = 34 * 10;
-constexpr int PIXB = 80;                         // LDS bytes per staged pixel
-constexpr int A_BYTES = NPIX * PIXB;             // 27,200
 constexpr int W_HALF = 9 * 2 * 64 * 16;          // 18,432 B: [tap][h][64 cout][8 x 16-bit]
-constexpr int NA = (NPIX * 4 + 255) / 256;       // 6 float4 per thread per chunk
 
-enum { M_BF16X3 = CDFO_PREC_BF16X3, M_BF16 = CDFO_PREC_BF16, M_FP16X2 = CDFO_PREC_FP16X2 };
+enum { M_BF16X3 = CDFO_PREC_BF16X3, M_BF16 = CDFO_PREC_BF16, M_FP16X2 = CDFO_PREC_FP16X2, M_FP16IN = CDFO_PREC_FP16 };
 
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
@@ -51,6 +50,8 @@ template <int MODE> struct Fmt;
 template <> struct Fmt<M_BF16X3> { using frag = bf16x8_t; static constexpr bool ALO = true, WLO = true; };
 template <> struct Fmt<M_BF16> { using frag = bf16x8_t; static constexpr bool ALO = false, WLO = false; };
 template <> struct Fmt<M_FP16X2> { using frag = f16x8_t; static constexpr bool ALO = true, WLO = false; };
+// M_FP16IN: the source tensor already holds fp16 values -> one pass, staging is a plain copy, 48-byte pixel records
+template <> struct Fmt<M_FP16IN> { using frag = f16x8_t; static constexpr bool ALO = false, WLO = false; };
 
 __device__ __forceinline__ f32x16 mma(bf16x8_t a, bf16x8_t b, f32x16 c) {
   return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
@@ -77,7 +78,11 @@ template <int MODE, int WAVES_PER_SIMD, int DBG>
 __global__ __launch_bounds__(256, WAVES_PER_SIMD) void conv3x3_mma16_kernel(cdfo_conv_args a) {
   using F = Fmt<MODE>;
   using frag_t = typename F::frag;
-  constexpr bool F16 = MODE == M_FP16X2;
+  constexpr bool F16 = MODE == M_FP16X2 || MODE == M_FP16IN;
+  constexpr bool SRC16 = MODE == M_FP16IN;
+  constexpr int PIXB = SRC16 ? 48 : ::PIXB_F32SRC;      // LDS bytes per staged pixel (odd multiple of 16: conflict-free)
+  constexpr int A_BYTES = NPIX * PIXB;
+  constexpr int NA = SRC16 ? (NPIX * 2 + 255) / 256 : (NPIX * 4 + 255) / 256;   // 16-byte loads per thread per chunk
   constexpr int LDS_W = F::WLO ? 2 * W_HALF : W_HALF;
   constexpr int NWU = LDS_W / 16;                 // 16-byte units in the weight slab
   constexpr int NWS = (NWU + 255) / 256;          // per-thread weight loads per chunk (9 or 5)
@@ -107,12 +112,13 @@ __global__ __launch_bounds__(256, WAVES_PER_SIMD) void conv3x3_mma16_kernel(cdfo
 #pragma unroll
   for (int s = 0; s < NA; ++s) {
     const int idx = tid + 256 * s;
-    const int p = idx >> 2, q = idx & 3;
+    constexpr int PER = SRC16 ? 2 : 4;             // 16-byte loads per (pixel, chunk)
+    const int p = idx / PER, q = idx % PER;
     const int iy = p / IW, ix = p - iy * IW;
     const int gy = oy0 - 1 + iy, gx = ox0 - 1 + ix;
-    const bool ok = idx < NPIX * 4 && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+    const bool ok = idx < NPIX * PER && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
     a_pix[s] = ok ? (b * a.H + gy) * a.W + gx : -1;
-    a_lds[s] = idx < NPIX * 4 ? p * PIXB + q * 8 : -1;
+    a_lds[s] = idx < NPIX * PER ? p * PIXB + q * (SRC16 ? 16 : 8) : -1;
   }
 
   f32x16 acc[2][2];
@@ -136,13 +142,23 @@ __global__ __launch_bounds__(256, WAVES_PER_SIMD) void conv3x3_mma16_kernel(cdfo
   auto issue_loads = [&](int c) {
     const int ch0 = c * 16;
     while (ch0 >= s_base + a.cs[s_idx]) { s_base += a.cs[s_idx]; ++s_idx; }
-    const float* src = a.src[s_idx] + (ch0 - s_base);
     const int ld = a.ld[s_idx];
+    if (SRC16) {       // fp16 source: 16 channels = 32 B = two 16-byte pieces per pixel
+      const _Float16* src = reinterpret_cast<const _Float16*>(a.src[s_idx]) + (ch0 - s_base);
 #pragma unroll
-    for (int s = 0; s < NA; ++s) {
-      const int q = (tid + 256 * s) & 3;
-      ra[s] = f32x4{0.f, 0.f, 0.f, 0.f};
-      if (a_pix[s] >= 0) ra[s] = *reinterpret_cast<const f32x4*>(src + (long long)a_pix[s] * ld + q * 4);
+      for (int s = 0; s < NA; ++s) {
+        const int q = (tid + 256 * s) & 1;
+        ra[s] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (a_pix[s] >= 0) ra[s] = *reinterpret_cast<const f32x4*>(src + (long long)a_pix[s] * ld + q * 8);
+      }
+    } else {
+      const float* src = a.src[s_idx] + (ch0 - s_base);
+#pragma unroll
+      for (int s = 0; s < NA; ++s) {
+        const int q = (tid + 256 * s) & 3;
+        ra[s] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (a_pix[s] >= 0) ra[s] = *reinterpret_cast<const f32x4*>(src + (long long)a_pix[s] * ld + q * 4);
+      }
     }
 #pragma unroll
     for (int s = 0; s < NWS; ++s) {
@@ -160,6 +176,10 @@ __global__ __launch_bounds__(256, WAVES_PER_SIMD) void conv3x3_mma16_kernel(cdfo
     for (int s = 0; s < NA; ++s) {
       if (a_lds[s] < 0) continue;
       const f32x4 v = ra[s];
+      if (SRC16) {     // already fp16: the 16 loaded bytes ARE the LDS image
+        *reinterpret_cast<f32x4*>(sA + a_lds[s]) = v;
+        continue;
+      }
       u32x2 hi, lo;
       hi[0] = pack16<F16>(v[0], v[1]);
       hi[1] = pack16<F16>(v[2], v[3]);
@@ -312,6 +332,8 @@ extern "C" int cdfo_conv3x3_bf16(const cdfo_conv_args* pa, void* stream) {
   if (!aligned16(a.w) || a.Cout % 4 || a.ldo % 4 || !aligned16(a.out) || (a.bias && !aligned16(a.bias))) return CDFO_EALIGN;
   if ((a.res1 && (a.ldr1 % 4 || !aligned16(a.res1))) || (a.res2 && (a.ldr2 % 4 || !aligned16(a.res2)))) return CDFO_EALIGN;
   if ((long long)a.B * a.H * a.W >= (1ll << 31)) return CDFO_EINVAL;
+  if (a.src_f16 != ((a.prec & 255) == CDFO_PREC_FP16) || (a.src_f16 && (a.nsrc != 1 || a.ld[0] % 8))) return CDFO_EINVAL;
+  if (a.out_f16 && (a.res1 || a.res2 || a.store_mode == CDFO_STORE_SHUFFLE2)) return CDFO_EINVAL;
   dim3 grid(cdiv(cdiv(a.Wo, TW) * cdiv(a.Ho, TH) * a.B, 8) * 8 * (a.CoutP / 64));
   const double px = (double)a.B * a.Ho * a.Wo;
   CdfoProfScope prof(st, KID_CONV3_WIDE, 2.0 * px * a.Cout * a.Cin * 9,
@@ -332,6 +354,8 @@ extern "C" int cdfo_conv3x3_bf16(const cdfo_conv_args* pa, void* stream) {
     hipLaunchKernelGGL((conv3x3_mma16_kernel<M_BF16, 2, 0>), grid, dim3(256), 0, st, a);
   } else if (prec == CDFO_PREC_FP16X2) {
     hipLaunchKernelGGL((conv3x3_mma16_kernel<M_FP16X2, 2, 0>), grid, dim3(256), 0, st, a);
+  } else if (prec == CDFO_PREC_FP16) {
+    hipLaunchKernelGGL((conv3x3_mma16_kernel<M_FP16IN, 2, 0>), grid, dim3(256), 0, st, a);
   } else {
     return CDFO_EINVAL;
   }

@@ -45,12 +45,15 @@ __device__ __forceinline__ void conv_tile_epilogue_impl(const cdfo_conv_args& a,
     if (oy >= a.Ho) break;
     // 64-bit base once per image row of the tile; 32-bit steps inside it
     const long long pixrow = (long long)(b * a.Ho + oy) * a.Wo + ox0;
-    float* orow;
-    if (plain) orow = a.out + pixrow * a.ldo + n;
+    // element offset of this lane's first value in the row (64-bit once per image row of the tile; 32-bit steps inside)
+    long long obase;
+    if (plain) obase = pixrow * a.ldo + n;
     else if (a.store_mode == CDFO_STORE_SHUFFLE2)
-      orow = a.out + ((long long)(b * 2 * a.Ho + 2 * oy + (sub >> 1)) * (2 * a.Wo) + 2 * ox0 + (sub & 1)) * a.ldo + cc;
+      obase = ((long long)(b * 2 * a.Ho + 2 * oy + (sub >> 1)) * (2 * a.Wo) + 2 * ox0 + (sub & 1)) * a.ldo + cc;
     else  // space-to-depth: pixel (oy>>1, x>>1), phase (oy&1, x&1); ox0 is even, so x&1 == xi&1
-      orow = a.out + ((long long)(b * (a.Ho >> 1) + (oy >> 1)) * (a.Wo >> 1) + (ox0 >> 1)) * a.ldo + (oy & 1) * 2 * a.Cout + n;
+      obase = ((long long)(b * (a.Ho >> 1) + (oy >> 1)) * (a.Wo >> 1) + (ox0 >> 1)) * a.ldo + (oy & 1) * 2 * a.Cout + n;
+    float* orow = a.out + obase;
+    _Float16* orow16 = reinterpret_cast<_Float16*>(a.out) + obase;   // out_f16: same indexing, 2-byte elements
     const float* r1row = a.res1 ? a.res1 + pixrow * a.ldr1 + n : nullptr;
     const float* r2row = a.res2 ? a.res2 + pixrow * a.ldr2 + n : nullptr;
     const bool s2d = a.store_mode == CDFO_STORE_S2D;
@@ -64,8 +67,16 @@ __device__ __forceinline__ void conv_tile_epilogue_impl(const cdfo_conv_args& a,
       if (!nok || ox0 + xi >= a.Wo) continue;
       if (r1row) v += *reinterpret_cast<const f32x4*>(r1row + xi * a.ldr1);
       if (r2row) v += *reinterpret_cast<const f32x4*>(r2row + xi * a.ldr2);
-      if (s2d) *reinterpret_cast<f32x4*>(orow + (xi >> 1) * a.ldo + (xi & 1) * a.Cout) = v;
-      else *reinterpret_cast<f32x4*>(orow + xi * ostep) = v;
+      const int eoff = s2d ? (xi >> 1) * a.ldo + (xi & 1) * a.Cout : xi * ostep;
+      if (a.out_f16) {
+        typedef _Float16 f16x4_t __attribute__((ext_vector_type(4)));
+        f16x4_t hv;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) hv[k] = (_Float16)v[k];
+        *reinterpret_cast<f16x4_t*>(orow16 + eoff) = hv;
+      } else {
+        *reinterpret_cast<f32x4*>(orow + eoff) = v;
+      }
     }
   }
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");

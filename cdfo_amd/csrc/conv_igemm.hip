@@ -230,7 +230,7 @@ extern "C" int cdfo_conv_igemm(const cdfo_conv_args* pa, void* stream) {
   if (a.store_mode == CDFO_STORE_SHUFFLE2 && (a.Cout % 16 || a.res1 || a.res2)) return CDFO_EINVAL;
   if (a.Cout % 4 || a.ldo % 4 || !aligned16(a.out) || (a.bias && !aligned16(a.bias))) return CDFO_EALIGN;
   if ((a.res1 && (a.ldr1 % 4 || !aligned16(a.res1))) || (a.res2 && (a.ldr2 % 4 || !aligned16(a.res2)))) return CDFO_EALIGN;
-  if (a.prec != CDFO_PREC_F32 || a.tap_mask) return CDFO_EINVAL;
+  if (a.prec != CDFO_PREC_F32 || a.tap_mask || a.src_f16 || a.out_f16) return CDFO_EINVAL;
   if (a.store_mode == CDFO_STORE_S2D && ((a.Ho | a.Wo) & 1 || a.res1 || a.res2)) return CDFO_EINVAL;
   const bool wide = (a.CoutP % 64) == 0;
   bool k64 = a.ks == 1 && a.stride == 1 && wide;       // 1x1: stage whole 64-channel pixels (HBM-bound streaming)

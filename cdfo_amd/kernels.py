@@ -15,7 +15,7 @@ from . import _lib
 from ._lib import ConvArgs, check
 
 ACT_NONE, ACT_LRELU, ACT_RELU, ACT_SIGMOID = 0, 1, 2, 3
-PREC_F32, PREC_BF16X3, PREC_BF16, PREC_FP16X2 = 0, 1, 2, 3
+PREC_F32, PREC_BF16X3, PREC_BF16, PREC_FP16X2, PREC_FP16 = 0, 1, 2, 3, 4
 
 
 def _stream() -> C.c_void_p:
@@ -26,10 +26,10 @@ def _p(t: Optional[torch.Tensor]) -> Optional[int]:
     return None if t is None else t.data_ptr()
 
 
-def _chk_act(t: torch.Tensor, name: str = "tensor"):
+def _chk_act(t: torch.Tensor, name: str = "tensor", dtype=torch.float32):
     if not t.is_cuda:
         raise NotImplementedError(f"{name}: the HIP path needs device tensors (no CPU fallback)")
-    if t.dtype != torch.float32 or t.dim() != 4 or t.stride(3) != 1:
+    if t.dtype != dtype or t.dim() != 4 or t.stride(3) != 1:
         raise ValueError(f"{name}: expected fp32 [B,H,W,C] with contiguous channels, got {t.dtype} {tuple(t.shape)} "
                          f"strides {t.stride()}")
     B, H, W, Cc = t.shape
@@ -113,14 +113,20 @@ def pack_conv(weight: torch.Tensor, bias: Optional[torch.Tensor], shuffle2: bool
 def conv(srcs: Sequence[torch.Tensor], pc: PackedConv, *, stride: int = 1, pad: int = 0, act: int = ACT_NONE,
          res1: Optional[torch.Tensor] = None, res2: Optional[torch.Tensor] = None,
          out: Optional[torch.Tensor] = None, prec: int = PREC_F32,
-         ln: Optional[tuple] = None, s2d: bool = False) -> torch.Tensor:
+         ln: Optional[tuple] = None, s2d: bool = False, out_f16: bool = False) -> torch.Tensor:
     if isinstance(srcs, torch.Tensor):
         srcs = [srcs]
     a = ConvArgs()
     B = H = W = None
     cin = 0
+    src_f16 = srcs[0].dtype == torch.float16       # Block_'s fp16 body intermediate (single source, 1-pass fp16 MFMA)
+    if src_f16:
+        prec = PREC_FP16
+    elif prec == PREC_FP16:
+        raise ValueError("PREC_FP16 needs an fp16 source tensor")
+    odt = torch.float16 if out_f16 else torch.float32
     for i, s in enumerate(srcs):
-        b_, h_, w_, c_, ld_ = _chk_act(s, f"src{i}")
+        b_, h_, w_, c_, ld_ = _chk_act(s, f"src{i}", torch.float16 if src_f16 else torch.float32)
         if B is None:
             B, H, W = b_, h_, w_
         elif (B, H, W) != (b_, h_, w_):
@@ -147,13 +153,14 @@ def conv(srcs: Sequence[torch.Tensor], pc: PackedConv, *, stride: int = 1, pad: 
         a.store_mode = 1
     elif s2d:
         if out is None:
-            out = empty_act(B, Ho // 2, Wo // 2, 4 * pc.Cout, srcs[0].device)
+            out = torch.empty((B, Ho // 2, Wo // 2, 4 * pc.Cout), dtype=odt, device=srcs[0].device)
         a.store_mode = 2
     else:
         if out is None:
-            out = empty_act(B, Ho, Wo, pc.Cout, srcs[0].device)
+            out = torch.empty((B, Ho, Wo, pc.Cout), dtype=odt, device=srcs[0].device)
         a.store_mode = 0
-    _, _, _, _, a.ldo = _chk_act(out, "out")
+    _, _, _, _, a.ldo = _chk_act(out, "out", odt)
+    a.src_f16, a.out_f16 = int(src_f16), int(out_f16)
     a.out = out.data_ptr()
     for nm, r in (("res1", res1), ("res2", res2)):
         if r is not None:
@@ -164,10 +171,12 @@ def conv(srcs: Sequence[torch.Tensor], pc: PackedConv, *, stride: int = 1, pad: 
             setattr(a, "ldr" + nm[-1], rld)
     if (prec != PREC_F32 and pc.wq is not None and stride == 1 and pad == 1 and pc.w_bstride == 0):
         a.prec = prec
-        a.w = (pc.wh if prec == PREC_FP16X2 else pc.wq).data_ptr()
+        a.w = (pc.wh if prec in (PREC_FP16X2, PREC_FP16) else pc.wq).data_ptr()
         a.tap_mask = _p(pc.tap_mask)
         check(_lib.lib().cdfo_conv3x3_bf16(C.byref(a), _stream()), "cdfo_conv3x3_bf16")
         return out
+    if src_f16 or out_f16:
+        raise ValueError("fp16 tensors are only supported by the 16-bit MFMA 3x3 kernel")
     a.prec = 0
     if ln is not None:
         a.ln_gamma, a.ln_beta = ln[0].data_ptr(), ln[1].data_ptr()

@@ -25,7 +25,7 @@ extern "C" {
 
 enum { CDFO_ACT_NONE = 0, CDFO_ACT_LRELU = 1, CDFO_ACT_RELU = 2, CDFO_ACT_SIGMOID = 3 };
 enum { CDFO_STORE_PLAIN = 0, CDFO_STORE_SHUFFLE2 = 1, CDFO_STORE_S2D = 2 };
-enum { CDFO_PREC_F32 = 0, CDFO_PREC_BF16X3 = 1, CDFO_PREC_BF16 = 2, CDFO_PREC_FP16X2 = 3 };
+enum { CDFO_PREC_F32 = 0, CDFO_PREC_BF16X3 = 1, CDFO_PREC_BF16 = 2, CDFO_PREC_FP16X2 = 3, CDFO_PREC_FP16 = 4 };
 
 /* ABI version / build info.  */
 int cdfo_abi_version(void);
@@ -51,6 +51,8 @@ typedef struct {
   int prec;
   const float* ln_gamma; const float* ln_beta;   /* optional fused per-pixel LayerNorm of a single 64-channel source (1x1 only) */
   const unsigned* tap_mask;   /* optional, cdfo_conv3x3_bf16 only: per 16-channel chunk, bit t set = tap t has non-zero weights */
+  int src_f16;                /* cdfo_conv3x3_bf16 only: the single source is an fp16 tensor (ld in halves); implies CDFO_PREC_FP16 */
+  int out_f16;                /* cdfo_conv3x3_bf16 only: store the result as fp16 (ldo in halves); no residual inputs */
 } cdfo_conv_args;
 int cdfo_conv_igemm(const cdfo_conv_args* a, void* stream);
 
@@ -64,7 +66,9 @@ int cdfo_pack_conv_weight(const float* w_oihw, float* packed, int Cout, int Cin,
 /* 3x3 / stride 1 / pad 1 convolution on the bf16 matrix cores, fp32 accumulate; same argument block and epilogue as
  * cdfo_conv_igemm.  a->prec = CDFO_PREC_BF16X3 (split-bf16, 3 passes, fp32-grade), CDFO_PREC_BF16 (plain bf16) -- both
  * with a->w packed by cdfo_pack_conv3x3_bf16 ([hi|lo] x [Cin/16][9][2][CoutP][8] bf16, CoutP = Cout up to 64) -- or
- * CDFO_PREC_FP16X2 (fp16 hi+lo activations x fp16 weights, 2 passes; a->w packed by cdfo_pack_conv3x3_f16, one block).  */
+ * CDFO_PREC_FP16X2 (fp16 hi+lo activations x fp16 weights, 2 passes; a->w packed by cdfo_pack_conv3x3_f16, one block),
+ * or CDFO_PREC_FP16 with a->src_f16 (the source already IS an fp16 tensor -- Block_'s 256-channel body intermediate,
+ * whose rounding to fp16 does not move the forward's error -- one pass, staging is a plain 16-byte copy).  */
 int cdfo_conv3x3_bf16(const cdfo_conv_args* a, void* stream);
 int cdfo_pack_conv3x3_bf16(const float* w_oihw, void* packed, int Cout, int Cin, void* stream);
 int cdfo_pack_conv3x3_f16(const float* w_oihw, void* packed, int Cout, int Cin, void* stream);

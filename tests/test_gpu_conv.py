@@ -151,3 +151,31 @@ def test_conv1x1_fused_layernorm_and_wide_sources():
     out2 = K.conv([_nhwc(t).cuda() for t in xs], K.pack_conv(w2.cuda(), b2.cuda()), act=K.ACT_LRELU)
     torch.cuda.synchronize()
     _cmp(out2, ref2, 2e-5, "7-source 1x1")
+
+
+def test_conv3x3_fp16_intermediate_chain():
+    """conv1 (fp16x2, fp16 output, optionally space-to-depth) -> conv2 (fp16 source, 1 pass) against torch on the
+    fp16-rounded intermediate."""
+    from cdfo_amd import kernels as K
+    g = torch.Generator().manual_seed(21)
+    B, H, W = 1, 16, 40
+    x = torch.randn(B, 64, H, W, generator=g)
+    w1 = torch.randn(256, 64, 3, 3, generator=g) / 24.0
+    b1 = torch.randn(256, generator=g) * 0.1
+    w2 = torch.randn(64, 256, 3, 3, generator=g) / 48.0
+    b2 = torch.randn(64, generator=g) * 0.1
+    r = torch.randn(B, 64, H, W, generator=g)
+    pc1, pc2 = K.pack_conv(w1.cuda(), b1.cuda()), K.pack_conv(w2.cuda(), b2.cuda())
+    t = K.conv([_nhwc(x).cuda()], pc1, pad=1, act=K.ACT_LRELU, prec=K.PREC_FP16X2, out_f16=True)
+    assert t.dtype == torch.float16
+    t_ref = F.leaky_relu(F.conv2d(x, w1, b1, padding=1), 0.1)
+    _cmp(t.float(), t_ref, 2e-3, "conv1 -> fp16")
+    out = K.conv([t], pc2, pad=1, res1=_nhwc(r).cuda())
+    torch.cuda.synchronize()
+    ref = F.conv2d(t.float().permute(0, 3, 1, 2).cpu(), w2.half().float(), b2, padding=1) + r
+    _cmp(out, ref, 1e-4, "conv2 from fp16 source")
+    # space-to-depth + fp16 store
+    t2 = K.conv([_nhwc(x).cuda()], pc1, pad=1, act=K.ACT_LRELU, prec=K.PREC_FP16X2, s2d=True, out_f16=True)
+    torch.cuda.synchronize()
+    exp = t.view(B, H // 2, 2, W // 2, 2, 256).permute(0, 1, 3, 2, 4, 5).reshape(B, H // 2, W // 2, 1024)
+    assert torch.equal(t2, exp)

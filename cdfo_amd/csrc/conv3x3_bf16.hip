@@ -39,7 +39,8 @@ namespace {
 constexpr int TH = 8, TW = 32, IW = 34, NPIX = 34 * 10;
 constexpr int W_HALF = 9 * 2 * 64 * 16;          // 18,432 B: [tap][h][64 cout][8 x 16-bit]
 
-enum { M_BF16X3 = CDFO_PREC_BF16X3, M_BF16 = CDFO_PREC_BF16, M_FP16X2 = CDFO_PREC_FP16X2, M_FP16IN = CDFO_PREC_FP16 };
+enum { M_BF16X3 = CDFO_PREC_BF16X3, M_BF16 = CDFO_PREC_BF16, M_FP16X2 = CDFO_PREC_FP16X2, M_FP16IN = CDFO_PREC_FP16,
+       M_FP16X1 = CDFO_PREC_FP16X1 };
 
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
@@ -52,6 +53,8 @@ template <> struct Fmt<M_BF16> { using frag = bf16x8_t; static constexpr bool AL
 template <> struct Fmt<M_FP16X2> { using frag = f16x8_t; static constexpr bool ALO = true, WLO = false; };
 // M_FP16IN: the source tensor already holds fp16 values -> one pass, staging is a plain copy, 48-byte pixel records
 template <> struct Fmt<M_FP16IN> { using frag = f16x8_t; static constexpr bool ALO = false, WLO = false; };
+// M_FP16X1: fp32 source rounded once to fp16 while staging, one pass
+template <> struct Fmt<M_FP16X1> { using frag = f16x8_t; static constexpr bool ALO = false, WLO = false; };
 
 __device__ __forceinline__ f32x16 mma(bf16x8_t a, bf16x8_t b, f32x16 c) {
   return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
@@ -78,9 +81,9 @@ template <int MODE, int WAVES_PER_SIMD, int DBG>
 __global__ __launch_bounds__(256, WAVES_PER_SIMD) void conv3x3_mma16_kernel(cdfo_conv_args a) {
   using F = Fmt<MODE>;
   using frag_t = typename F::frag;
-  constexpr bool F16 = MODE == M_FP16X2 || MODE == M_FP16IN;
+  constexpr bool F16 = MODE == M_FP16X2 || MODE == M_FP16IN || MODE == M_FP16X1;
   constexpr bool SRC16 = MODE == M_FP16IN;
-  constexpr int PIXB = SRC16 ? 48 : ::PIXB_F32SRC;      // LDS bytes per staged pixel (odd multiple of 16: conflict-free)
+  constexpr int PIXB = (SRC16 || MODE == M_FP16X1) ? 48 : ::PIXB_F32SRC;      // LDS bytes per staged pixel (odd multiple of 16: conflict-free)
   constexpr int A_BYTES = NPIX * PIXB;
   constexpr int NA = SRC16 ? (NPIX * 2 + 255) / 256 : (NPIX * 4 + 255) / 256;   // 16-byte loads per thread per chunk
   constexpr int LDS_W = F::WLO ? 2 * W_HALF : W_HALF;
@@ -356,6 +359,8 @@ extern "C" int cdfo_conv3x3_bf16(const cdfo_conv_args* pa, void* stream) {
     hipLaunchKernelGGL((conv3x3_mma16_kernel<M_FP16X2, 2, 0>), grid, dim3(256), 0, st, a);
   } else if (prec == CDFO_PREC_FP16) {
     hipLaunchKernelGGL((conv3x3_mma16_kernel<M_FP16IN, 2, 0>), grid, dim3(256), 0, st, a);
+  } else if (prec == CDFO_PREC_FP16X1) {
+    hipLaunchKernelGGL((conv3x3_mma16_kernel<M_FP16X1, 2, 0>), grid, dim3(256), 0, st, a);
   } else {
     return CDFO_EINVAL;
   }

@@ -223,12 +223,16 @@ class CVSR_V8(nn.Module):
     # -- arithmetic of the 3x3 convolutions ---------------------------------------------------------------------
     PRECISIONS = {"f32": K.PREC_F32, "bf16x3": K.PREC_BF16X3, "bf16": K.PREC_BF16, "fp16x2": K.PREC_FP16X2}
 
-    def _conv(self, *args, exact=False, **kw):
+    def _conv(self, *args, exact=False, inner=False, **kw):
         """``exact``: convolutions whose result is RETURNED to the caller (the L1_fea feature cache) never drop below
         split-bf16 accuracy, so both outputs of forward() stay inside the 1e-3 bound in every parity-grade mode."""
         prec = self.PRECISIONS[self.precision]
         if exact and prec == K.PREC_FP16X2:
             prec = K.PREC_BF16X3
+        elif inner and prec == K.PREC_FP16X2:
+            # convolutions inside Block_: a single fp16 rounding of their input leaves the forward's error where the
+            # fp16 weight rounding puts it (2.76e-4 -> 2.78e-4 in the oracle emulation): one MFMA pass
+            prec = K.PREC_FP16X1
         return K.conv(*args, prec=prec, **kw)
 
     # -- building blocks ------------------------------------------------------------------------------------------
@@ -305,15 +309,15 @@ class CVSR_V8(nn.Module):
         # error: 2.76e-4 with and without, oracle emulation) -> half the HBM bytes between the two convs, body.2 becomes
         # a single-pass fp16 MFMA whose staging is a plain copy
         t16 = self.precision == "fp16x2"
-        out = self._conv(self._conv(x, b0, pad=1, act=K.ACT_LRELU, out_f16=t16), b2, pad=1, res1=x)
+        out = self._conv(self._conv(x, b0, pad=1, act=K.ACT_LRELU, out_f16=t16, inner=True), b2, pad=1, res1=x)
         # half-resolution branch
         d = self._conv(K.resample2(x, up=False), dn)
-        d = self._conv(self._conv(d, b0, pad=1, act=K.ACT_LRELU, out_f16=t16), b2, pad=1)
+        d = self._conv(self._conv(d, b0, pad=1, act=K.ACT_LRELU, out_f16=t16, inner=True), b2, pad=1)
         K.resample2(self._conv(d, up), up=True, out=out, accumulate=True)
         # double-resolution branch: conv1 writes its 256 channels space-to-depth; conv2 + 2x2 mean + down.0 are one
         # composed sparse-tap convolution at the block's own resolution (see _weights)
         u = K.resample2(self._conv(x, up), up=True)
-        t = self._conv(u, b0, pad=1, act=K.ACT_LRELU, s2d=True, out_f16=t16)
+        t = self._conv(u, b0, pad=1, act=K.ACT_LRELU, s2d=True, out_f16=t16, inner=True)
         return self._conv(t, w[p + "down_fused"], pad=1, res1=out)
 
     def _trunk(self, w, fused):

@@ -15,7 +15,7 @@ from . import _lib
 from ._lib import ConvArgs, check
 
 ACT_NONE, ACT_LRELU, ACT_RELU, ACT_SIGMOID = 0, 1, 2, 3
-PREC_F32, PREC_BF16X3, PREC_BF16, PREC_FP16X2, PREC_FP16 = 0, 1, 2, 3, 4
+PREC_F32, PREC_BF16X3, PREC_BF16, PREC_FP16X2, PREC_FP16, PREC_FP16X1 = 0, 1, 2, 3, 4, 5
 
 
 def _stream() -> C.c_void_p:
@@ -171,7 +171,7 @@ def conv(srcs: Sequence[torch.Tensor], pc: PackedConv, *, stride: int = 1, pad: 
             setattr(a, "ldr" + nm[-1], rld)
     if (prec != PREC_F32 and pc.wq is not None and stride == 1 and pad == 1 and pc.w_bstride == 0):
         a.prec = prec
-        a.w = (pc.wh if prec in (PREC_FP16X2, PREC_FP16) else pc.wq).data_ptr()
+        a.w = (pc.wh if prec in (PREC_FP16X2, PREC_FP16, PREC_FP16X1) else pc.wq).data_ptr()
         a.tap_mask = _p(pc.tap_mask)
         check(_lib.lib().cdfo_conv3x3_bf16(C.byref(a), _stream()), "cdfo_conv3x3_bf16")
         return out

@@ -25,7 +25,7 @@ extern "C" {
 
 enum { CDFO_ACT_NONE = 0, CDFO_ACT_LRELU = 1, CDFO_ACT_RELU = 2, CDFO_ACT_SIGMOID = 3 };
 enum { CDFO_STORE_PLAIN = 0, CDFO_STORE_SHUFFLE2 = 1, CDFO_STORE_S2D = 2 };
-enum { CDFO_PREC_F32 = 0, CDFO_PREC_BF16X3 = 1, CDFO_PREC_BF16 = 2, CDFO_PREC_FP16X2 = 3, CDFO_PREC_FP16 = 4 };
+enum { CDFO_PREC_F32 = 0, CDFO_PREC_BF16X3 = 1, CDFO_PREC_BF16 = 2, CDFO_PREC_FP16X2 = 3, CDFO_PREC_FP16 = 4, CDFO_PREC_FP16X1 = 5 };
 
 /* ABI version / build info.  */
 int cdfo_abi_version(void);
@@ -68,7 +68,9 @@ int cdfo_pack_conv_weight(const float* w_oihw, float* packed, int Cout, int Cin,
  * with a->w packed by cdfo_pack_conv3x3_bf16 ([hi|lo] x [Cin/16][9][2][CoutP][8] bf16, CoutP = Cout up to 64) -- or
  * CDFO_PREC_FP16X2 (fp16 hi+lo activations x fp16 weights, 2 passes; a->w packed by cdfo_pack_conv3x3_f16, one block),
  * or CDFO_PREC_FP16 with a->src_f16 (the source already IS an fp16 tensor -- Block_'s 256-channel body intermediate,
- * whose rounding to fp16 does not move the forward's error -- one pass, staging is a plain 16-byte copy).  */
+ * whose rounding to fp16 does not move the forward's error -- one pass, staging is a plain 16-byte copy), or
+ * CDFO_PREC_FP16X1 (fp32 source rounded once to fp16 while staging, fp16 weights, one pass: used for the convolutions
+ * INSIDE Block_, where the oracle emulation shows the forward's error is set by the weight rounding alone).  */
 int cdfo_conv3x3_bf16(const cdfo_conv_args* a, void* stream);
 int cdfo_pack_conv3x3_bf16(const float* w_oihw, void* packed, int Cout, int Cin, void* stream);
 int cdfo_pack_conv3x3_f16(const float* w_oihw, void* packed, int Cout, int Cin, void* stream);

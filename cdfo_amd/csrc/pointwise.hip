@@ -194,7 +194,7 @@ __global__ __launch_bounds__(256) void down2_kernel(const float* __restrict__ in
 }
 
 __global__ __launch_bounds__(256) void up2_kernel(const float* __restrict__ in, int ldi, int B, int H, int W, int C,
-                                                  float* __restrict__ out, int ldo, int accumulate) {
+                                                  float* __restrict__ out, int ldo, int accumulate, int out_f16) {
   const int Ho = H * 2, Wo = W * 2, cgs = C >> 2;
   const long long total = (long long)B * Ho * Wo * cgs;
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
@@ -217,6 +217,14 @@ __global__ __launch_bounds__(256) void up2_kernel(const float* __restrict__ in, 
     const f32x4 v10 = *reinterpret_cast<const f32x4*>(base + ((long long)y1 * W + x0) * ldi);
     const f32x4 v11 = *reinterpret_cast<const f32x4*>(base + ((long long)y1 * W + x1) * ldi);
     f32x4 v = (1.f - ly) * ((1.f - lx) * v00 + lx * v01) + ly * ((1.f - lx) * v10 + lx * v11);
+    if (out_f16) {   // fp16 result (feeds a single-pass fp16 convolution): ldo counts halves
+      typedef _Float16 f16x4_t __attribute__((ext_vector_type(4)));
+      f16x4_t hv;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) hv[k] = (_Float16)v[k];
+      *reinterpret_cast<f16x4_t*>(reinterpret_cast<_Float16*>(out) + p * ldo + cg * 4) = hv;
+      continue;
+    }
     float* o = out + p * ldo + cg * 4;
     if (accumulate) v += *reinterpret_cast<const f32x4*>(o);
     *reinterpret_cast<f32x4*>(o) = v;
@@ -355,13 +363,14 @@ extern "C" int cdfo_flow_warp(const float* in, int ldi, const float* mv, long lo
 }
 
 extern "C" int cdfo_resample2(const float* in, int ldi, int B, int H, int W, int C, float* out, int ldo, int up,
-                              int accumulate, void* stream) {
+                              int accumulate, int out_f16, void* stream) {
   if (B <= 0 || C % 4 || ldi % 4 || ldo % 4 || (!up && ((H | W) & 1))) return CDFO_EINVAL;
+  if (out_f16 && (!up || accumulate)) return CDFO_EINVAL;
   if (!aligned16(in) || !aligned16(out)) return CDFO_EALIGN;
   CdfoProfScope prof(static_cast<hipStream_t>(stream), KID_RESAMPLE, 0, 4.0*C*(double)B*H*W*(up?5.0:1.25));
   if (up)
     hipLaunchKernelGGL(up2_kernel, dim3(grid_for((long long)B * H * W * C)), dim3(256), 0,
-                       static_cast<hipStream_t>(stream), in, ldi, B, H, W, C, out, ldo, accumulate);
+                       static_cast<hipStream_t>(stream), in, ldi, B, H, W, C, out, ldo, accumulate, out_f16);
   else
     hipLaunchKernelGGL(down2_kernel, dim3(grid_for((long long)B * H * W * C / 16)), dim3(256), 0,
                        static_cast<hipStream_t>(stream), in, ldi, B, H, W, C, out, ldo, accumulate);

@@ -316,7 +316,7 @@ class CVSR_V8(nn.Module):
         K.resample2(self._conv(d, up), up=True, out=out, accumulate=True)
         # double-resolution branch: conv1 writes its 256 channels space-to-depth; conv2 + 2x2 mean + down.0 are one
         # composed sparse-tap convolution at the block's own resolution (see _weights)
-        u = K.resample2(self._conv(x, up), up=True)
+        u = K.resample2(self._conv(x, up), up=True, out_f16=t16)     # fp16 in fp16x2 mode: conv1 stages it by plain copy
         t = self._conv(u, b0, pad=1, act=K.ACT_LRELU, s2d=True, out_f16=t16, inner=True)
         return self._conv(t, w[p + "down_fused"], pad=1, res1=out)
 

@@ -237,16 +237,18 @@ def flow_warp(x: torch.Tensor, mv: torch.Tensor, mv_bstride: int) -> torch.Tenso
     return out
 
 
-def resample2(x: torch.Tensor, up: bool, out: Optional[torch.Tensor] = None, accumulate: bool = False) -> torch.Tensor:
+def resample2(x: torch.Tensor, up: bool, out: Optional[torch.Tensor] = None, accumulate: bool = False,
+              out_f16: bool = False) -> torch.Tensor:
     B, H, W, Cc, ld = _chk_act(x)
     Ho, Wo = (2 * H, 2 * W) if up else (H // 2, W // 2)
+    odt = torch.float16 if out_f16 else torch.float32
     if out is None:
         assert not accumulate
-        out = empty_act(B, Ho, Wo, Cc, x.device)
-    ob, oh, ow, oc, ldo = _chk_act(out, "out")
+        out = torch.empty((B, Ho, Wo, Cc), dtype=odt, device=x.device)
+    ob, oh, ow, oc, ldo = _chk_act(out, "out", odt)
     assert (ob, oh, ow, oc) == (B, Ho, Wo, Cc)
-    check(_lib.lib().cdfo_resample2(_vp(x), ld, B, H, W, Cc, _vp(out), ldo, int(up), int(accumulate), _stream()),
-          "cdfo_resample2")
+    check(_lib.lib().cdfo_resample2(_vp(x), ld, B, H, W, Cc, _vp(out), ldo, int(up), int(accumulate), int(out_f16),
+                                    _stream()), "cdfo_resample2")
     return out
 
 

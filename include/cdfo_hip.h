@@ -95,9 +95,10 @@ int cdfo_dwconv3x3(const float* in, int ldi, const float* w, int B, int H, int W
 /* flow_warp (arch.py:3068-3099); mv = [B][2][H][W] planes (x then y), image pitch mv_bstride floats. */
 int cdfo_flow_warp(const float* in, int ldi, const float* mv, long long mv_bstride, int B, int H, int W, int C,
                    float* out, int ldo, void* stream);
-/* bilinear x2 (up=1) or x0.5 (up=0), align_corners=False (arch.py:324-333); accumulate: out += result. */
+/* bilinear x2 (up=1) or x0.5 (up=0), align_corners=False (arch.py:324-333); accumulate: out += result;
+ * out_f16 (up only): `out` is an fp16 tensor (ldo in halves) that feeds a single-pass fp16 convolution. */
 int cdfo_resample2(const float* in, int ldi, int B, int H, int W, int C, float* out, int ldo, int up, int accumulate,
-                   void* stream);
+                   int out_f16, void* stream);
 /* out = in * gate[b][c] (CALayer, arch.py:2041-2043). */
 int cdfo_scale_channels(const float* in, int ldi, const float* gate, int B, long long P, int C, float* out, int ldo,
                         void* stream);

@@ -239,7 +239,7 @@ class CVSR_V8(nn.Module):
     def _udsa(self, w, x2, res):
         raw = w["raw"]
         u = "transformer_feature_extraction.path1.side_to_feaoneUDSA.body."
-        t = self._conv(x2, w[u + "0"], pad=1, act=K.ACT_LRELU)
+        t = self._conv(x2, w[u + "0"], pad=1, act=K.ACT_LRELU, exact=True)
         t = K.small_conv16(t, raw[u + "2.weight"], raw[u + "2.bias"], 2, 2, act=K.ACT_LRELU)
         t = K.small_conv16(t, raw[u + "4.weight"], raw[u + "4.bias"], 2, 2, act=K.ACT_LRELU)
         t = K.spatial_gate16(t, raw[u + "6.spatial.weight"], raw[u + "6.spatial.bias"])

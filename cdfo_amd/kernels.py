@@ -77,6 +77,7 @@ class PackedConv:
     wq: Optional[torch.Tensor] = None   # split-bf16 packing for cdfo_conv3x3_bf16 (3x3, Cout % 64 == 0)
     tap_mask: Optional[torch.Tensor] = None   # int32 [Cin/16]: bit t set = tap t of that chunk has weights
     wh: Optional[torch.Tensor] = None   # fp16 packing (single block) for PREC_FP16X2
+    CoutP16: int = 0                    # padded output channels of the 16-bit packings (multiple of 64)
 
 
 def pack_conv(weight: torch.Tensor, bias: Optional[torch.Tensor], shuffle2: bool = False,
@@ -98,12 +99,14 @@ def pack_conv(weight: torch.Tensor, bias: Optional[torch.Tensor], shuffle2: bool
             cq = Cout // 4
             b = b.view(cq, 4).t().contiguous().view(-1)
     pc = PackedConv(packed, b, Cout, Cin, ks, CoutP, shuffle2)
-    if ks == 3 and not transposed and not shuffle2 and Cout % 64 == 0 and Cin % 16 == 0:
-        wq = torch.empty(2 * (Cin // 16) * 18 * Cout * 8, dtype=torch.bfloat16, device=w.device)
+    if ks == 3 and not transposed and not shuffle2 and Cout % 4 == 0 and Cin % 16 == 0:
+        cp16 = (Cout + 63) // 64 * 64          # thin outputs (UDSA 64->16) ride on a 64-wide tile, masked in the epilogue
+        pc.CoutP16 = cp16
+        wq = torch.empty(2 * (Cin // 16) * 18 * cp16 * 8, dtype=torch.bfloat16, device=w.device)
         check(_lib.lib().cdfo_pack_conv3x3_bf16(C.c_void_p(w.data_ptr()), C.c_void_p(wq.data_ptr()), Cout, Cin,
                                                 _stream()), "cdfo_pack_conv3x3_bf16")
         pc.wq = wq
-        wh = torch.empty((Cin // 16) * 18 * Cout * 8, dtype=torch.float16, device=w.device)
+        wh = torch.empty((Cin // 16) * 18 * cp16 * 8, dtype=torch.float16, device=w.device)
         check(_lib.lib().cdfo_pack_conv3x3_f16(C.c_void_p(w.data_ptr()), C.c_void_p(wh.data_ptr()), Cout, Cin, _stream()),
               "cdfo_pack_conv3x3_f16")
         pc.wh = wh
@@ -171,6 +174,7 @@ def conv(srcs: Sequence[torch.Tensor], pc: PackedConv, *, stride: int = 1, pad: 
             setattr(a, "ldr" + nm[-1], rld)
     if (prec != PREC_F32 and pc.wq is not None and stride == 1 and pad == 1 and pc.w_bstride == 0):
         a.prec = prec
+        a.CoutP = pc.CoutP16
         a.w = (pc.wh if prec in (PREC_FP16X2, PREC_FP16, PREC_FP16X1) else pc.wq).data_ptr()
         a.tap_mask = _p(pc.tap_mask)
         check(_lib.lib().cdfo_conv3x3_bf16(C.byref(a), _stream()), "cdfo_conv3x3_bf16")

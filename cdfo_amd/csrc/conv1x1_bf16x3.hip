@@ -1,0 +1,208 @@
+// 1x1 convolution as a streaming GEMM on the bf16 matrix cores in split-bf16 (3-pass, fp32-grade) arithmetic.
+//
+// The exact-fp32 MFMA kernel (conv_igemm.hip) spends as long in v_mfma_f32_32x32x2_f32 as in HBM traffic once the
+// output is 128-256 channels wide (64->192 qkv: 2.4 TB/s algorithmic); a 1x1 convolution moves 4*(Cin+Cout) bytes per
+// pixel for 2*Cin*Cout FLOP, so it should be a pure HBM stream.  Here one workgroup owns 128 consecutive pixels of one
+// image: the 64-channel input block is read ONCE (fp32 -> bf16 hi/lo while staging, optional fused per-pixel LayerNorm)
+// and kept in LDS for every 64-wide output-channel block; weights come straight from the fp32 packing
+// [Cin/4][CoutP][4] of cdfo_pack_conv_weight (also the per-image folded attention weights) and are split on the fly.
+// Three bf16 MFMA passes (a_hi*w_hi + a_lo*w_hi + a_hi*w_lo) cost ~1/5 of the exact-fp32 MFMA time.
+//
+// Same argument block / epilogue contract as cdfo_conv_igemm (bias, LeakyReLU/ReLU, two residuals, plain or 2x
+// pixel-shuffle store); every source must be a multiple of 64 channels wide.  Replaces the 1x1 convolutions of the
+// CVSR_V8 path (qkv, project_out folded, input_conv, fuse, fusion_out, down.0 / up.0, tsa_fusion, upconv1/2).
+#include "common.h"
+
+namespace {
+
+constexpr int PXT = 128;                        // pixels per workgroup (4 waves x one 32-pixel MFMA M tile)
+constexpr int PIXB = 80;                        // LDS bytes per staged pixel and 16-channel chunk: 32 hi | 32 lo | 16 pad
+constexpr int A_CHUNK = PXT * PIXB;             // 10,240
+constexpr int A_BYTES = 4 * A_CHUNK;            // 40,960: one 64-channel K block
+constexpr int W_HALF = 4 * 2 * 64 * 16;         // 8,192: [chunk][k-half][64 cout][8 bf16]
+constexpr int W_BYTES = 2 * W_HALF;             // hi | lo
+constexpr int EPI_RS = 68;                      // floats per pixel row in the epilogue transpose (64 + 4)
+constexpr int EPI_BYTES = 4 * 32 * EPI_RS * 4;  // 34,816
+constexpr int MAXCB = 4;                        // up to 256 output channels
+
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ unsigned pack_bf16(float a, float b) {
+  const __bf16 ha = (__bf16)a, hb = (__bf16)b;
+  return (unsigned)__builtin_bit_cast(unsigned short, ha) | ((unsigned)__builtin_bit_cast(unsigned short, hb) << 16);
+}
+__device__ __forceinline__ float bf16_round(float a) { return (float)(__bf16)a; }
+__device__ __forceinline__ void split_store(unsigned char* dst_hi, int lo_delta, const f32x4 v) {
+  u32x2 hi, lo;
+  hi[0] = pack_bf16(v[0], v[1]);
+  hi[1] = pack_bf16(v[2], v[3]);
+  lo[0] = pack_bf16(v[0] - bf16_round(v[0]), v[1] - bf16_round(v[1]));
+  lo[1] = pack_bf16(v[2] - bf16_round(v[2]), v[3] - bf16_round(v[3]));
+  *reinterpret_cast<u32x2*>(dst_hi) = hi;
+  *reinterpret_cast<u32x2*>(dst_hi + lo_delta) = lo;
+}
+
+template <int NCB>   // number of 64-wide output-channel blocks (1..4)
+__global__ __launch_bounds__(256, 2) void conv1x1_bf16x3_kernel(cdfo_conv_args a) {
+  __shared__ __attribute__((aligned(16))) unsigned char smem[A_BYTES + W_BYTES];
+  unsigned char* sA = smem;
+  unsigned char* sW = smem + A_BYTES;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, h = lane >> 5, r = lane & 31;
+  const int b = blockIdx.y;
+  const long long P = (long long)a.H * a.W;
+  const long long p0 = (long long)blockIdx.x * PXT;          // first pixel of this tile inside image b
+  const long long gp0 = (long long)b * P + p0;               // global pixel index
+  const float* wbase = a.w + (long long)b * a.w_bstride;
+
+  f32x16 acc[NCB][2];
+#pragma unroll
+  for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[cb][ni][e] = 0.f;
+
+  const int a_off = (wave * 32 + r) * PIXB + h * 16;   // this lane's pixel record inside a chunk
+  const int b_off = (h * 64 + r) * 16;
+  const bool do_ln = a.ln_gamma != nullptr;
+
+  const int nkb = a.Cin >> 6;
+  int s_idx = 0, s_base = 0;
+  for (int kb = 0; kb < nkb; ++kb) {
+    const int ch0 = kb * 64;
+    while (ch0 >= s_base + a.cs[s_idx]) { s_base += a.cs[s_idx]; ++s_idx; }
+    const float* src = a.src[s_idx] + (ch0 - s_base);
+    const int ld = a.ld[s_idx];
+    __syncthreads();   // previous K block's MFMAs are done with sA / sW
+    // ---- stage 128 pixels x 64 channels: 8 float4 per thread, all loads first
+    f32x4 v[8];
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+      const int idx = tid + 256 * s, px = idx >> 4, q = idx & 15;
+      const long long pp = p0 + px < P ? gp0 + px : gp0;          // clamped: always loaded, zeroed below
+      v[s] = *reinterpret_cast<const f32x4*>(src + pp * ld + q * 4);
+    }
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+      const int idx = tid + 256 * s, px = idx >> 4, q = idx & 15;
+      f32x4 t = v[s];
+      if (do_ln) {   // per-pixel LayerNorm over the 64 channels held by 16 consecutive lanes (arch.py:1169-1185)
+        float sm = (t[0] + t[1]) + (t[2] + t[3]);
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) sm += __shfl_xor(sm, o, 64);
+        const f32x4 d = t - sm * (1.f / 64.f);
+        float sq = (d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3]);
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) sq += __shfl_xor(sq, o, 64);
+        const float rstd = 1.f / sqrtf(sq * (1.f / 64.f) + 1e-5f);
+        t = d * rstd * *reinterpret_cast<const f32x4*>(a.ln_gamma + q * 4) + *reinterpret_cast<const f32x4*>(a.ln_beta + q * 4);
+      }
+      if (p0 + px >= P) t = f32x4{0.f, 0.f, 0.f, 0.f};
+      split_store(sA + (q >> 2) * A_CHUNK + px * PIXB + (q & 3) * 8, 32, t);
+    }
+#pragma unroll
+    for (int cb = 0; cb < NCB; ++cb) {
+      if (cb > 0) __syncthreads();   // the previous output block's MFMAs are done with sW
+      // ---- weights of (K block kb, output block cb) from the fp32 packing, split to bf16 hi/lo: 4 float4 per thread
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const int idx = tid + 256 * s, kg = idx >> 6, n = idx & 63;   // kg: group of 4 input channels inside the block
+        const f32x4 wv = *reinterpret_cast<const f32x4*>(wbase + ((long long)(kb * 16 + kg) * a.CoutP + cb * 64 + n) * 4);
+        const int c = kg >> 2, hh = (kg >> 1) & 1, j0 = (kg & 1) * 4;
+        split_store(sW + ((c * 2 + hh) * 64 + n) * 16 + j0 * 2, W_HALF, wv);
+      }
+      __syncthreads();
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const bf16x8_t ah = *reinterpret_cast<const bf16x8_t*>(sA + c * A_CHUNK + a_off);
+        const bf16x8_t al = *reinterpret_cast<const bf16x8_t*>(sA + c * A_CHUNK + a_off + 32);
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) {
+          const bf16x8_t bh = *reinterpret_cast<const bf16x8_t*>(sW + (c * 2 * 64 + ni * 32) * 16 + b_off);
+          const bf16x8_t bl = *reinterpret_cast<const bf16x8_t*>(sW + W_HALF + (c * 2 * 64 + ni * 32) * 16 + b_off);
+          acc[cb][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[cb][ni], 0, 0, 0);
+          acc[cb][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[cb][ni], 0, 0, 0);
+          acc[cb][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[cb][ni], 0, 0, 0);
+        }
+      }
+    }
+  }
+
+  // ---- epilogue: wave-private LDS transpose, then 16-byte rows: +bias -> act -> +res1 -> +res2 -> store
+  __syncthreads();
+  float* wl = reinterpret_cast<float*>(smem) + wave * 32 * EPI_RS;
+  const float slope = a.act == CDFO_ACT_NONE ? 1.f : (a.act == CDFO_ACT_LRELU ? 0.1f : 0.f);
+  const int c4 = lane & 15, pr = lane >> 4;                  // 16 float4 columns, 4 pixel rows per wave-instruction
+  const bool plain = a.store_mode == CDFO_STORE_PLAIN;
+  const int cq = a.Cout >> 2;
+#pragma unroll
+  for (int cb = 0; cb < NCB; ++cb) {
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) wl[((e & 3) + 8 * (e >> 2) + 4 * h) * EPI_RS + ni * 32 + r] = acc[cb][ni][e];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const int n = cb * 64 + c4 * 4;
+    const bool nok = n < a.Cout;
+    f32x4 bias = {0.f, 0.f, 0.f, 0.f};
+    if (a.bias && nok) bias = *reinterpret_cast<const f32x4*>(a.bias + n);
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      const int i = it * 4 + pr;                              // pixel inside this wave's M tile
+      f32x4 t = *reinterpret_cast<const f32x4*>(wl + i * EPI_RS + c4 * 4) + bias;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) t[k] = fmaxf(t[k], 0.f) + slope * fminf(t[k], 0.f);
+      const long long pin = p0 + wave * 32 + i;               // pixel inside the image
+      if (!nok || pin >= P) continue;
+      const long long pix = (long long)b * P + pin;
+      if (plain) {
+        if (a.res1) t += *reinterpret_cast<const f32x4*>(a.res1 + pix * a.ldr1 + n);
+        if (a.res2) t += *reinterpret_cast<const f32x4*>(a.res2 + pix * a.ldr2 + n);
+        *reinterpret_cast<f32x4*>(a.out + pix * a.ldo + n) = t;
+      } else {  // 2x pixel shuffle; packed channel order is (dy,dx,c)
+        const int sub = n / cq, cc = n - sub * cq;
+        const int oy = (int)(pin / a.W), ox = (int)(pin - (long long)oy * a.W);
+        const long long opix = ((long long)b * 2 * a.H + 2 * oy + (sub >> 1)) * (2 * a.W) + 2 * ox + (sub & 1);
+        *reinterpret_cast<f32x4*>(a.out + opix * a.ldo + cc) = t;
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+}  // namespace
+
+extern "C" int cdfo_conv1x1_bf16x3(const cdfo_conv_args* pa, void* stream) {
+  const cdfo_conv_args& a = *pa;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (a.nsrc < 1 || a.nsrc > CDFO_MAXSRC || a.B <= 0 || a.ks != 1 || a.stride != 1 || a.pad != 0) return CDFO_EINVAL;
+  if (a.act == CDFO_ACT_SIGMOID || a.tap_mask || a.src_f16 || a.out_f16) return CDFO_EINVAL;
+  int csum = 0;
+  for (int s = 0; s < a.nsrc; ++s) {
+    if (a.cs[s] <= 0 || a.cs[s] % 64 || a.ld[s] % 4 || a.ld[s] < a.cs[s]) return CDFO_EINVAL;
+    if (!aligned16(a.src[s])) return CDFO_EALIGN;
+    csum += a.cs[s];
+  }
+  if (csum != a.Cin || a.CoutP % 64 || a.CoutP > 64 * MAXCB || a.CoutP < a.Cout || a.Cout <= 0 || a.Cout % 4) return CDFO_EINVAL;
+  if (a.Ho != a.H || a.Wo != a.W) return CDFO_EINVAL;
+  if (a.store_mode == CDFO_STORE_S2D || (a.store_mode == CDFO_STORE_SHUFFLE2 && (a.Cout % 16 || a.res1 || a.res2))) return CDFO_EINVAL;
+  if (!aligned16(a.w) || a.w_bstride % 4 || a.ldo % 4 || !aligned16(a.out) || (a.bias && !aligned16(a.bias))) return CDFO_EALIGN;
+  if ((a.res1 && (a.ldr1 % 4 || !aligned16(a.res1))) || (a.res2 && (a.ldr2 % 4 || !aligned16(a.res2)))) return CDFO_EALIGN;
+  if (a.ln_gamma && !(a.nsrc == 1 && a.cs[0] == 64 && a.ln_beta && aligned16(a.ln_gamma) && aligned16(a.ln_beta))) return CDFO_EINVAL;
+  const long long P = (long long)a.H * a.W;
+  dim3 grid((unsigned)((P + PXT - 1) / PXT), a.B);
+  const double px = (double)a.B * P;
+  CdfoProfScope prof(st, KID_CONV1, 2.0 * px * a.Cout * a.Cin, 4.0 * (px * a.Cout + px * a.Cin + (double)a.Cin * a.Cout));
+  switch (a.CoutP / 64) {
+    case 1: hipLaunchKernelGGL(conv1x1_bf16x3_kernel<1>, grid, dim3(256), 0, st, a); break;
+    case 2: hipLaunchKernelGGL(conv1x1_bf16x3_kernel<2>, grid, dim3(256), 0, st, a); break;
+    case 3: hipLaunchKernelGGL(conv1x1_bf16x3_kernel<3>, grid, dim3(256), 0, st, a); break;
+    default: hipLaunchKernelGGL(conv1x1_bf16x3_kernel<4>, grid, dim3(256), 0, st, a); break;
+  }
+  CDFO_LAUNCH_CHECK();
+  return 0;
+}

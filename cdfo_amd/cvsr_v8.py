@@ -126,7 +126,9 @@ class CVSR_V8(nn.Module):
         # arithmetic of the wide 3x3 convolutions (89 % of the FLOPs):
         #   "f32"    exact fp32 MFMA (1e-6 max-abs on the forward vs the fp32 reference);
         #   "bf16x3" split-bf16 3-pass MFMA (fp32-grade: ~1e-5);
-        #   "fp16x2" fp16 hi+lo activations x fp16 weights, 2-pass MFMA (3-5e-4: inside the 1e-3 parity bound; default);
+        #   "fp16x2" fp16 weights; fp16 hi+lo activations (2 MFMA passes), single fp16 rounding (1 pass) inside Block_, whose
+        #            256-channel intermediates also live in HBM as fp16; the returned feature cache stays split-bf16
+        #            (2-4e-4 max-abs: inside the 1e-3 parity bound; default);
         #   "bf16"   plain bf16 MFMA with fp32 accumulation (BASELINE's bf16 configuration, ~6e-3: outside the bound).
         self.precision = "fp16x2"
         for key, shape, fan_in, init in _param_spec():

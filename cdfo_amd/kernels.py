@@ -184,6 +184,10 @@ def conv(srcs: Sequence[torch.Tensor], pc: PackedConv, *, stride: int = 1, pad: 
     a.prec = 0
     if ln is not None:
         a.ln_gamma, a.ln_beta = ln[0].data_ptr(), ln[1].data_ptr()
+    if (prec != PREC_F32 and pc.ks == 1 and stride == 1 and pad == 0 and pc.CoutP % 64 == 0 and pc.CoutP <= 256
+            and all(s.shape[3] % 64 == 0 for s in srcs)):
+        check(_lib.lib().cdfo_conv1x1_bf16x3(C.byref(a), _stream()), "cdfo_conv1x1_bf16x3")
+        return out
     check(_lib.lib().cdfo_conv_igemm(C.byref(a), _stream()), "cdfo_conv_igemm")
     return out
 

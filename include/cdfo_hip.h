@@ -75,6 +75,11 @@ int cdfo_conv3x3_bf16(const cdfo_conv_args* a, void* stream);
 int cdfo_pack_conv3x3_bf16(const float* w_oihw, void* packed, int Cout, int Cin, void* stream);
 int cdfo_pack_conv3x3_f16(const float* w_oihw, void* packed, int Cout, int Cin, void* stream);
 
+/* 1x1 convolution as an HBM-streaming GEMM in split-bf16 (3-pass, fp32-grade) arithmetic; same argument block and
+ * epilogue as cdfo_conv_igemm with ks = 1 (fp32 packing of cdfo_pack_conv_weight, per-image weights, fused LayerNorm,
+ * residuals, pixel-shuffle store).  Every source must be a multiple of 64 channels, CoutP a multiple of 64 (<= 256).  */
+int cdfo_conv1x1_bf16x3(const cdfo_conv_args* a, void* stream);
+
 /* Layout changes at the module boundary (reference tensors are NCHW).  */
 int cdfo_nchw_to_nhwc(const float* in, float* out, int B, int C, int H, int W, int ldo, void* stream);
 int cdfo_nhwc_to_nchw(const float* in, int ldi, float* out, int B, int C, int H, int W, void* stream);

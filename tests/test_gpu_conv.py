@@ -179,3 +179,53 @@ def test_conv3x3_fp16_intermediate_chain():
     torch.cuda.synchronize()
     exp = t.view(B, H // 2, 2, W // 2, 2, 256).permute(0, 1, 3, 2, 4, 5).reshape(B, H // 2, W // 2, 1024)
     assert torch.equal(t2, exp)
+
+
+@pytest.mark.parametrize("srcs,Cout,res,shuf", [([64], 192, False, False), ([64], 64, True, False), ([64, 64, 64], 64, False, False),
+                                                ([128], 64, True, False), ([64] * 7, 64, False, False), ([64], 256, False, True),
+                                                ([64], 128, False, False)])
+def test_conv1x1_bf16x3(srcs, Cout, res, shuf):
+    from cdfo_amd import kernels as K
+    g = torch.Generator().manual_seed(sum(srcs) + Cout)
+    B, H, W = 2, 13, 21                       # 273 pixels: partial last tile
+    xs = [torch.randn(B, c, H, W, generator=g) for c in srcs]
+    cin = sum(srcs)
+    w = torch.randn(Cout, cin, 1, 1, generator=g) / cin ** 0.5
+    b = torch.randn(Cout, generator=g)
+    y = F.conv2d(torch.cat(xs, 1), w, b)
+    if shuf:
+        ref = F.leaky_relu(F.pixel_shuffle(y, 2), 0.1)
+    else:
+        ref = F.leaky_relu(y, 0.1)
+    r = torch.randn(B, Cout, H, W, generator=g) if res else None
+    if res:
+        ref = ref + r
+    pc = K.pack_conv(w.cuda(), b.cuda(), shuffle2=shuf)
+    out = K.conv([_nhwc(t).cuda() for t in xs], pc, act=K.ACT_LRELU, res1=None if r is None else _nhwc(r).cuda(),
+                 prec=K.PREC_BF16X3)
+    torch.cuda.synchronize()
+    _cmp(out, ref, 3e-5, "conv1x1 bf16x3")
+
+
+def test_conv1x1_bf16x3_layernorm_and_per_image_weights():
+    from cdfo_amd import kernels as K
+    g = torch.Generator().manual_seed(77)
+    B, H, W = 3, 8, 24
+    x = torch.randn(B, 64, H, W, generator=g) * 2 + 0.5
+    gamma, beta = torch.randn(64, generator=g), torch.randn(64, generator=g)
+    w = torch.randn(192, 64, 1, 1, generator=g) / 8.0
+    mu = x.mean(1, keepdim=True)
+    var = x.var(1, keepdim=True, unbiased=False)
+    ln = (x - mu) / torch.sqrt(var + 1e-5) * gamma.view(1, -1, 1, 1) + beta.view(1, -1, 1, 1)
+    out = K.conv([_nhwc(x).cuda()], K.pack_conv(w.cuda(), None), ln=(gamma.cuda(), beta.cuda()), prec=K.PREC_BF16X3)
+    torch.cuda.synchronize()
+    _cmp(out, F.conv2d(ln, w), 5e-5, "ln + 1x1 bf16x3")
+    ws = torch.randn(B, 64, 64, 1, 1, generator=g) / 8.0
+    ref = torch.cat([F.conv2d(x[i:i + 1], ws[i]) for i in range(B)], 0)
+    pcs = [K.pack_conv(ws[i].cuda(), None) for i in range(B)]
+    pc = pcs[0]
+    pc.w = torch.stack([p.w for p in pcs], 0).contiguous()
+    pc.w_bstride = pc.w.stride(0)
+    out = K.conv([_nhwc(x).cuda()], pc, prec=K.PREC_BF16X3)
+    torch.cuda.synchronize()
+    _cmp(out, ref, 5e-5, "per-image weights bf16x3")

@@ -39,6 +39,9 @@ for name, npix, srcs, Cout, res, shuf in SHAPES:
     pc = K.pack_conv(w, torch.randn(Cout, device="cuda"), shuffle2=shuf)
     r = torch.randn(1, H, W, Cout, device="cuda") if res else None
     out = None if shuf else K.empty_act(1, H, W, Cout, "cuda")
-    ms = timeit(lambda: K.conv(xs, pc, act=1, res1=r, out=out))
     by = 4.0 * npix * (cin + Cout * (2 if res else 1))
-    print(f"{name:34s} {ms:7.3f} ms  {by/ms/1e6:7.1f} GB/s algorithmic  {2.0*npix*cin*Cout/ms/1e9:6.1f} TF/s", flush=True)
+    line = f"{name:34s}"
+    for prec in (0, 1):
+        ms = timeit(lambda: K.conv(xs, pc, act=1, res1=r, out=out, prec=prec))
+        line += f"  prec{prec}: {ms:7.3f} ms {by/ms/1e6:7.1f} GB/s"
+    print(line, flush=True)

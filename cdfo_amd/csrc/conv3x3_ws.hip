@@ -1,0 +1,375 @@
+// 3x3 stride-1 convolution with 64 input channels, weights-stationary and barrier-free (fp16 MFMA, fp32 accumulate).
+//
+// Block_.body[0] (arch/SIDECVSR_our.py:383-387: Conv2d(64, 256, 3, 1, 1) + LeakyReLU) runs three times per block (own,
+// half and double resolution) and is half of the forward's FLOPs.  With 64 input channels the fp16 weights of one
+// 64-output-channel block are 73,728 bytes: they fit the CU's 160 KB LDS next to the activations, so this kernel
+//   * is persistent: one 512-thread workgroup per CU loads its weight block ONCE and then walks over pixel tiles
+//     (cdfo_conv3x3_bf16 re-stages 18 KB of weights per 16-channel chunk of every 256-pixel tile: ~1.1 KB of
+//     L2->LDS traffic per output pixel, more than the activations);
+//   * has NO workgroup barrier after the weight load: every wave owns a 2-row x 32-pixel x 64-channel output tile and
+//     stages its own 4 x 34 pixel halo, 16 channels at a time, straight from global memory into a wave-private LDS
+//     ring by LDS-DMA (buffer_load_dwordx4 ... lds: no staging VGPRs, no ds_write pass; out-of-image lanes are given an
+//     out-of-range buffer offset, which the hardware zero-fills = the convolution's zero padding).  The eight waves
+//     drift apart freely, so one wave's DMA wait or epilogue is covered by its SIMD partner's MFMAs;
+//   * reads a "chunk-planar" fp16 source [B][Cin/16][H][W][16]: a staged image row is 34 x 32 contiguous bytes, every
+//     DMA piece moves whole cache lines (the pixel-major layout would touch 32 bytes of each 128-byte line);
+//   * computes the transposed product (M = output channels, N = pixels): a lane's accumulator registers then hold four
+//     CONSECUTIVE channels of one pixel, the epilogue packs them to fp16 and transposes through 4.6 KB of the wave's
+//     own ring with 8-byte writes / 16-byte reads, and every global store is 16 bytes per lane, 128 bytes per pixel.
+// The LDS image is dense (32 bytes per pixel) because LDS-DMA writes lane-linear; bank conflicts of the ds_read_b128
+// fragment reads are removed by swapping the two 16-byte halves of every second group of 8 pixels, applied on the DMA
+// source side and on the read side.
+//
+// DMA completion is tracked by hand (hipcc does not count inline-asm memory operations) with counted s_waitcnt; the
+// rules are written next to each wait.
+#include "common.h"
+
+namespace {
+
+constexpr int WS_THREADS = 512;
+constexpr int WS_W_BYTES = 4 * 9 * 2 * 64 * 16;            // 73,728: [chunk][tap][k-half][64 cout][8 x fp16]
+constexpr int WS_BIAS_OFF = WS_W_BYTES;                    // 64 floats
+constexpr int WS_STG_OFF = WS_W_BYTES + 256;
+constexpr int WS_BUF = 5 * 1024;                           // one 16-channel chunk of a wave's halo: 136 px x 32 B in 5 DMA pieces
+constexpr int WS_LDS = WS_STG_OFF + 8 * 2 * WS_BUF;        // 155,904 bytes
+constexpr int WS_IW = 34, WS_NPIX = 4 * 34;
+constexpr int WS_EPI_ROW = 144;                            // epilogue scratch: 64 fp16 + 16 B pad per pixel (32 rows = 4,608 B)
+
+typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4_t __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+
+struct ws_args {
+  const void* src; unsigned src_bytes;
+  int B, H, W;
+  const unsigned short* w; int CoutP;       // cdfo_pack_conv3x3_f16 packing, CoutP = its padded channel count
+  const float* bias;
+  int Cout, act;
+  _Float16* out; int ldo, s2d;
+};
+
+// five 1 KiB LDS-DMA pieces: lane l of piece k writes LDS bytes lds + 1024 k + 16 l from (buffer base + voff[k] + soff)
+__device__ __forceinline__ void ws_dma5(const unsigned (&voff)[5], i32x4 rsrc, unsigned soff, unsigned lds) {
+  unsigned keep;
+  asm volatile(
+      "s_nop 4\n\t"
+      "s_mov_b32 %0, m0\n\t"
+      "s_mov_b32 m0, %7\n\ts_nop 0\n\t"
+      "buffer_load_dwordx4 %1, %6, %8 offen lds\n\t"
+      "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\t"
+      "buffer_load_dwordx4 %2, %6, %8 offen lds\n\t"
+      "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\t"
+      "buffer_load_dwordx4 %3, %6, %8 offen lds\n\t"
+      "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\t"
+      "buffer_load_dwordx4 %4, %6, %8 offen lds\n\t"
+      "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\t"
+      "buffer_load_dwordx4 %5, %6, %8 offen lds\n\t"
+      "s_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(voff[0]), "v"(voff[1]), "v"(voff[2]), "v"(voff[3]), "v"(voff[4]), "s"(rsrc), "s"(lds), "s"(soff)
+      : "memory", "scc");
+}
+
+// DBG (developer ablations): 1 = skip the MFMAs, 2 = skip the DMA, 8 = skip the epilogue, 16 = drain every DMA wait
+// (vmcnt(0)), 64 = no start-up stagger
+template <int DBG>
+__global__ __launch_bounds__(WS_THREADS) void conv3x3_c64_ws_kernel(ws_args a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, r = lane & 31;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  // workgroups are dealt round-robin over the 8 XCDs: the nco output-channel blocks of one pixel partition share an L2
+  const int nco = a.Cout >> 6;
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int nb = slot % nco, q = slot / nco;
+  const int nparts = ((int)(gridDim.x >> 3) / nco) * 8, part = q * 8 + xcd;
+  const int n0 = nb * 64;
+  const int H = a.H, W = a.W;
+
+  // ---- one-time: this workgroup's weight block and bias
+  for (int i = tid; i < WS_W_BYTES / 16; i += WS_THREADS) {
+    const int row = i >> 6, n = i & 63;          // row = (chunk*9 + tap)*2 + k-half
+    *reinterpret_cast<u32x4*>(smem + i * 16) =
+        *reinterpret_cast<const u32x4*>(a.w + ((long long)row * a.CoutP + n0 + n) * 8);
+  }
+  if (tid < 64) reinterpret_cast<float*>(smem + WS_BIAS_OFF)[tid] = a.bias ? a.bias[n0 + tid] : 0.f;
+  __syncthreads();
+
+  // ---- per-lane constants
+  // DMA slot s = 64 k + lane holds pixel p = s >> 1 of the 4 x 34 halo, k-half (s & 1) ^ ((p >> 3) & 1)
+  int d_iy[5], d_ix[5], d_rel[5];
+#pragma unroll
+  for (int k = 0; k < 5; ++k) {
+    const int s = lane + 64 * k, p = s >> 1, half = (s & 1) ^ ((p >> 3) & 1);
+    const int iy = p / WS_IW, ix = p - iy * WS_IW;
+    d_iy[k] = p < WS_NPIX ? iy : 1 << 20;          // pad slots: never inside the image
+    d_ix[k] = ix;
+    d_rel[k] = (iy * W + ix) * 32 + half * 16;
+  }
+  // fragment read offsets: halo row rr (0..3), column offset dx (0..2), this lane's pixel r
+  int p_off[12];
+#pragma unroll
+  for (int rr = 0; rr < 4; ++rr)
+#pragma unroll
+    for (int dx = 0; dx < 3; ++dx) {
+      const int p = rr * WS_IW + dx + r;
+      p_off[rr * 3 + dx] = (2 * p + (h ^ ((p >> 3) & 1))) * 16;
+    }
+  const unsigned char* sWl = smem + (h * 64 + r) * 16;
+  unsigned char* stg = smem + WS_STG_OFF + wave * (2 * WS_BUF);
+  const unsigned stg_lds = (unsigned)(unsigned long long)(smem) + WS_STG_OFF + wave * (2 * WS_BUF);
+
+  i32x4 rsrc;
+  {
+    const unsigned long long p = reinterpret_cast<unsigned long long>(a.src);
+    rsrc[0] = (int)(unsigned)p;
+    rsrc[1] = (int)(unsigned)(p >> 32);
+    rsrc[2] = (int)a.src_bytes;
+    rsrc[3] = 0x00020000;
+  }
+  const int tiles_x = (W + 31) >> 5, hp = H >> 1;
+  const int total = a.B * hp * tiles_x;
+  const unsigned plane = (unsigned)(H * W) * 32u;        // bytes of one 16-channel plane of one image
+  const int ustride = nparts * 8;
+  int u = part * 8 + wave;
+
+  unsigned voff[5], soff0 = 0;
+  int ub = 0, uy0 = 0, ux0 = 0;
+  auto make_desc = [&](int uu) {
+    const int xs = uu % tiles_x, t2 = uu / tiles_x;
+    const int yp = t2 % hp;
+    ub = t2 / hp; uy0 = yp * 2; ux0 = xs * 32;
+    soff0 = (unsigned)ub * 4u * plane;
+    const int base = ((uy0 - 1) * W + (ux0 - 1)) * 32;
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+      const int gy = uy0 - 1 + d_iy[k], gx = ux0 - 1 + d_ix[k];
+      const bool ok = gy >= 0 && gy < H && gx >= 0 && gx < W;
+      voff[k] = ok ? (unsigned)(base + d_rel[k]) : 0x80000000u;     // out of range => the DMA writes zeros
+    }
+  };
+
+  const float slope = a.act == CDFO_ACT_NONE ? 1.f : (a.act == CDFO_ACT_LRELU ? 0.1f : 0.f);
+
+  if (u < total) {
+    make_desc(u);
+    if (!(DBG & 2)) ws_dma5(voff, rsrc, soff0, stg_lds);
+  }
+  // Start-up stagger.  The waves run the same program with no barrier, so the two waves of a SIMD (w, w+4) would stay
+  // in lockstep -- sharing the matrix pipe during their MFMA phases and leaving it idle during their simultaneous
+  // epilogues.  A lead, once given, persists (neither wave waits for the other): waves 4-7 start half a tile's MFMA
+  // time late, and the four SIMDs are spread over the rest so that their epilogues do not collide in LDS / the
+  // store path either.
+  if (!(DBG & 64)) {
+    const int naps = (wave >> 2) * 4 + (wave & 3);          // x 576 cycles (tile MFMA time ~4,600 cycles)
+    for (int i = 0; i < naps; ++i) __builtin_amdgcn_s_sleep(9);
+  }
+  bool prev_full = false;
+  for (; u < total; u += ustride) {
+    const int cb = ub, cy0 = uy0, cx0 = ux0;     // this unit (make_desc below moves on to the next one)
+    f32x16 acc[2][2];                            // [ni: 32-channel block][mi: image row]
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const f32x4 bv = *reinterpret_cast<const f32x4*>(smem + WS_BIAS_OFF + (ni * 32 + 8 * j + 4 * h) * 4);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { acc[ni][0][4 * j + k] = bv[k]; acc[ni][1][4 * j + k] = bv[k]; }
+      }
+
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      // wait for this chunk's image.  It was issued during the previous chunk (below); the only younger vector-memory
+      // operations are the previous tile's 8 epilogue stores (all 8 are issued when that tile was full width), and
+      // gfx9 retires loads and stores in issue order -- the same rule hipcc's own vmcnt(N) waits rely on.
+      if (c == 0 && prev_full && !(DBG & 16)) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      const unsigned char* sA = stg + (c & 1) * WS_BUF;
+      const unsigned char* sWc = sWl + c * (9 * 2 * 64 * 16);
+      f16x8_t fp[2][2], fw[2][2];                // [parity][mi / ni]: fragments are read one tap ahead
+      auto load_frags = [&](int t, int par) {
+        const int dy = t / 3, dx = t - dy * 3;
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) fp[par][mi] = *reinterpret_cast<const f16x8_t*>(sA + p_off[(mi + dy) * 3 + dx]);
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) fw[par][ni] = *reinterpret_cast<const f16x8_t*>(sWc + (t * 2 * 64 + ni * 32) * 16);
+      };
+      load_frags(0, 0);
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        if (t < 8) load_frags(t + 1, (t & 1) ^ 1);
+        if (t == 0) {
+          // Next chunk's DMA, into the OTHER ring buffer, whose last readers were the previous chunk's fragment reads.
+          // Those must have returned before a DMA piece can land (one that hits in the CU's L1 lands within ~100
+          // cycles; issuing without this wait corrupted ~1 tile per launch).  LDS operations of a wave return in
+          // order and the 8 reads of taps 0 and 1 above are younger than all of them, so "at most 8 outstanding"
+          // is enough -- and free, those 8 are about to be waited for anyway.
+          asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
+          if (c < 3) {
+            if (!(DBG & 2)) ws_dma5(voff, rsrc, soff0 + (unsigned)(c + 1) * plane, stg_lds + ((c + 1) & 1) * WS_BUF);
+          } else if (u + ustride < total) {
+            make_desc(u + ustride);
+            if (!(DBG & 2)) ws_dma5(voff, rsrc, soff0, stg_lds);
+          }
+        }
+        const int par = t & 1;
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+          for (int mi = 0; mi < 2; ++mi) {
+            if (DBG & 1) acc[ni][mi][0] += (float)fw[par][ni][0] * (float)fp[par][mi][0];
+            else acc[ni][mi] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fw[par][ni], fp[par][mi], acc[ni][mi], 0, 0, 0);
+          }
+      }
+    }
+    prev_full = cx0 + 32 <= W;
+
+    // ---- epilogue: act -> fp16 -> transpose through ring buffer 1 (chunk 3's image, dead now; the DMA in flight
+    // targets buffer 0) -> 16-byte stores.  acc[ni][mi][4j+k] = channel ni*32 + 8j + 4h + k of pixel r in row mi.
+    if (DBG & 8) {
+      float t = 0.f;
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) t += acc[ni][mi][e];
+      if (t == 123.456f) a.out[0] = (_Float16)t;
+      continue;
+    }
+    unsigned char* scr = stg + WS_BUF;
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) {
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          f16x4_t hv;
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const float v = acc[ni][mi][4 * j + k];
+            hv[k] = (_Float16)(fmaxf(v, 0.f) + slope * fminf(v, 0.f));
+          }
+          *reinterpret_cast<f16x4_t*>(scr + r * WS_EPI_ROW + (ni * 32 + 8 * j + 4 * h) * 2) = hv;
+        }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      const int y = cy0 + mi, piece = lane & 7;
+      long long rowbase;    // element offset of (row y, pixel cx0, channel n0 + 8 piece)
+      if (a.s2d) rowbase = ((long long)(cb * hp + (y >> 1)) * (W >> 1) + (cx0 >> 1)) * a.ldo + (y & 1) * 2 * a.Cout + n0 + piece * 8;
+      else rowbase = ((long long)(cb * H + y) * W + cx0) * a.ldo + n0 + piece * 8;
+      _Float16* orow = a.out + rowbase;
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        const int pix = it * 8 + (lane >> 3);
+        const u32x4 v = *reinterpret_cast<const u32x4*>(scr + pix * WS_EPI_ROW + piece * 16);
+        const int eoff = a.s2d ? (pix >> 1) * a.ldo + (pix & 1) * a.Cout : pix * a.ldo;
+        if (cx0 + pix < W) *reinterpret_cast<u32x4*>(orow + eoff) = v;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
+}
+
+int ws_num_cus() {
+  static int cus = 0;
+  if (!cus) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 0;
+    cus = prop.multiProcessorCount;
+  }
+  return cus;
+}
+
+template <int DBG>
+int ws_launch(const ws_args& a, int grid, hipStream_t st) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_c64_ws_kernel<DBG>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, WS_LDS);
+    if (e != hipSuccess) return (int)e;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((conv3x3_c64_ws_kernel<DBG>), dim3(grid), dim3(WS_THREADS), WS_LDS, st, a);
+  return 0;
+}
+
+// fp32 pixel-major [B][P][ld] -> fp16 chunk-planar [B][C/16][P][16]
+__global__ __launch_bounds__(256) void to_cp16_kernel(const float* __restrict__ in, int ldi, int B, long long P, int C,
+                                                      _Float16* __restrict__ out) {
+  const int nc = C >> 4;
+  const long long total = (long long)B * nc * P * 4;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int g = i & 3;
+    const long long t = i >> 2;
+    const long long p = t % P;
+    const int c = (t / P) % nc;
+    const long long b = t / (P * nc);
+    const f32x4 v = *reinterpret_cast<const f32x4*>(in + (b * P + p) * ldi + c * 16 + g * 4);
+    f16x4_t hv;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) hv[k] = (_Float16)v[k];
+    *reinterpret_cast<f16x4_t*>(out + i * 4) = hv;
+  }
+}
+
+}  // namespace
+
+extern "C" int cdfo_conv3x3_c64_ws(const void* src_cp16, int B, int H, int W, const void* w_f16, int CoutP,
+                                   const float* bias, int Cout, int act, void* out_f16, int ldo, int store_mode,
+                                   int dbg, void* stream) {
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (B <= 0 || H <= 0 || W <= 0 || (H & 1) || Cout <= 0 || Cout % 64 || CoutP < Cout || CoutP % 64) return CDFO_EINVAL;
+  if (act == CDFO_ACT_SIGMOID || (store_mode != CDFO_STORE_PLAIN && store_mode != CDFO_STORE_S2D)) return CDFO_EINVAL;
+  if (store_mode == CDFO_STORE_S2D && (W & 1)) return CDFO_EINVAL;
+  const long long src_bytes = (long long)B * 4 * H * W * 32;
+  if (src_bytes >= (1ll << 31)) return CDFO_EINVAL;      // 32-bit buffer offsets, out-of-range marker 0x80000000
+  if (!aligned16(src_cp16) || !aligned16(w_f16) || !aligned16(out_f16) || ldo % 8) return CDFO_EALIGN;
+  const int cus = ws_num_cus();
+  if (cus < 8) return CDFO_EINVAL;
+  const int nco = Cout / 64;
+  int qn = (cus / 8) / nco;
+  if (qn < 1) qn = 1;
+  const int grid = 8 * qn * nco;
+  ws_args a;
+  a.src = src_cp16; a.src_bytes = (unsigned)src_bytes;
+  a.B = B; a.H = H; a.W = W;
+  a.w = static_cast<const unsigned short*>(w_f16); a.CoutP = CoutP;
+  a.bias = bias; a.Cout = Cout; a.act = act;
+  a.out = static_cast<_Float16*>(out_f16); a.ldo = ldo; a.s2d = store_mode == CDFO_STORE_S2D;
+  const double px = (double)B * H * W;
+  CdfoProfScope prof(st, KID_CONV3_WIDE, 2.0 * px * Cout * 64 * 9, 2.0 * (px * Cout + px * 64) + 2.0 * 9 * 64 * Cout);
+  int rc;
+  switch (dbg) {
+    case 0: rc = ws_launch<0>(a, grid, st); break;
+    case 1: rc = ws_launch<1>(a, grid, st); break;
+    case 2: rc = ws_launch<2>(a, grid, st); break;
+    case 3: rc = ws_launch<3>(a, grid, st); break;
+    case 8: rc = ws_launch<8>(a, grid, st); break;
+    case 9: rc = ws_launch<9>(a, grid, st); break;
+    case 11: rc = ws_launch<11>(a, grid, st); break;
+    case 16: rc = ws_launch<16>(a, grid, st); break;
+    case 64: rc = ws_launch<64>(a, grid, st); break;
+    case 72: rc = ws_launch<72>(a, grid, st); break;
+    default: return CDFO_EINVAL;
+  }
+  if (rc) return rc;
+  CDFO_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int cdfo_to_cp16(const float* in, int ldi, int B, long long P, int C, void* out_cp16, void* stream) {
+  if (B <= 0 || P <= 0 || C <= 0 || C % 16 || ldi % 4 || ldi < C) return CDFO_EINVAL;
+  if (!aligned16(in) || !aligned16(out_cp16)) return CDFO_EALIGN;
+  const long long threads = (long long)B * (C / 16) * P * 4;
+  const long long blocks = (threads + 255) / 256;
+  CdfoProfScope prof(static_cast<hipStream_t>(stream), KID_LAYOUT, 0, 6.0 * C * (double)B * P);
+  hipLaunchKernelGGL(to_cp16_kernel, dim3((unsigned)(blocks > 16384 ? 16384 : blocks)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), in, ldi, B, P, C, static_cast<_Float16*>(out_cp16));
+  CDFO_LAUNCH_CHECK();
+  return 0;
+}

@@ -192,9 +192,39 @@ def conv(srcs: Sequence[torch.Tensor], pc: PackedConv, *, stride: int = 1, pad: 
     return out
 
 
-# ----------------------------------------------------------------------------------------------- pointwise
 def _vp(t):
     return C.c_void_p(None if t is None else t.data_ptr())
+
+
+def to_cp16(x: torch.Tensor) -> torch.Tensor:
+    """fp32 pixel-major [B,H,W,C] -> fp16 chunk-planar [B, C/16, H, W, 16] (the source layout of conv3x3_ws)."""
+    B, H, W, Cc, ld = _chk_act(x)
+    out = torch.empty((B, Cc // 16, H, W, 16), dtype=torch.float16, device=x.device)
+    check(_lib.lib().cdfo_to_cp16(_vp(x), ld, B, C.c_longlong(H * W), Cc, _vp(out), _stream()), "cdfo_to_cp16")
+    return out
+
+
+def conv3x3_ws(src: torch.Tensor, pc: PackedConv, *, act: int = ACT_NONE, s2d: bool = False,
+               out: Optional[torch.Tensor] = None, dbg: int = 0) -> torch.Tensor:
+    """Block_.body[0]-shaped convolution (3x3, 64 input channels, Cout % 64 == 0) on the weights-stationary kernel.
+    src: fp16 chunk-planar [B,4,H,W,16]; result: fp16 pixel-major [B,H,W,Cout] (or space-to-depth [B,H/2,W/2,4*Cout])."""
+    if not src.is_cuda:
+        raise NotImplementedError("conv3x3_ws: the HIP path needs device tensors (no CPU fallback)")
+    if src.dtype != torch.float16 or src.dim() != 5 or src.shape[1] != 4 or src.shape[4] != 16 or not src.is_contiguous():
+        raise ValueError(f"conv3x3_ws: expected a contiguous fp16 [B,4,H,W,16] source, got {src.dtype} {tuple(src.shape)}")
+    if pc.wh is None or pc.Cin != 64 or pc.ks != 3 or pc.Cout % 64:
+        raise ValueError("conv3x3_ws: needs a 3x3 weight with 64 input channels and Cout % 64 == 0")
+    B, _, H, W, _ = src.shape
+    if out is None:
+        shape = (B, H // 2, W // 2, 4 * pc.Cout) if s2d else (B, H, W, pc.Cout)
+        out = torch.empty(shape, dtype=torch.float16, device=src.device)
+    _, _, _, _, ldo = _chk_act(out, "out", torch.float16)
+    check(_lib.lib().cdfo_conv3x3_c64_ws(_vp(src), B, H, W, _vp(pc.wh), pc.CoutP16, _vp(pc.bias), pc.Cout, act, _vp(out),
+                                         ldo, 2 if s2d else 0, dbg, _stream()), "cdfo_conv3x3_c64_ws")
+    return out
+
+
+# ----------------------------------------------------------------------------------------------- pointwise
 
 
 def swap_outer(x: torch.Tensor, B: int, N: int) -> torch.Tensor:
@@ -246,9 +276,15 @@ def flow_warp(x: torch.Tensor, mv: torch.Tensor, mv_bstride: int) -> torch.Tenso
 
 
 def resample2(x: torch.Tensor, up: bool, out: Optional[torch.Tensor] = None, accumulate: bool = False,
-              out_f16: bool = False) -> torch.Tensor:
+              out_f16: bool = False, cp16: bool = False) -> torch.Tensor:
+    """cp16 (up only): the result is the fp16 chunk-planar tensor [B, C/16, 2H, 2W, 16] that conv3x3_ws reads."""
     B, H, W, Cc, ld = _chk_act(x)
     Ho, Wo = (2 * H, 2 * W) if up else (H // 2, W // 2)
+    if cp16:
+        assert up and out is None and not accumulate
+        out = torch.empty((B, Cc // 16, Ho, Wo, 16), dtype=torch.float16, device=x.device)
+        check(_lib.lib().cdfo_resample2(_vp(x), ld, B, H, W, Cc, _vp(out), 16, 1, 0, 2, _stream()), "cdfo_resample2")
+        return out
     odt = torch.float16 if out_f16 else torch.float32
     if out is None:
         assert not accumulate

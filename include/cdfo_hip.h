@@ -75,6 +75,17 @@ int cdfo_conv3x3_bf16(const cdfo_conv_args* a, void* stream);
 int cdfo_pack_conv3x3_bf16(const float* w_oihw, void* packed, int Cout, int Cin, void* stream);
 int cdfo_pack_conv3x3_f16(const float* w_oihw, void* packed, int Cout, int Cin, void* stream);
 
+/* Block_.body[0] (arch/SIDECVSR_our.py:383-387, Conv2d(64, Cout, 3, 1, 1) + activation) as a persistent,
+ * weights-stationary fp16 MFMA kernel: one workgroup per CU keeps the fp16 weights of 64 output channels in LDS and
+ * streams pixel tiles past them.  src_cp16: fp16 "chunk-planar" tensor [B][4][H][W][16] (cdfo_to_cp16, or
+ * cdfo_resample2 with out_f16 = 2); w_f16/CoutP: cdfo_pack_conv3x3_f16 packing and its padded channel count;
+ * out_f16: fp16 pixel-major [B][H][W][ldo] (CDFO_STORE_PLAIN) or space-to-depth (CDFO_STORE_S2D, see above).
+ * H even, Cout % 64 == 0, the source smaller than 2 GiB.  dbg: 0 (developer ablation flags otherwise).  */
+int cdfo_conv3x3_c64_ws(const void* src_cp16, int B, int H, int W, const void* w_f16, int CoutP, const float* bias,
+                        int Cout, int act, void* out_f16, int ldo, int store_mode, int dbg, void* stream);
+/* fp32 pixel-major [B][P][ldi] (C channels, C % 16 == 0) -> fp16 chunk-planar [B][C/16][P][16].  */
+int cdfo_to_cp16(const float* in, int ldi, int B, long long P, int C, void* out_cp16, void* stream);
+
 /* 1x1 convolution as an HBM-streaming GEMM in split-bf16 (3-pass, fp32-grade) arithmetic; same argument block and
  * epilogue as cdfo_conv_igemm with ks = 1 (fp32 packing of cdfo_pack_conv_weight, per-image weights, fused LayerNorm,
  * residuals, pixel-shuffle store).  Every source must be a multiple of 64 channels, CoutP a multiple of 64 (<= 256).  */
@@ -101,7 +112,8 @@ int cdfo_dwconv3x3(const float* in, int ldi, const float* w, int B, int H, int W
 int cdfo_flow_warp(const float* in, int ldi, const float* mv, long long mv_bstride, int B, int H, int W, int C,
                    float* out, int ldo, void* stream);
 /* bilinear x2 (up=1) or x0.5 (up=0), align_corners=False (arch.py:324-333); accumulate: out += result;
- * out_f16 (up only): `out` is an fp16 tensor (ldo in halves) that feeds a single-pass fp16 convolution. */
+ * out_f16 (up only): 1 = `out` is an fp16 pixel-major tensor (ldo in halves) that feeds a single-pass fp16 convolution;
+ * 2 = `out` is an fp16 chunk-planar tensor [B][C/16][2H][2W][16] (ldo ignored), the source of cdfo_conv3x3_c64_ws. */
 int cdfo_resample2(const float* in, int ldi, int B, int H, int W, int C, float* out, int ldo, int up, int accumulate,
                    int out_f16, void* stream);
 /* out = in * gate[b][c] (CALayer, arch.py:2041-2043). */

@@ -229,3 +229,39 @@ def test_conv1x1_bf16x3_layernorm_and_per_image_weights():
     out = K.conv([_nhwc(x).cuda()], pc, prec=K.PREC_BF16X3)
     torch.cuda.synchronize()
     _cmp(out, ref, 5e-5, "per-image weights bf16x3")
+
+
+WS_CASES = [
+    # Cout, H, W, B, s2d, act      (W % 32 != 0 and tiny images exercise the masked tile edges; B*H/2*tiles_x both
+    (256, 24, 40, 1, False, 1),    # below and above the number of wave streams)
+    (64, 16, 64, 2, False, 0),
+    (128, 6, 34, 3, False, 2),
+    (256, 36, 52, 2, True, 1),
+    (256, 272, 480, 2, True, 1),
+]
+
+
+@pytest.mark.parametrize("Cout,H,W,B,s2d,act", WS_CASES)
+def test_conv3x3_c64_ws(Cout, H, W, B, s2d, act):
+    """Weights-stationary Block_.body[0] kernel vs torch-cpu conv2d on the SAME fp16-rounded operands (so the only
+    differences are the fp32 accumulation order and the fp16 rounding of the result)."""
+    from cdfo_amd import kernels as K
+    g = torch.Generator().manual_seed(Cout + H + W)
+    x = torch.randn(B, 64, H, W, generator=g)
+    w = torch.randn(Cout, 64, 3, 3, generator=g) / 24.0
+    b = torch.randn(Cout, generator=g)
+    xh, wh = x.half().float(), w.half().float()
+    ref = F.conv2d(xh, wh, b, padding=1)
+    ref = {0: ref, 1: F.leaky_relu(ref, 0.1), 2: F.relu(ref)}[act]
+    pc = K.pack_conv(w.cuda(), b.cuda())
+    src = K.to_cp16(_nhwc(x).cuda())
+    assert torch.equal(src.cpu().permute(0, 1, 4, 2, 3).reshape(B, 64, H, W), x.half())
+    out = K.conv3x3_ws(src, pc, act=act, s2d=s2d)
+    torch.cuda.synchronize()
+    got = out.float().cpu()
+    if s2d:   # [B,H/2,W/2,(py,px,c)] -> [B,H,W,c]
+        got = got.view(B, H // 2, W // 2, 2, 2, Cout).permute(0, 1, 3, 2, 4, 5).reshape(B, H, W, Cout)
+    got = got.permute(0, 3, 1, 2)
+    err = (got - ref).abs().max().item()
+    scale = ref.abs().max().item()
+    assert err <= 1.5e-3 * max(1.0, scale), f"ws conv: max-abs {err} (ref scale {scale})"

@@ -1,0 +1,469 @@
+// 3x3 stride-1 convolution of an fp16 chunk-planar source, many input channels -> 64-wide output blocks, as a persistent
+// kernel fed by an LDS-DMA ring (fp16 MFMA, fp32 accumulate).
+//
+// Block_.body[2] (arch/SIDECVSR_our.py:383-387: Conv2d(256, 64, 3, 1, 1)) and the composed stride-2 convolution of the
+// block's double-resolution branch (1024 space-to-depth channels, 4 of 9 taps per chunk) have too many input channels
+// for weights-stationary LDS (295 / 524 KB per 64 outputs), so both operands stream:
+//   * one 512-thread workgroup per CU walks over 16-row x 32-pixel output tiles; per 16-channel chunk the 18 x 34 pixel
+//     halo (20 pieces of 1 KiB) and the chunk's weight slab (18 pieces; 8 when only four taps carry weights) are
+//     copied global -> LDS by LDS-DMA (buffer_load_dwordx4 ... lds), four or five instructions per wave and chunk,
+//     issued one at a time BETWEEN the taps' MFMAs -- no staging registers, no ds_write pass;
+//   * four ring stages, three chunks (85-115 KB per CU) in flight -- the activations come from HBM, and at its ~4 us
+//     loaded latency two chunks in flight capped the chip at ~3.5 TB/s --, ONE workgroup barrier per chunk (the tiled
+//     kernel needs two and restages through VGPRs); the ring runs across tile boundaries, so the epilogue of one
+//     tile overlaps the loads of the next;
+//   * chunk-planar source [B][Cin/16][H][W][16]: a halo row is 34 x 32 contiguous bytes; out-of-image pixels get an
+//     out-of-range buffer offset = hardware zero fill = the zero padding;
+//   * the dense 32-byte pixel records are made conflict-free for ds_read_b128 by swapping the two 16-byte halves of
+//     every second group of 8 pixels (on the DMA source side and on the read side);
+//   * epilogue (bias, activation, residuals, fp32 or fp16 pixel-major store) 32 output channels at a time through
+//     wave-private scratch that aliases the ring stage just consumed; the residual rows are fetched into registers
+//     while the tile's last chunk computes, so their memory latency is not paid four times per tile.
+// DMA completion is hand-counted (hipcc does not see inline-asm memory operations); the rules sit next to each wait.
+#include "common.h"
+#include "conv_epilogue.h"
+
+namespace {
+
+constexpr int RG_THREADS = 512;
+constexpr int RG_TH = 16, RG_IW = 34, RG_NPIX = 18 * 34;   // 612 staged pixels per chunk
+constexpr int RG_ACT = 20 * 1024;                          // 20 DMA pieces (612 x 32 B = 19,584 B + pad slots)
+constexpr int RG_NS = 4;                                   // ring stages: three chunk batches in flight
+constexpr int RG_SCR = ConvEpi<1>::WAVE_FLOATS * 4;        // 4,608 B of epilogue scratch per wave (8 x = 36,864 B)
+// LDS map.  dense (18 KB of weights per chunk): 4 x 38 KB ring (the epilogue scratch aliases the stage just consumed)
+// | 1 KB dump | 4 KB bias = 160,768 B;  four-tap form (8 KB): 4 x 28 KB ring | 36 KB scratch | dump | bias = 156,672 B
+template <bool SPARSE> struct RingLds {
+  static constexpr int WGT = (SPARSE ? 8 : 18) * 1024;
+  static constexpr int STAGE = RG_ACT + WGT;
+  static constexpr int SCRATCH = RG_NS * STAGE;                                   // used when SPARSE
+  static constexpr int DUMP = RG_NS * STAGE + (SPARSE ? 8 * RG_SCR : 0);          // target of the padding DMA pieces
+  static constexpr int BIAS = DUMP + 1024;
+  static constexpr int TOTAL = BIAS + 4096;
+};
+
+typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+
+struct ring_extra {
+  const void* src;            // fp16 chunk-planar [B][nc][H][W][16]
+  int nc;                     // 16-channel chunks = Cin / 16
+  const void* w;              // fp16 [nc][taps][2][CoutP][8], taps = 9 (dense) or 4 (the chunk's active taps, ascending)
+  int CoutP;
+  const unsigned* tap_mask;   // nullptr = dense
+  int w_bytes;                // size of the weight buffer
+};
+
+// one 1 KiB LDS-DMA piece: lane l writes LDS bytes lds + 16 l from (buffer base + voff + soff).  rsrc / soff / lds must
+// be wave-uniform values the compiler can keep in SGPRs (readfirstlane them).
+__device__ __forceinline__ void rg_dma1(unsigned voff, i32x4 rsrc, unsigned soff, unsigned lds) {
+  unsigned keep;
+  asm volatile(
+      "s_nop 4\n\t"
+      "s_mov_b32 %0, m0\n\t"
+      "s_mov_b32 m0, %4\n\ts_nop 0\n\t"
+      "buffer_load_dwordx4 %1, %2, %3 offen lds\n\t"
+      "s_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(voff), "s"(rsrc), "s"(soff), "s"(lds)
+      : "memory");
+}
+
+__device__ __forceinline__ i32x4 rg_rsrc(const void* base, unsigned bytes) {
+  const unsigned long long p = reinterpret_cast<unsigned long long>(base);
+  i32x4 r;
+  r[0] = (int)(unsigned)p;
+  r[1] = (int)(unsigned)(p >> 32);
+  r[2] = (int)bytes;
+  r[3] = 0x00020000;
+  return r;
+}
+
+template <int V> struct IntC { static constexpr int value = V; };
+
+// DBG (developer ablations, tools/bench_ring.py): 1 = skip the MFMAs, 2 = skip the DMA, 8 = skip the epilogue
+template <bool SPARSE, int DBG>
+__global__ __launch_bounds__(RG_THREADS) void conv3x3_ring_kernel(cdfo_conv_args a, ring_extra e) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int TAPS = SPARSE ? 4 : 9;
+  using L = RingLds<SPARSE>;
+  constexpr int STAGE = L::STAGE;
+  // DMA pieces per wave and chunk.  dense: waves 0-3 copy the 20 activation pieces, waves 4-7 the 18 weight pieces
+  // (+2 padding pieces into the dump kilobyte, so that every loader issues exactly PPW instructions per chunk);
+  // four-tap form: waves 0-4 the activations, waves 5-6 the 8 weight pieces, wave 7 none.
+  constexpr int PPW = SPARSE ? 4 : 5, ACT_WAVES = 20 / PPW;
+  const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, r = lane & 31;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const bool loader_w = wave >= ACT_WAVES;
+  const bool loader = !loader_w || (wave - ACT_WAVES) * PPW < TAPS * 2;
+  const int H = a.H, W = a.W, nc = e.nc;
+  const int tiles_x = (W + 31) >> 5, tiles_y = (H + RG_TH - 1) / RG_TH, tiles = tiles_x * tiles_y;
+  const int nco = a.CoutP >> 6;
+  const int units = a.B * tiles * nco;             // unit = (image, tile, 64-channel output block), block fastest
+  // each XCD (private L2) takes a contiguous band of units; its workgroups stride through the band
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, nslots = gridDim.x >> 3;
+  const int band = (units + 7) >> 3, band0 = xcd * band;
+  const int band_n = min(band, units - band0);     // may be <= 0
+  const int my_units = band_n > slot ? (band_n - slot + nslots - 1) / nslots : 0;
+  if (my_units == 0) return;
+  const unsigned lds0 = (unsigned)(unsigned long long)(smem);
+  for (int i = tid; i < a.CoutP; i += RG_THREADS)
+    reinterpret_cast<float*>(smem + L::BIAS)[i] = (a.bias && i < a.Cout) ? a.bias[i] : 0.f;
+  // (made visible to the other waves by the barriers of the chunk loop, long before the first epilogue)
+
+  // ---- per-lane DMA descriptors
+  // activation piece q = PPW*wave + j: slot s = 64 q + lane -> pixel p = s >> 1 of the 18 x 34 halo, k-half
+  // (s & 1) ^ ((p >> 3) & 1);  weight piece q = slab row (tap*2 + k-half), lane = output channel of the block
+  int d_iy[PPW], d_ix[PPW], d_rel[PPW], dst_off[PPW];
+#pragma unroll
+  for (int j = 0; j < PPW; ++j) {
+    if (!loader_w) {
+      const int q = wave * PPW + j, s = q * 64 + lane, p = s >> 1, half = (s & 1) ^ ((p >> 3) & 1);
+      const int iy = p / RG_IW, ix = p - iy * RG_IW;
+      d_iy[j] = p < RG_NPIX ? iy : 1 << 20;
+      d_ix[j] = ix;
+      d_rel[j] = (iy * W + ix) * 32 + half * 16;
+      dst_off[j] = q * 1024;
+    } else {
+      const int q = (wave - ACT_WAVES) * PPW + j;
+      d_iy[j] = q < TAPS * 2 ? 0 : 1 << 20;
+      d_ix[j] = 0;
+      d_rel[j] = (q * e.CoutP + lane) * 16;
+      dst_off[j] = q < TAPS * 2 ? RG_ACT + q * 1024 : -1;      // padding piece -> dump
+    }
+  }
+  const unsigned plane = (unsigned)(H * W) * 32u;                 // bytes of one 16-channel plane
+  const unsigned wchunk = (unsigned)(TAPS * 2 * e.CoutP) * 16u;   // bytes of one chunk's weight slab (all output blocks)
+  const unsigned img_bytes = plane * (unsigned)nc;
+  const i32x4 rsrc_w = rg_rsrc(e.w, (unsigned)e.w_bytes);
+
+  // ---- fragment read offsets: tile rows 2w..2w+3 of the halo, column offset dx, this lane's pixel r
+  int p_off[12];
+#pragma unroll
+  for (int rr = 0; rr < 4; ++rr)
+#pragma unroll
+    for (int dx = 0; dx < 3; ++dx) {
+      const int p = (wave * 2 + rr) * RG_IW + dx + r;
+      p_off[rr * 3 + dx] = (2 * p + (h ^ ((p >> 3) & 1))) * 16;
+    }
+  const int w_off = RG_ACT + (h * 64 + r) * 16;
+
+  auto unit_coords = [&](int ord, int& b, int& oy0, int& ox0, int& n0) {
+    const int uidx = band0 + slot + ord * nslots;
+    const int nb = uidx % nco, t = uidx / nco;
+    const int tile = t % tiles;
+    b = t / tiles;
+    const int ty = tile / tiles_x;
+    oy0 = ty * RG_TH; ox0 = (tile - ty * tiles_x) * 32; n0 = nb * 64;
+  };
+
+  // ---- issue cursor: (unit, chunk) of the next DMA batch; a batch is issued piece by piece between the MFMAs
+  int iu = 0, ic = 0, gi = 0;         // unit ordinal, chunk, batches issued so far (stage = gi % RG_NS)
+  unsigned voff[PPW];
+  i32x4 rsrc_i = rsrc_w;
+  unsigned soff_i = 0, stage_i = 0;
+  auto issue_begin = [&]() {
+    if (ic == 0) {                    // descriptors of unit `iu`
+      int b, oy0, ox0, n0;
+      unit_coords(iu, b, oy0, ox0, n0);
+      if (!loader_w) {
+        rsrc_i = rg_rsrc(static_cast<const unsigned char*>(e.src) + (unsigned long long)b * img_bytes, img_bytes);
+        const int base = ((oy0 - 1) * W + (ox0 - 1)) * 32;
+#pragma unroll
+        for (int j = 0; j < PPW; ++j) {
+          const int gy = oy0 - 1 + d_iy[j], gx = ox0 - 1 + d_ix[j];
+          const bool ok = gy >= 0 && gy < H && gx >= 0 && gx < W;
+          voff[j] = ok ? (unsigned)(base + d_rel[j]) : 0x80000000u;      // out of range => the DMA writes zeros
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < PPW; ++j) voff[j] = d_iy[j] == 0 ? (unsigned)(d_rel[j] + n0 * 16) : 0x80000000u;
+      }
+      soff_i = 0;
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) rsrc_i[k] = __builtin_amdgcn_readfirstlane(rsrc_i[k]);
+    soff_i = __builtin_amdgcn_readfirstlane(soff_i);
+    stage_i = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)((gi % RG_NS) * STAGE));
+  };
+  auto issue_piece = [&](int j) {     // j is a compile-time constant at every call site
+    if (DBG & 2) return;
+    if (!loader) return;
+    const unsigned dst = __builtin_amdgcn_readfirstlane(dst_off[j] >= 0 ? stage_i + (unsigned)dst_off[j] : lds0 + (unsigned)L::DUMP);
+    rg_dma1(voff[j], rsrc_i, soff_i, dst);
+  };
+  auto issue_end = [&]() {
+    soff_i += loader_w ? wchunk : plane;
+    ++gi;
+    if (++ic == nc) { ic = 0; ++iu; }
+  };
+  const int total = my_units * nc;    // chunk batches of this workgroup
+#pragma unroll
+  for (int k = 0; k < RG_NS - 1; ++k)
+    if (k < total) {
+      issue_begin();
+#pragma unroll
+      for (int j = 0; j < PPW; ++j) issue_piece(j);
+      issue_end();
+    }
+  bool prev_full = false, prev_res = false;
+
+  const float slope = a.act == CDFO_ACT_NONE ? 1.f : (a.act == CDFO_ACT_LRELU ? 0.1f : 0.f);
+  const int c4 = lane & 7, pr = lane >> 3;    // epilogue read-back: 4 channels c4*4.. of pixel it*8 + pr
+
+  int g = 0;                          // batch being consumed
+  for (int ord = 0; ord < my_units; ++ord) {
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc[mi][ni][q] = 0.f;
+    int b, oy0, ox0, n0;
+    unit_coords(ord, b, oy0, ox0, n0);
+    const int oyw = oy0 + wave * 2;
+    // a full tile issues exactly 16 epilogue stores (+ 16 residual loads) per wave: counted in the next wait
+    const bool full = ox0 + 32 <= W && oyw + 2 <= H && n0 + 64 <= a.Cout;
+
+    // one chunk: wait + barrier, then the taps' MFMAs with the pieces of batch g+3 issued between them (a DMA
+    // instruction takes 100-200 cycles to issue; behind a tap's four MFMAs that time is covered by the matrix pipe)
+    auto chunk = [&](int c, bool first_after_full_tile, bool had_res) {
+      // (1) my pieces of batch g have landed.  Younger vector-memory operations: the DMA batches g+1, g+2 (2 PPW
+      //     instructions) and, on the first chunk after a full tile, that tile's 16 epilogue stores and 16 residual
+      //     loads, all issued after batch g (gfx9 retires loads and stores in issue order, the rule hipcc's own
+      //     vmcnt(N) rely on).  (2) my fragment reads of batch g-1 have RETURNED (its stage is overwritten after the
+      //     barrier).  Then the barrier: everyone's pieces of g are in LDS, nobody still reads the stage of g-1.
+      if (g + 2 >= total) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      else if (first_after_full_tile && had_res) {
+        if (PPW == 5) asm volatile("s_waitcnt vmcnt(42) lgkmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(40) lgkmcnt(0)" ::: "memory");
+      } else if (first_after_full_tile) {
+        if (PPW == 5) asm volatile("s_waitcnt vmcnt(26) lgkmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(24) lgkmcnt(0)" ::: "memory");
+      } else {
+        if (PPW == 5) asm volatile("s_waitcnt vmcnt(10) lgkmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+      }
+      __builtin_amdgcn_s_barrier();
+      const bool do_issue = g + RG_NS - 1 < total;     // batch g+3 -> the stage batch g-1 lived in
+      if (do_issue) issue_begin();
+      const unsigned char* st = smem + (g % RG_NS) * STAGE;
+      const unsigned char* sW = st + w_off;
+      f16x8_t fa[2][2], fb[2][2];                      // [parity][tile]: fragments are read one tap ahead
+      auto mma_tap = [&](int par) {
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < 2; ++ni) {
+            if (DBG & 1) acc[mi][ni][0] += (float)fa[par][mi][0] * (float)fb[par][ni][0];
+            else acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[par][mi], fb[par][ni], acc[mi][ni], 0, 0, 0);
+          }
+      };
+      if (SPARSE) {
+        // the chunk's four taps are a 2x2 window of the 3x3 stencil (checked by the host wrapper): top-left (y0, x0)
+        const unsigned tm = e.tap_mask[c];
+        const int win = ((tm & 0x7u) ? 0 : 2) + ((tm & 0x49u) ? 0 : 1);
+        auto window = [&](auto Y0, auto X0) {
+          constexpr int y0 = decltype(Y0)::value, x0 = decltype(X0)::value;
+          auto load_frags = [&](int j, int par) {      // j = dy*2 + dx inside the window = slab slot
+            const int dy = y0 + (j >> 1), dx = x0 + (j & 1);
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi) fa[par][mi] = *reinterpret_cast<const f16x8_t*>(st + p_off[(mi + dy) * 3 + dx]);
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni) fb[par][ni] = *reinterpret_cast<const f16x8_t*>(sW + (j * 2 * 64 + ni * 32) * 16);
+          };
+          load_frags(0, 0);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            if (j < 3) load_frags(j + 1, (j & 1) ^ 1);
+            mma_tap(j & 1);
+            if (do_issue) issue_piece(j);
+          }
+        };
+        switch (win) {
+          case 0: window(IntC<0>{}, IntC<0>{}); break;
+          case 1: window(IntC<0>{}, IntC<1>{}); break;
+          case 2: window(IntC<1>{}, IntC<0>{}); break;
+          default: window(IntC<1>{}, IntC<1>{}); break;
+        }
+      } else {
+        auto load_frags = [&](int t, int par) {
+          const int dy = t / 3, dx = t - dy * 3;
+#pragma unroll
+          for (int mi = 0; mi < 2; ++mi) fa[par][mi] = *reinterpret_cast<const f16x8_t*>(st + p_off[(mi + dy) * 3 + dx]);
+#pragma unroll
+          for (int ni = 0; ni < 2; ++ni) fb[par][ni] = *reinterpret_cast<const f16x8_t*>(sW + (t * 2 * 64 + ni * 32) * 16);
+        };
+        load_frags(0, 0);
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+          if (t < 8) load_frags(t + 1, (t & 1) ^ 1);
+          mma_tap(t & 1);
+          if (do_issue && t < PPW) issue_piece(t);
+        }
+      }
+      if (do_issue) issue_end();
+    };
+
+    for (int c = 0; c < nc - 1; ++c, ++g) chunk(c, c == 0 && prev_full, prev_res);
+    // ---- last chunk of the tile (peeled so that the residual registers are live only here): the residual rows are
+    // fetched while its MFMAs run
+    f32x4 rv[2][2][4];
+    const bool has_res = a.res1 != nullptr && !(DBG & 8);
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+        for (int it = 0; it < 4; ++it) rv[mi][ni][it] = f32x4{0.f, 0.f, 0.f, 0.f};
+    auto load_res = [&]() {
+      if (!has_res) return;
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi) {
+        const float* rrow = a.res1 + ((long long)(b * H + oyw + mi) * W + ox0) * a.ldr1 + n0 + c4 * 4;
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+          for (int it = 0; it < 4; ++it) {
+            const int xi = it * 8 + pr;
+            if (oyw + mi < H && ox0 + xi < W && n0 + ni * 32 + c4 * 4 < a.Cout)
+              rv[mi][ni][it] = *reinterpret_cast<const f32x4*>(rrow + xi * a.ldr1 + ni * 32);
+          }
+      }
+    };
+    // (four-tap form: 64 chunks per tile, the window switch needs the registers -> fetch after the last chunk)
+    if (!SPARSE) load_res();
+    chunk(nc - 1, nc == 1 && prev_full, prev_res);
+    ++g;
+    if (SPARSE) load_res();
+
+    // ---- epilogue: +bias -> act -> +res1 -> +res2 -> store, 32 channels x 32 pixels at a time through wave-private
+    // scratch.  Dense form: the scratch aliases the stage of the tile's last batch (g-1): every wave must be done
+    // reading it (barrier), and the next DMA into that stage is issued only after the NEXT barrier, which every wave
+    // reaches after its epilogue.  Four-tap form: dedicated scratch, no barrier.
+    if (!SPARSE) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+    }
+    prev_full = full && !(DBG & 8);
+    prev_res = has_res;
+    if (DBG & 8) {
+      float t = 0.f;
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+          for (int q = 0; q < 16; ++q) t += acc[mi][ni][q];
+      if (t == 123.456f) a.out[0] = t;
+      continue;
+    }
+    constexpr int RS = ConvEpi<1>::RS;
+    float* wl = reinterpret_cast<float*>(smem + (SPARSE ? L::SCRATCH : ((g - 1) % RG_NS) * STAGE) + wave * RG_SCR);
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) {
+      const int oy = oyw + mi;
+      const long long pixrow = (long long)(b * H + oy) * W + ox0;
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni) {
+        const int n = n0 + ni * 32 + c4 * 4;
+        const bool nok = n < a.Cout;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) wl[((q & 3) + 8 * (q >> 2) + 4 * h) * RS + r] = acc[mi][ni][q];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        // from LDS: a conditional global load here would make hipcc drain vmcnt -- and with it the DMA ring -- at
+        // the top of every tile
+        const f32x4 bias = *reinterpret_cast<const f32x4*>(smem + L::BIAS + (n0 + ni * 32 + c4 * 4) * 4);
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+          const int xi = it * 8 + pr;
+          f32x4 v = *reinterpret_cast<const f32x4*>(wl + xi * RS + c4 * 4) + bias;
+#pragma unroll
+          for (int k = 0; k < 4; ++k) v[k] = fmaxf(v[k], 0.f) + slope * fminf(v[k], 0.f);
+          v += rv[mi][ni][it];      // unconditional use: no residual load may stay "pending" across the tile loop
+          if (!nok || oy >= H || ox0 + xi >= W) continue;
+          if (a.res2) v += *reinterpret_cast<const f32x4*>(a.res2 + (pixrow + xi) * a.ldr2 + n);
+          const long long o = (pixrow + xi) * a.ldo + n;
+          if (a.out_f16) {
+            typedef _Float16 f16x4_t __attribute__((ext_vector_type(4)));
+            f16x4_t hv;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) hv[k] = (_Float16)v[k];
+            *reinterpret_cast<f16x4_t*>(reinterpret_cast<_Float16*>(a.out) + o) = hv;
+          } else {
+            *reinterpret_cast<f32x4*>(a.out + o) = v;
+          }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+      }
+    }
+  }
+}
+
+int rg_num_cus() {
+  static int cus = 0;
+  if (!cus) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 0;
+    cus = prop.multiProcessorCount;
+  }
+  return cus;
+}
+
+template <bool SPARSE, int DBG>
+int rg_launch(const cdfo_conv_args& a, const ring_extra& e, int grid, hipStream_t st) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_ring_kernel<SPARSE, DBG>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, RingLds<SPARSE>::TOTAL);
+    if (err != hipSuccess) return (int)err;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((conv3x3_ring_kernel<SPARSE, DBG>), dim3(grid), dim3(RG_THREADS), RingLds<SPARSE>::TOTAL, st, a, e);
+  return 0;
+}
+
+}  // namespace
+
+extern "C" int cdfo_conv3x3_ring(const cdfo_conv_args* pa, void* stream) {
+  const cdfo_conv_args& a = *pa;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (a.nsrc != 1 || a.B <= 0 || a.ks != 3 || a.stride != 1 || a.pad != 1 || !a.src_f16) return CDFO_EINVAL;
+  if (a.act == CDFO_ACT_SIGMOID || a.Cin <= 0 || a.Cin % 16 || a.cs[0] != a.Cin || a.ld[0] != 16) return CDFO_EINVAL;
+  if (a.CoutP % 64 || a.CoutP > 1024 || a.CoutP < a.Cout || a.Cout <= 0 || a.Ho != a.H || a.Wo != a.W || a.w_bstride != 0) return CDFO_EINVAL;
+  if (a.store_mode != CDFO_STORE_PLAIN) return CDFO_EINVAL;
+  if (!aligned16(a.src[0]) || !aligned16(a.w) || a.Cout % 4 || a.ldo % 4 || !aligned16(a.out) ||
+      (a.bias && !aligned16(a.bias)))
+    return CDFO_EALIGN;
+  if ((a.res1 && (a.ldr1 % 4 || !aligned16(a.res1))) || (a.res2 && (a.ldr2 % 4 || !aligned16(a.res2)))) return CDFO_EALIGN;
+  const int nc = a.Cin / 16;
+  if ((long long)nc * a.H * a.W * 32 >= (1ll << 31) || (long long)a.B * a.H * a.W >= (1ll << 31)) return CDFO_EINVAL;
+  const int taps = a.tap_mask ? 4 : 9;
+  const long long w_bytes = (long long)nc * taps * 2 * a.CoutP * 16;
+  if (w_bytes >= (1ll << 31)) return CDFO_EINVAL;
+  const int cus = rg_num_cus();
+  if (cus < 8) return CDFO_EINVAL;
+  ring_extra e;
+  e.src = a.src[0]; e.nc = nc; e.w = a.w; e.CoutP = a.CoutP; e.tap_mask = a.tap_mask; e.w_bytes = (int)w_bytes;
+  const int grid = cus / 8 * 8;
+  const double px = (double)a.B * a.Ho * a.Wo;
+  CdfoProfScope prof(st, KID_CONV3_WIDE, 2.0 * px * a.Cout * a.Cin * taps,
+                     2.0 * px * a.Cin + (a.out_f16 ? 2.0 : 4.0) * px * a.Cout + 2.0 * taps * a.Cin * a.Cout);
+  int rc;
+  switch (a.prec >> 8) {
+    case 0: rc = a.tap_mask ? rg_launch<true, 0>(a, e, grid, st) : rg_launch<false, 0>(a, e, grid, st); break;
+    case 1: rc = a.tap_mask ? rg_launch<true, 1>(a, e, grid, st) : rg_launch<false, 1>(a, e, grid, st); break;
+    case 2: rc = a.tap_mask ? rg_launch<true, 2>(a, e, grid, st) : rg_launch<false, 2>(a, e, grid, st); break;
+    case 8: rc = a.tap_mask ? rg_launch<true, 8>(a, e, grid, st) : rg_launch<false, 8>(a, e, grid, st); break;
+    case 9: rc = a.tap_mask ? rg_launch<true, 9>(a, e, grid, st) : rg_launch<false, 9>(a, e, grid, st); break;
+    case 10: rc = a.tap_mask ? rg_launch<true, 10>(a, e, grid, st) : rg_launch<false, 10>(a, e, grid, st); break;
+    default: return CDFO_EINVAL;
+  }
+  if (rc) return rc;
+  CDFO_LAUNCH_CHECK();
+  return 0;
+}

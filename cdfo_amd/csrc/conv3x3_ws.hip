@@ -13,9 +13,13 @@
 //     drift apart freely, so one wave's DMA wait or epilogue is covered by its SIMD partner's MFMAs;
 //   * reads a "chunk-planar" fp16 source [B][Cin/16][H][W][16]: a staged image row is 34 x 32 contiguous bytes, every
 //     DMA piece moves whole cache lines (the pixel-major layout would touch 32 bytes of each 128-byte line);
-//   * computes the transposed product (M = output channels, N = pixels): a lane's accumulator registers then hold four
-//     CONSECUTIVE channels of one pixel, the epilogue packs them to fp16 and transposes through 4.6 KB of the wave's
-//     own ring with 8-byte writes / 16-byte reads, and every global store is 16 bytes per lane, 128 bytes per pixel.
+//   * computes the transposed product (M = output channels, N = pixels) with the weight rows of each 32-channel block
+//     permuted so that a lane's accumulator registers hold 8 CONSECUTIVE channels of one pixel per 16-channel chunk:
+//     the epilogue is activation + fp16 pack + one 16-byte store per lane and chunk straight from registers into the
+//     chunk-planar result [B][Cout/16][H][W][16] (a wave-instruction writes 1 KiB contiguous) -- no LDS transpose.
+//     The result is the source layout of cdfo_conv3x3_ring (Block_.body[2]); CDFO_STORE_S2D writes the
+//     space-to-depth form [B][4*Cout/16][H/2][W/2][16] (chunk = phase*Cout/16 + channel/16) for the composed
+//     stride-2 convolution of the double-resolution branch.
 // The LDS image is dense (32 bytes per pixel) because LDS-DMA writes lane-linear; bank conflicts of the ds_read_b128
 // fragment reads are removed by swapping the two 16-byte halves of every second group of 8 pixels, applied on the DMA
 // source side and on the read side.
@@ -33,7 +37,6 @@ constexpr int WS_STG_OFF = WS_W_BYTES + 256;
 constexpr int WS_BUF = 5 * 1024;                           // one 16-channel chunk of a wave's halo: 136 px x 32 B in 5 DMA pieces
 constexpr int WS_LDS = WS_STG_OFF + 8 * 2 * WS_BUF;        // 155,904 bytes
 constexpr int WS_IW = 34, WS_NPIX = 4 * 34;
-constexpr int WS_EPI_ROW = 144;                            // epilogue scratch: 64 fp16 + 16 B pad per pixel (32 rows = 4,608 B)
 
 typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x4_t __attribute__((ext_vector_type(4)));
@@ -46,7 +49,7 @@ struct ws_args {
   const unsigned short* w; int CoutP;       // cdfo_pack_conv3x3_f16 packing, CoutP = its padded channel count
   const float* bias;
   int Cout, act;
-  _Float16* out; int ldo, s2d;
+  _Float16* out; int s2d;
 };
 
 // five 1 KiB LDS-DMA pieces: lane l of piece k writes LDS bytes lds + 1024 k + 16 l from (buffer base + voff[k] + soff)
@@ -87,12 +90,15 @@ __global__ __launch_bounds__(WS_THREADS) void conv3x3_c64_ws_kernel(ws_args a) {
   const int H = a.H, W = a.W;
 
   // ---- one-time: this workgroup's weight block and bias
+  // MFMA row m = 8j + 4h + k of a 32-channel block holds channel (j>>1)*16 + h*8 + (j&1)*4 + k, so that a lane's
+  // accumulators (fixed h; j, k = register index) are 8 consecutive channels of each 16-channel chunk
+  auto chan_of_row = [](int n) { const int m = n & 31; return (n & 32) + ((m >> 4) & 1) * 16 + ((m >> 2) & 1) * 8 + ((m >> 3) & 1) * 4 + (m & 3); };
   for (int i = tid; i < WS_W_BYTES / 16; i += WS_THREADS) {
     const int row = i >> 6, n = i & 63;          // row = (chunk*9 + tap)*2 + k-half
     *reinterpret_cast<u32x4*>(smem + i * 16) =
-        *reinterpret_cast<const u32x4*>(a.w + ((long long)row * a.CoutP + n0 + n) * 8);
+        *reinterpret_cast<const u32x4*>(a.w + ((long long)row * a.CoutP + n0 + chan_of_row(n)) * 8);
   }
-  if (tid < 64) reinterpret_cast<float*>(smem + WS_BIAS_OFF)[tid] = a.bias ? a.bias[n0 + tid] : 0.f;
+  if (tid < 64) reinterpret_cast<float*>(smem + WS_BIAS_OFF)[tid] = a.bias ? a.bias[n0 + chan_of_row(tid)] : 0.f;
   __syncthreads();
 
   // ---- per-lane constants
@@ -224,8 +230,8 @@ __global__ __launch_bounds__(WS_THREADS) void conv3x3_c64_ws_kernel(ws_args a) {
     }
     prev_full = cx0 + 32 <= W;
 
-    // ---- epilogue: act -> fp16 -> transpose through ring buffer 1 (chunk 3's image, dead now; the DMA in flight
-    // targets buffer 0) -> 16-byte stores.  acc[ni][mi][4j+k] = channel ni*32 + 8j + 4h + k of pixel r in row mi.
+    // ---- epilogue: act -> fp16 -> 16-byte stores.  acc[ni][mi][8jj + 4b + k] = channel ni*32 + jj*16 + h*8 + b*4 + k of
+    // pixel r in image row mi, i.e. halves [h*8, h*8+8) of chunk nb*4 + ni*2 + jj.
     if (DBG & 8) {
       float t = 0.f;
 #pragma unroll
@@ -237,38 +243,33 @@ __global__ __launch_bounds__(WS_THREADS) void conv3x3_c64_ws_kernel(ws_args a) {
       if (t == 123.456f) a.out[0] = (_Float16)t;
       continue;
     }
-    unsigned char* scr = stg + WS_BUF;
+    const int nck = a.Cout >> 4;                     // 16-channel chunks of the result
+    const bool xok = cx0 + r < W;
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi) {
+      const int y = cy0 + mi, x = cx0 + r;
+      long long pos;      // (chunk-plane 0 of this workgroup's block, pixel) in 16-half records
+      long long cstride;  // records between consecutive chunk planes
+      if (a.s2d) {
+        const int ph = (y & 1) * 2 + (x & 1);
+        cstride = (long long)hp * (W >> 1);
+        pos = ((long long)cb * 4 * nck + ph * nck + nb * 4) * cstride + (long long)(y >> 1) * (W >> 1) + (x >> 1);
+      } else {
+        cstride = (long long)H * W;
+        pos = ((long long)cb * nck + nb * 4) * cstride + (long long)y * W + x;
+      }
 #pragma unroll
       for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          f16x4_t hv;
+        for (int jj = 0; jj < 2; ++jj) {
+          f16x8_t hv;
 #pragma unroll
-          for (int k = 0; k < 4; ++k) {
-            const float v = acc[ni][mi][4 * j + k];
-            hv[k] = (_Float16)(fmaxf(v, 0.f) + slope * fminf(v, 0.f));
+          for (int q = 0; q < 8; ++q) {
+            const float v = acc[ni][mi][8 * jj + q];
+            hv[q] = (_Float16)(fmaxf(v, 0.f) + slope * fminf(v, 0.f));
           }
-          *reinterpret_cast<f16x4_t*>(scr + r * WS_EPI_ROW + (ni * 32 + 8 * j + 4 * h) * 2) = hv;
+          if (xok) *reinterpret_cast<f16x8_t*>(a.out + (pos + (ni * 2 + jj) * cstride) * 16 + h * 8) = hv;
         }
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-      const int y = cy0 + mi, piece = lane & 7;
-      long long rowbase;    // element offset of (row y, pixel cx0, channel n0 + 8 piece)
-      if (a.s2d) rowbase = ((long long)(cb * hp + (y >> 1)) * (W >> 1) + (cx0 >> 1)) * a.ldo + (y & 1) * 2 * a.Cout + n0 + piece * 8;
-      else rowbase = ((long long)(cb * H + y) * W + cx0) * a.ldo + n0 + piece * 8;
-      _Float16* orow = a.out + rowbase;
-#pragma unroll
-      for (int it = 0; it < 4; ++it) {
-        const int pix = it * 8 + (lane >> 3);
-        const u32x4 v = *reinterpret_cast<const u32x4*>(scr + pix * WS_EPI_ROW + piece * 16);
-        const int eoff = a.s2d ? (pix >> 1) * a.ldo + (pix & 1) * a.Cout : pix * a.ldo;
-        if (cx0 + pix < W) *reinterpret_cast<u32x4*>(orow + eoff) = v;
-      }
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
     }
   }
 }
@@ -320,15 +321,15 @@ __global__ __launch_bounds__(256) void to_cp16_kernel(const float* __restrict__ 
 }  // namespace
 
 extern "C" int cdfo_conv3x3_c64_ws(const void* src_cp16, int B, int H, int W, const void* w_f16, int CoutP,
-                                   const float* bias, int Cout, int act, void* out_f16, int ldo, int store_mode,
-                                   int dbg, void* stream) {
+                                   const float* bias, int Cout, int act, void* out_cp16, int store_mode, int dbg,
+                                   void* stream) {
   hipStream_t st = static_cast<hipStream_t>(stream);
   if (B <= 0 || H <= 0 || W <= 0 || (H & 1) || Cout <= 0 || Cout % 64 || CoutP < Cout || CoutP % 64) return CDFO_EINVAL;
   if (act == CDFO_ACT_SIGMOID || (store_mode != CDFO_STORE_PLAIN && store_mode != CDFO_STORE_S2D)) return CDFO_EINVAL;
   if (store_mode == CDFO_STORE_S2D && (W & 1)) return CDFO_EINVAL;
   const long long src_bytes = (long long)B * 4 * H * W * 32;
   if (src_bytes >= (1ll << 31)) return CDFO_EINVAL;      // 32-bit buffer offsets, out-of-range marker 0x80000000
-  if (!aligned16(src_cp16) || !aligned16(w_f16) || !aligned16(out_f16) || ldo % 8) return CDFO_EALIGN;
+  if (!aligned16(src_cp16) || !aligned16(w_f16) || !aligned16(out_cp16)) return CDFO_EALIGN;
   const int cus = ws_num_cus();
   if (cus < 8) return CDFO_EINVAL;
   const int nco = Cout / 64;
@@ -340,7 +341,7 @@ extern "C" int cdfo_conv3x3_c64_ws(const void* src_cp16, int B, int H, int W, co
   a.B = B; a.H = H; a.W = W;
   a.w = static_cast<const unsigned short*>(w_f16); a.CoutP = CoutP;
   a.bias = bias; a.Cout = Cout; a.act = act;
-  a.out = static_cast<_Float16*>(out_f16); a.ldo = ldo; a.s2d = store_mode == CDFO_STORE_S2D;
+  a.out = static_cast<_Float16*>(out_cp16); a.s2d = store_mode == CDFO_STORE_S2D;
   const double px = (double)B * H * W;
   CdfoProfScope prof(st, KID_CONV3_WIDE, 2.0 * px * Cout * 64 * 9, 2.0 * (px * Cout + px * 64) + 2.0 * 9 * 64 * Cout);
   int rc;

@@ -312,15 +312,16 @@ class CVSR_V8(nn.Module):
         # a single-pass fp16 MFMA whose staging is a plain copy
         t16 = self.precision == "fp16x2"
         if t16 and x.shape[1] % 4 == 0 and b0.wh is not None:
-            # body[0] on the weights-stationary kernel (fp16 chunk-planar sources, fp16 results; same arithmetic as the
-            # single-pass fp16 mode of the tiled kernel: fp16 operands, fp32 accumulation)
+            # body[0] on the weights-stationary kernel, body[2] / the composed stride-2 convolution on the LDS-DMA ring
+            # kernel; the 64- and 256-channel tensors between them are fp16 chunk-planar [B,C/16,H,W,16].  Same
+            # arithmetic as the single-pass fp16 mode of the tiled kernel: fp16 operands, fp32 accumulation
             c1 = lambda src, **kw: K.conv3x3_ws(src, b0, act=K.ACT_LRELU, **kw)
-            out = self._conv(c1(K.to_cp16(x)), b2, pad=1, res1=x)
+            out = K.conv_ring(c1(K.to_cp16(x)), b2, res1=x)
             d = self._conv(K.resample2(x, up=False), dn)
-            d = self._conv(c1(K.to_cp16(d)), b2, pad=1)
+            d = K.conv_ring(c1(K.to_cp16(d)), b2)
             K.resample2(self._conv(d, up), up=True, out=out, accumulate=True)
             t = c1(K.resample2(self._conv(x, up), up=True, cp16=True), s2d=True)
-            return self._conv(t, w[p + "down_fused"], pad=1, res1=out)
+            return K.conv_ring(t, w[p + "down_fused"], res1=out)
         out = self._conv(self._conv(x, b0, pad=1, act=K.ACT_LRELU, out_f16=t16, inner=True), b2, pad=1, res1=x)
         # half-resolution branch
         d = self._conv(K.resample2(x, up=False), dn)

@@ -78,6 +78,7 @@ class PackedConv:
     tap_mask: Optional[torch.Tensor] = None   # int32 [Cin/16]: bit t set = tap t of that chunk has weights
     wh: Optional[torch.Tensor] = None   # fp16 packing (single block) for PREC_FP16X2
     CoutP16: int = 0                    # padded output channels of the 16-bit packings (multiple of 64)
+    wh_sparse: Optional[torch.Tensor] = None   # fp16 packing of the four active taps per chunk (conv_ring + tap_mask)
 
 
 def pack_conv(weight: torch.Tensor, bias: Optional[torch.Tensor], shuffle2: bool = False,
@@ -207,7 +208,8 @@ def to_cp16(x: torch.Tensor) -> torch.Tensor:
 def conv3x3_ws(src: torch.Tensor, pc: PackedConv, *, act: int = ACT_NONE, s2d: bool = False,
                out: Optional[torch.Tensor] = None, dbg: int = 0) -> torch.Tensor:
     """Block_.body[0]-shaped convolution (3x3, 64 input channels, Cout % 64 == 0) on the weights-stationary kernel.
-    src: fp16 chunk-planar [B,4,H,W,16]; result: fp16 pixel-major [B,H,W,Cout] (or space-to-depth [B,H/2,W/2,4*Cout])."""
+    src: fp16 chunk-planar [B,4,H,W,16]; result: fp16 chunk-planar [B,Cout/16,H,W,16], or with s2d its space-to-depth
+    form [B,4*Cout/16,H/2,W/2,16] (chunk = phase*Cout/16 + channel/16, phase = (y&1)*2 + (x&1))."""
     if not src.is_cuda:
         raise NotImplementedError("conv3x3_ws: the HIP path needs device tensors (no CPU fallback)")
     if src.dtype != torch.float16 or src.dim() != 5 or src.shape[1] != 4 or src.shape[4] != 16 or not src.is_contiguous():
@@ -215,12 +217,76 @@ def conv3x3_ws(src: torch.Tensor, pc: PackedConv, *, act: int = ACT_NONE, s2d: b
     if pc.wh is None or pc.Cin != 64 or pc.ks != 3 or pc.Cout % 64:
         raise ValueError("conv3x3_ws: needs a 3x3 weight with 64 input channels and Cout % 64 == 0")
     B, _, H, W, _ = src.shape
+    shape = (B, pc.Cout // 4, H // 2, W // 2, 16) if s2d else (B, pc.Cout // 16, H, W, 16)
     if out is None:
-        shape = (B, H // 2, W // 2, 4 * pc.Cout) if s2d else (B, H, W, pc.Cout)
         out = torch.empty(shape, dtype=torch.float16, device=src.device)
-    _, _, _, _, ldo = _chk_act(out, "out", torch.float16)
+    elif out.shape != shape or out.dtype != torch.float16 or not out.is_contiguous():
+        raise ValueError(f"conv3x3_ws: out must be a contiguous fp16 tensor of shape {shape}")
     check(_lib.lib().cdfo_conv3x3_c64_ws(_vp(src), B, H, W, _vp(pc.wh), pc.CoutP16, _vp(pc.bias), pc.Cout, act, _vp(out),
-                                         ldo, 2 if s2d else 0, dbg, _stream()), "cdfo_conv3x3_c64_ws")
+                                         2 if s2d else 0, dbg, _stream()), "cdfo_conv3x3_c64_ws")
+    return out
+
+
+def from_cp16(t: torch.Tensor) -> torch.Tensor:
+    """chunk-planar [B,C/16,H,W,16] -> pixel-major [B,H,W,C] (torch ops; tests and tools only)."""
+    B, nc, H, W, _ = t.shape
+    return t.permute(0, 2, 3, 1, 4).reshape(B, H, W, nc * 16)
+
+
+def sparse_taps_f16(pc: PackedConv) -> torch.Tensor:
+    """fp16 packing [Cin/16][9][2][CoutP][8] + tap_mask -> [Cin/16][4][2][CoutP][8]: each chunk's four active taps in
+    ascending order (the weight layout cdfo_conv3x3_ring reads when a tap mask is given)."""
+    nc = pc.Cin // 16
+    masks = pc.tap_mask.tolist()
+    idx = []
+    for m in masks:
+        taps = [t for t in range(9) if (m >> t) & 1]
+        if m not in (0x1B, 0x36, 0xD8, 0x1B0):
+            raise ValueError("sparse_taps_f16: every chunk's active taps must be a 2x2 window of the 3x3 stencil")
+        idx.append(taps)
+    idx = torch.tensor(idx, dtype=torch.long, device=pc.wh.device)                  # [nc,4]
+    w = pc.wh.view(nc, 9, 2 * pc.CoutP16 * 8)
+    return torch.gather(w, 1, idx[:, :, None].expand(nc, 4, w.shape[2])).contiguous().view(-1)
+
+
+def conv_ring(src: torch.Tensor, pc: PackedConv, *, act: int = ACT_NONE, res1: Optional[torch.Tensor] = None,
+              res2: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None,
+              out_f16: bool = False, dbg: int = 0) -> torch.Tensor:
+    """3x3/s1/p1 convolution of an fp16 chunk-planar source [B,Cin/16,H,W,16] on the LDS-DMA ring kernel
+    (Block_.body[2] and the composed stride-2 convolution).  Result: pixel-major fp32 (or fp16) [B,H,W,Cout]."""
+    if not src.is_cuda:
+        raise NotImplementedError("conv_ring: the HIP path needs device tensors (no CPU fallback)")
+    if src.dtype != torch.float16 or src.dim() != 5 or src.shape[4] != 16 or not src.is_contiguous():
+        raise ValueError(f"conv_ring: expected a contiguous fp16 [B,C/16,H,W,16] source, got {src.dtype} {tuple(src.shape)}")
+    B, nc, H, W, _ = src.shape
+    if pc.wh is None or pc.ks != 3 or pc.Cin != nc * 16:
+        raise ValueError("conv_ring: weight does not match the source")
+    a = ConvArgs()
+    a.src[0], a.ld[0], a.cs[0], a.nsrc = src.data_ptr(), 16, pc.Cin, 1
+    a.B, a.H, a.W, a.Ho, a.Wo = B, H, W, H, W
+    a.ks, a.stride, a.pad = 3, 1, 1
+    a.Cin, a.Cout, a.CoutP = pc.Cin, pc.Cout, pc.CoutP16
+    if pc.tap_mask is not None:
+        if pc.wh_sparse is None:
+            pc.wh_sparse = sparse_taps_f16(pc)
+        a.w, a.tap_mask = pc.wh_sparse.data_ptr(), pc.tap_mask.data_ptr()
+    else:
+        a.w = pc.wh.data_ptr()
+    a.bias, a.act = _p(pc.bias), act
+    odt = torch.float16 if out_f16 else torch.float32
+    if out is None:
+        out = torch.empty((B, H, W, pc.Cout), dtype=odt, device=src.device)
+    _, _, _, _, a.ldo = _chk_act(out, "out", odt)
+    a.out, a.store_mode, a.prec = out.data_ptr(), 0, PREC_FP16 | (dbg << 8)
+    a.src_f16, a.out_f16 = 1, int(out_f16)
+    for nm, r in (("res1", res1), ("res2", res2)):
+        if r is not None:
+            rb, rh, rw, rc, rld = _chk_act(r, nm)
+            if (rb, rh, rw) != (B, H, W) or rc < pc.Cout:
+                raise ValueError(f"{nm} shape {tuple(r.shape)} does not match the conv output")
+            setattr(a, nm, r.data_ptr())
+            setattr(a, "ldr" + nm[-1], rld)
+    check(_lib.lib().cdfo_conv3x3_ring(C.byref(a), _stream()), "cdfo_conv3x3_ring")
     return out
 
 

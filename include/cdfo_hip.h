@@ -79,10 +79,17 @@ int cdfo_pack_conv3x3_f16(const float* w_oihw, void* packed, int Cout, int Cin, 
  * weights-stationary fp16 MFMA kernel: one workgroup per CU keeps the fp16 weights of 64 output channels in LDS and
  * streams pixel tiles past them.  src_cp16: fp16 "chunk-planar" tensor [B][4][H][W][16] (cdfo_to_cp16, or
  * cdfo_resample2 with out_f16 = 2); w_f16/CoutP: cdfo_pack_conv3x3_f16 packing and its padded channel count;
- * out_f16: fp16 pixel-major [B][H][W][ldo] (CDFO_STORE_PLAIN) or space-to-depth (CDFO_STORE_S2D, see above).
+ * out_cp16: fp16 chunk-planar [B][Cout/16][H][W][16] (CDFO_STORE_PLAIN) or its space-to-depth form
+ * [B][4*Cout/16][H/2][W/2][16], chunk = ((y&1)*2+(x&1))*Cout/16 + channel/16 (CDFO_STORE_S2D).
  * H even, Cout % 64 == 0, the source smaller than 2 GiB.  dbg: 0 (developer ablation flags otherwise).  */
 int cdfo_conv3x3_c64_ws(const void* src_cp16, int B, int H, int W, const void* w_f16, int CoutP, const float* bias,
-                        int Cout, int act, void* out_f16, int ldo, int store_mode, int dbg, void* stream);
+                        int Cout, int act, void* out_cp16, int store_mode, int dbg, void* stream);
+/* 3x3 / stride 1 / pad 1 convolution of an fp16 chunk-planar source (a->src[0] = [B][Cin/16][H][W][16], a->src_f16 = 1,
+ * a->ld[0] = 16, a->cs[0] = Cin) as a persistent kernel fed by an LDS-DMA ring: Block_.body[2] (256 -> 64) and the
+ * composed stride-2 convolution of Block_'s double-resolution branch.  a->w: fp16 [Cin/16][taps][2][CoutP][8] with
+ * taps = 9 (cdfo_pack_conv3x3_f16) or, when a->tap_mask is given, taps = 4: only the chunk's four active taps, in
+ * ascending tap order.  Epilogue and the other fields as cdfo_conv_igemm (fp32 or fp16 pixel-major result).  */
+int cdfo_conv3x3_ring(const cdfo_conv_args* a, void* stream);
 /* fp32 pixel-major [B][P][ldi] (C channels, C % 16 == 0) -> fp16 chunk-planar [B][C/16][P][16].  */
 int cdfo_to_cp16(const float* in, int ldi, int B, long long P, int C, void* out_cp16, void* stream);
 

@@ -258,10 +258,66 @@ def test_conv3x3_c64_ws(Cout, H, W, B, s2d, act):
     assert torch.equal(src.cpu().permute(0, 1, 4, 2, 3).reshape(B, 64, H, W), x.half())
     out = K.conv3x3_ws(src, pc, act=act, s2d=s2d)
     torch.cuda.synchronize()
-    got = out.float().cpu()
+    got = K.from_cp16(out).float().cpu()
     if s2d:   # [B,H/2,W/2,(py,px,c)] -> [B,H,W,c]
         got = got.view(B, H // 2, W // 2, 2, 2, Cout).permute(0, 1, 3, 2, 4, 5).reshape(B, H, W, Cout)
     got = got.permute(0, 3, 1, 2)
     err = (got - ref).abs().max().item()
     scale = ref.abs().max().item()
     assert err <= 1.5e-3 * max(1.0, scale), f"ws conv: max-abs {err} (ref scale {scale})"
+
+
+RING_CASES = [
+    # Cin, Cout, H, W, B, res, out_f16
+    (256, 64, 20, 40, 1, True, False),
+    (256, 64, 16, 32, 3, False, False),
+    (128, 128, 34, 70, 2, True, False),     # two output blocks, ragged tile edges in both directions
+    (64, 64, 48, 96, 2, False, True),
+    (256, 64, 272, 480, 2, True, False),    # more tiles than workgroups: ring runs across tile boundaries
+]
+
+
+@pytest.mark.parametrize("Cin,Cout,H,W,B,res,out_f16", RING_CASES)
+def test_conv3x3_ring_dense(Cin, Cout, H, W, B, res, out_f16):
+    """LDS-DMA ring kernel vs torch-cpu conv2d on the same fp16-rounded operands."""
+    from cdfo_amd import kernels as K
+    g = torch.Generator().manual_seed(Cin + Cout + H + W)
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / (Cin * 9) ** 0.5
+    b = torch.randn(Cout, generator=g)
+    r1 = torch.randn(B, Cout, H, W, generator=g) if res else None
+    ref = F.relu(F.conv2d(x.half().float(), w.half().float(), b, padding=1))
+    if res:
+        ref = ref + r1
+    pc = K.pack_conv(w.cuda(), b.cuda())
+    src = K.to_cp16(_nhwc(x).cuda())
+    out = K.conv_ring(src, pc, act=K.ACT_RELU, res1=_nhwc(r1).cuda() if res else None, out_f16=out_f16)
+    torch.cuda.synchronize()
+    _cmp(out.float(), ref, 1.5e-3 if out_f16 else 1e-4, "ring conv")
+
+
+def test_conv3x3_ring_sparse_taps():
+    """Four-taps-per-chunk form (the composed stride-2 convolution): weights zero outside a per-chunk 2x2 tap window."""
+    from cdfo_amd import kernels as K
+    g = torch.Generator().manual_seed(11)
+    B, H, W, Cin, Cout = 2, 36, 44, 128, 64
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / (Cin * 4) ** 0.5
+    masks = []
+    for c in range(Cin // 16):
+        y0, x0 = (c >> 1) & 1, c & 1                    # 2x2 window at (y0, x0)
+        m = 0
+        for dy in range(2):
+            for dx in range(2):
+                m |= 1 << ((y0 + dy) * 3 + x0 + dx)
+        masks.append(m)
+        keep = torch.zeros(3, 3)
+        keep[y0:y0 + 2, x0:x0 + 2] = 1
+        w[:, c * 16:(c + 1) * 16] *= keep
+    b = torch.randn(Cout, generator=g)
+    ref = F.conv2d(x.half().float(), w.half().float(), b, padding=1)
+    pc = K.pack_conv(w.cuda(), b.cuda())
+    pc.tap_mask = torch.tensor(masks, dtype=torch.int32, device="cuda")
+    out = K.conv_ring(K.to_cp16(_nhwc(x).cuda()), pc)
+    torch.cuda.synchronize()
+    _cmp(out, ref, 1e-4, "ring conv, sparse taps")

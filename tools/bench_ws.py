@@ -26,7 +26,7 @@ def main():
             ms = timeit(lambda: K.conv3x3_ws(src, pc, act=1, s2d=s2d, out=out, dbg=d))
             line += f" ws[dbg {d}] {ms:6.3f} ms {fl/ms/1e9:6.1f} TF/s"
             if d == 0:
-                line += f" (max diff vs tiled {(out.float() - ref.float()).abs().max().item():.2e})"
+                line += f" (max diff vs tiled {(K.from_cp16(out).float() - ref.float()).abs().max().item():.2e})"
         ms = timeit(lambda: K.to_cp16(x))
         print(line + f" | to_cp16 {ms:.3f} ms", flush=True)
 

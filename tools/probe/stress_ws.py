@@ -10,7 +10,7 @@ b = torch.randn(Cout, device="cuda", generator=g)
 pc = K.pack_conv(w, b)
 ref = K.conv([x.half()], pc, pad=1, act=1, out_f16=True)
 src = K.to_cp16(x)
-out = torch.empty_like(ref)
+out = K.conv3x3_ws(src, pc, act=1)
 for dbg in [int(a) for a in sys.argv[1].split(",")]:
     tot = 0
     runs = int(sys.argv[2])
@@ -18,7 +18,7 @@ for dbg in [int(a) for a in sys.argv[1].split(",")]:
     for it in range(runs):
         out.zero_()
         K.conv3x3_ws(src, pc, act=1, out=out, dbg=dbg)
-        bad = ((out.float() - ref.float()).abs() > 0.03)
+        bad = ((K.from_cp16(out).float() - ref.float()).abs() > 0.03)
         n = int(bad.sum().item())
         tot += n
         if n and len(detail) < 6:

@@ -38,6 +38,7 @@ class ConvArgs(C.Structure):
         ("ln_gamma", C.c_void_p), ("ln_beta", C.c_void_p),
         ("tap_mask", C.c_void_p),
         ("src_f16", C.c_int), ("out_f16", C.c_int),
+        ("out2_cp16", C.c_void_p),
     ]
 
 

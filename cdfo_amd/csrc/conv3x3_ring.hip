@@ -222,7 +222,7 @@ __global__ __launch_bounds__(RG_THREADS) void conv3x3_ring_kernel(cdfo_conv_args
     int b, oy0, ox0, n0;
     unit_coords(ord, b, oy0, ox0, n0);
     const int oyw = oy0 + wave * 2;
-    // a full tile issues exactly 16 epilogue stores (+ 16 residual loads) per wave: counted in the next wait
+    // a full tile issues at least 16 epilogue stores (+ 16 residual loads) per wave: counted in the next wait
     const bool full = ox0 + 32 <= W && oyw + 2 <= H && n0 + 64 <= a.Cout;
 
     // one chunk: wait + barrier, then the taps' MFMAs with the pieces of batch g+3 issued between them (a DMA
@@ -386,15 +386,16 @@ __global__ __launch_bounds__(RG_THREADS) void conv3x3_ring_kernel(cdfo_conv_args
           if (!nok || oy >= H || ox0 + xi >= W) continue;
           if (a.res2) v += *reinterpret_cast<const f32x4*>(a.res2 + (pixrow + xi) * a.ldr2 + n);
           const long long o = (pixrow + xi) * a.ldo + n;
-          if (a.out_f16) {
-            typedef _Float16 f16x4_t __attribute__((ext_vector_type(4)));
-            f16x4_t hv;
+          typedef _Float16 f16x4_t __attribute__((ext_vector_type(4)));
+          f16x4_t hv;
 #pragma unroll
-            for (int k = 0; k < 4; ++k) hv[k] = (_Float16)v[k];
-            *reinterpret_cast<f16x4_t*>(reinterpret_cast<_Float16*>(a.out) + o) = hv;
-          } else {
-            *reinterpret_cast<f32x4*>(a.out + o) = v;
-          }
+          for (int k = 0; k < 4; ++k) hv[k] = (_Float16)v[k];
+          if (a.out_f16) *reinterpret_cast<f16x4_t*>(reinterpret_cast<_Float16*>(a.out) + o) = hv;
+          else *reinterpret_cast<f32x4*>(a.out + o) = v;
+          if (a.out2_cp16)   // chunk-planar fp16 copy: record (image, chunk n/16, pixel), halves n%16 ..
+            *reinterpret_cast<f16x4_t*>(static_cast<_Float16*>(a.out2_cp16) +
+                                        (((long long)b * (a.Cout >> 4) + (n >> 4)) * H * W + (long long)oy * W + ox0 + xi) * 16 +
+                                        (n & 15)) = hv;
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -436,6 +437,7 @@ extern "C" int cdfo_conv3x3_ring(const cdfo_conv_args* pa, void* stream) {
   if (a.act == CDFO_ACT_SIGMOID || a.Cin <= 0 || a.Cin % 16 || a.cs[0] != a.Cin || a.ld[0] != 16) return CDFO_EINVAL;
   if (a.CoutP % 64 || a.CoutP > 1024 || a.CoutP < a.Cout || a.Cout <= 0 || a.Ho != a.H || a.Wo != a.W || a.w_bstride != 0) return CDFO_EINVAL;
   if (a.store_mode != CDFO_STORE_PLAIN) return CDFO_EINVAL;
+  if (a.out2_cp16 && (a.Cout % 16 || !aligned16(a.out2_cp16))) return CDFO_EINVAL;
   if (!aligned16(a.src[0]) || !aligned16(a.w) || a.Cout % 4 || a.ldo % 4 || !aligned16(a.out) ||
       (a.bias && !aligned16(a.bias)))
     return CDFO_EALIGN;

@@ -231,38 +231,48 @@ __global__ __launch_bounds__(256) void up2_kernel(const float* __restrict__ in, 
   }
 }
 
-// bilinear x2 with an fp16 "chunk-planar" result [B][C/16][2H][2W][16] (the source layout of cdfo_conv3x3_c64_ws):
-// thread = 4 channels of one output pixel, consecutive threads walk along x inside one 16-channel plane, so a wave
-// writes 512 contiguous bytes.
+// bilinear x2 with an fp16 "chunk-planar" result [B][C/16][2H][2W][16] (the source layout of cdfo_conv3x3_c64_ws).
+// A thread owns 4 channels of the 2x2 output block (2q-1..2q, 2p-1..2p), which reads exactly the 2x2 source block
+// (q-1..q, p-1..p) (clamped at the image edge): one 16-byte load per output pixel instead of four.  Threads walk along
+// p inside one 16-channel plane, so the two output rows are written as runs of consecutive 32-byte pixel records.
 __global__ __launch_bounds__(256) void up2_cp16_kernel(const float* __restrict__ in, int ldi, int B, int H, int W, int C,
                                                        _Float16* __restrict__ out) {
   const int Ho = H * 2, Wo = W * 2, nc = C >> 4;
-  const long long total = (long long)B * nc * Ho * Wo * 4;
+  const long long total = (long long)B * nc * (H + 1) * (W + 1) * 4;
+  typedef _Float16 f16x4_t __attribute__((ext_vector_type(4)));
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
        i += (long long)gridDim.x * blockDim.x) {
     const int g = i & 3;
     long long t = i >> 2;
-    const int x = t % Wo; t /= Wo;
-    const int y = t % Ho; t /= Ho;
+    const int p = t % (W + 1); t /= (W + 1);
+    const int q = t % (H + 1); t /= (H + 1);
     const int c = t % nc;
     const long long b = t / nc;
-    float sy = ((float)y + 0.5f) * 0.5f - 0.5f, sx = ((float)x + 0.5f) * 0.5f - 0.5f;
-    sy = sy < 0.f ? 0.f : sy;
-    sx = sx < 0.f ? 0.f : sx;
-    const int y0 = (int)sy, x0 = (int)sx;
-    const int y1 = y0 + (y0 < H - 1 ? 1 : 0), x1 = x0 + (x0 < W - 1 ? 1 : 0);
-    const float ly = sy - (float)y0, lx = sx - (float)x0;
+    const int xa = p > 0 ? p - 1 : 0, xb = p < W ? p : W - 1;
+    const int ya = q > 0 ? q - 1 : 0, yb = q < H ? q : H - 1;
     const float* base = in + b * H * W * ldi + c * 16 + g * 4;
-    const f32x4 v00 = *reinterpret_cast<const f32x4*>(base + ((long long)y0 * W + x0) * ldi);
-    const f32x4 v01 = *reinterpret_cast<const f32x4*>(base + ((long long)y0 * W + x1) * ldi);
-    const f32x4 v10 = *reinterpret_cast<const f32x4*>(base + ((long long)y1 * W + x0) * ldi);
-    const f32x4 v11 = *reinterpret_cast<const f32x4*>(base + ((long long)y1 * W + x1) * ldi);
-    const f32x4 v = (1.f - ly) * ((1.f - lx) * v00 + lx * v01) + ly * ((1.f - lx) * v10 + lx * v11);
-    typedef _Float16 f16x4_t __attribute__((ext_vector_type(4)));
-    f16x4_t hv;
+    const f32x4 vaa = *reinterpret_cast<const f32x4*>(base + ((long long)ya * W + xa) * ldi);
+    const f32x4 vab = *reinterpret_cast<const f32x4*>(base + ((long long)ya * W + xb) * ldi);
+    const f32x4 vba = *reinterpret_cast<const f32x4*>(base + ((long long)yb * W + xa) * ldi);
+    const f32x4 vbb = *reinterpret_cast<const f32x4*>(base + ((long long)yb * W + xb) * ldi);
+    _Float16* oplane = out + ((b * nc + c) * Ho) * (long long)Wo * 16 + g * 4;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) hv[k] = (_Float16)v[k];
-    *reinterpret_cast<f16x4_t*>(out + i * 4) = hv;
+    for (int dy = 0; dy < 2; ++dy) {
+      const int Y = 2 * q - 1 + dy;
+      if (Y < 0 || Y >= Ho) continue;
+      const float ly = dy ? 0.75f : 0.25f;            // odd output rows sit 1/4 past source row q-1, even ones 3/4
+#pragma unroll
+      for (int dx = 0; dx < 2; ++dx) {
+        const int X = 2 * p - 1 + dx;
+        if (X < 0 || X >= Wo) continue;
+        const float lx = dx ? 0.75f : 0.25f;
+        const f32x4 v = (1.f - ly) * ((1.f - lx) * vaa + lx * vab) + ly * ((1.f - lx) * vba + lx * vbb);
+        f16x4_t hv;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) hv[k] = (_Float16)v[k];
+        *reinterpret_cast<f16x4_t*>(oplane + ((long long)Y * Wo + X) * 16) = hv;
+      }
+    }
   }
 }
 
@@ -405,7 +415,7 @@ extern "C" int cdfo_resample2(const float* in, int ldi, int B, int H, int W, int
   if (!aligned16(in) || !aligned16(out)) return CDFO_EALIGN;
   CdfoProfScope prof(static_cast<hipStream_t>(stream), KID_RESAMPLE, 0, 4.0*C*(double)B*H*W*(up?5.0:1.25));
   if (out_f16 == 2)
-    hipLaunchKernelGGL(up2_cp16_kernel, dim3(grid_for((long long)B * H * W * C)), dim3(256), 0,
+    hipLaunchKernelGGL(up2_cp16_kernel, dim3(grid_for((long long)B * (H + 1) * (W + 1) * (C / 4))), dim3(256), 0,
                        static_cast<hipStream_t>(stream), in, ldi, B, H, W, C, reinterpret_cast<_Float16*>(out));
   else if (up)
     hipLaunchKernelGGL(up2_kernel, dim3(grid_for((long long)B * H * W * C)), dim3(256), 0,

@@ -303,9 +303,10 @@ class CVSR_V8(nn.Module):
         r = self._conv(o, w[a + "ResidualBlock1.conv1"], pad=1, act=K.ACT_RELU)
         return self._conv(r, w[a + "ResidualBlock1.conv2"], pad=1, res1=o, res2=xc, out=out)
 
-    def _block(self, w, p, x):
+    def _block(self, w, p, x, x16=None, want16=False):
         """Block_ (arch.py:378-406): x + body(x) + up(body(down(x))) + down(body(up(x))).
-        The 1x1 convs commute with the (linear) resampling, so they run on the smaller side of it."""
+        The 1x1 convs commute with the (linear) resampling, so they run on the smaller side of it.
+        x16: optional fp16 chunk-planar copy of x; want16: also return such a copy of the result (fp16x2 mode)."""
         b0, b2, dn, up = w[p + "body.0"], w[p + "body.2"], w[p + "down.0"], w[p + "up.0"]
         # fp16x2 mode: the 256-channel body intermediate is stored as fp16 (rounding it does not move the forward's
         # error: 2.76e-4 with and without, oracle emulation) -> half the HBM bytes between the two convs, body.2 becomes
@@ -316,12 +317,16 @@ class CVSR_V8(nn.Module):
             # kernel; the 64- and 256-channel tensors between them are fp16 chunk-planar [B,C/16,H,W,16].  Same
             # arithmetic as the single-pass fp16 mode of the tiled kernel: fp16 operands, fp32 accumulation
             c1 = lambda src, **kw: K.conv3x3_ws(src, b0, act=K.ACT_LRELU, **kw)
-            out = K.conv_ring(c1(K.to_cp16(x)), b2, res1=x)
+            if x16 is None:
+                x16 = K.to_cp16(x)
+            out = K.conv_ring(c1(x16), b2, res1=x)
             d = self._conv(K.resample2(x, up=False), dn)
             d = K.conv_ring(c1(K.to_cp16(d)), b2)
             K.resample2(self._conv(d, up), up=True, out=out, accumulate=True)
             t = c1(K.resample2(self._conv(x, up), up=True, cp16=True), s2d=True)
-            return K.conv_ring(t, w[p + "down_fused"], res1=out)
+            y16 = torch.empty_like(x16) if want16 else None
+            y = K.conv_ring(t, w[p + "down_fused"], res1=out, out2_cp16=y16)
+            return (y, y16) if want16 else y
         out = self._conv(self._conv(x, b0, pad=1, act=K.ACT_LRELU, out_f16=t16, inner=True), b2, pad=1, res1=x)
         # half-resolution branch
         d = self._conv(K.resample2(x, up=False), dn)
@@ -331,14 +336,16 @@ class CVSR_V8(nn.Module):
         # composed sparse-tap convolution at the block's own resolution (see _weights)
         u = K.resample2(self._conv(x, up), up=True, out_f16=t16)     # fp16 in fp16x2 mode: conv1 stages it by plain copy
         t = self._conv(u, b0, pad=1, act=K.ACT_LRELU, s2d=True, out_f16=t16, inner=True)
-        return self._conv(t, w[p + "down_fused"], pad=1, res1=out)
+        y = self._conv(t, w[p + "down_fused"], pad=1, res1=out)
+        return (y, None) if want16 else y
 
     def _trunk(self, w, fused):
         y = fused
         for g in range(7):
-            r = y
-            for b in range(3):
-                r = self._block(w, f"recon_trunk.body.{g}.body.{b}.", r)
+            r, r16 = y, None
+            for b in range(3):      # blocks 0 and 1 hand their successor an fp16 chunk-planar copy of the result
+                r, r16 = self._block(w, f"recon_trunk.body.{g}.body.{b}.", r, r16, want16=True) if b < 2 else \
+                    (self._block(w, f"recon_trunk.body.{g}.body.{b}.", r, r16), None)
             y = self._conv(r, w[f"recon_trunk.body.{g}.conv"], pad=1, res1=y, res2=fused if g == 6 else None)
         return y
 

@@ -251,7 +251,7 @@ def sparse_taps_f16(pc: PackedConv) -> torch.Tensor:
 
 def conv_ring(src: torch.Tensor, pc: PackedConv, *, act: int = ACT_NONE, res1: Optional[torch.Tensor] = None,
               res2: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None,
-              out_f16: bool = False, dbg: int = 0) -> torch.Tensor:
+              out_f16: bool = False, out2_cp16: Optional[torch.Tensor] = None, dbg: int = 0) -> torch.Tensor:
     """3x3/s1/p1 convolution of an fp16 chunk-planar source [B,Cin/16,H,W,16] on the LDS-DMA ring kernel
     (Block_.body[2] and the composed stride-2 convolution).  Result: pixel-major fp32 (or fp16) [B,H,W,Cout]."""
     if not src.is_cuda:
@@ -286,6 +286,11 @@ def conv_ring(src: torch.Tensor, pc: PackedConv, *, act: int = ACT_NONE, res1: O
                 raise ValueError(f"{nm} shape {tuple(r.shape)} does not match the conv output")
             setattr(a, nm, r.data_ptr())
             setattr(a, "ldr" + nm[-1], rld)
+    if out2_cp16 is not None:       # second, fp16 chunk-planar copy of the result (the next Block_'s body[0] source)
+        if (out2_cp16.dtype != torch.float16 or tuple(out2_cp16.shape) != (B, pc.Cout // 16, H, W, 16)
+                or not out2_cp16.is_contiguous()):
+            raise ValueError("conv_ring: out2_cp16 must be a contiguous fp16 [B,Cout/16,H,W,16] tensor")
+        a.out2_cp16 = out2_cp16.data_ptr()
     check(_lib.lib().cdfo_conv3x3_ring(C.byref(a), _stream()), "cdfo_conv3x3_ring")
     return out
 

@@ -53,6 +53,8 @@ typedef struct {
   const unsigned* tap_mask;   /* optional, cdfo_conv3x3_bf16 only: per 16-channel chunk, bit t set = tap t has non-zero weights */
   int src_f16;                /* cdfo_conv3x3_bf16 only: the single source is an fp16 tensor (ld in halves); implies CDFO_PREC_FP16 */
   int out_f16;                /* cdfo_conv3x3_bf16 only: store the result as fp16 (ldo in halves); no residual inputs */
+  void* out2_cp16;            /* optional, cdfo_conv3x3_ring only: second copy of the result as an fp16 chunk-planar tensor
+                                 [B][Cout/16][H][W][16] (the next Block_'s body[0] source), Cout % 16 == 0 */
 } cdfo_conv_args;
 int cdfo_conv_igemm(const cdfo_conv_args* a, void* stream);
 

@@ -321,3 +321,31 @@ def test_conv3x3_ring_sparse_taps():
     out = K.conv_ring(K.to_cp16(_nhwc(x).cuda()), pc)
     torch.cuda.synchronize()
     _cmp(out, ref, 1e-4, "ring conv, sparse taps")
+
+
+@pytest.mark.parametrize("B,H,W,C", [(2, 9, 13, 64), (1, 16, 32, 32)])
+def test_resample2_chunk_planar_fp16(B, H, W, C):
+    """bilinear x2 written as the fp16 chunk-planar tensor vs F.interpolate (align_corners=False)."""
+    from cdfo_amd import kernels as K
+    g = torch.Generator().manual_seed(B + H + W)
+    x = torch.randn(B, C, H, W, generator=g)
+    ref = F.interpolate(x, scale_factor=2, mode="bilinear", align_corners=False)
+    out = K.resample2(_nhwc(x).cuda(), up=True, cp16=True)
+    torch.cuda.synchronize()
+    assert tuple(out.shape) == (B, C // 16, 2 * H, 2 * W, 16)
+    _cmp(K.from_cp16(out).float(), ref, 1e-3, "up2 -> cp16")
+
+
+def test_conv3x3_ring_second_output_chunk_planar():
+    """out2_cp16 of the ring kernel is the fp16 rounding of its fp32 result, in chunk-planar layout."""
+    from cdfo_amd import kernels as K
+    g = torch.Generator().manual_seed(3)
+    B, H, W, Cin, Cout = 2, 20, 36, 64, 64
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / 24.0
+    pc = K.pack_conv(w.cuda(), torch.randn(Cout, generator=g).cuda())
+    res = torch.randn(B, H, W, Cout, generator=g).cuda()
+    o16 = torch.zeros(B, Cout // 16, H, W, 16, dtype=torch.float16, device="cuda")
+    out = K.conv_ring(K.to_cp16(_nhwc(x).cuda()), pc, res1=res, out2_cp16=o16)
+    torch.cuda.synchronize()
+    assert torch.equal(K.from_cp16(o16), out.half())

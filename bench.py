@@ -27,10 +27,13 @@ sys.path.insert(0, ROOT)
 EXACT_FLOPS = {(272, 480): 9_753_744_609_072, (120, 240): 2_134_302_625_536, (64, 64): 302_119_013_712,
                (544, 960): 39_617_571_644_688}
 PEAK_TFLOPS = {"f32": 157.3, "bf16x3": 2500.0, "bf16": 2500.0, "fp16x2": 2500.0}   # /opt/skills/guides/MI355X_MICROARCH.md dense MFMA peaks
-MFMA_PASSES = {"f32": 1, "bf16x3": 3, "bf16": 1, "fp16x2": 1}   # fp16x2: 1 inside Block_ (95 % of the FLOPs), 2 elsewhere                    # bf16 MFMA MACs issued per algorithmic MAC
+MFMA_PASSES = {"f32": 1, "bf16x3": 3, "bf16": 1, "fp16x2": 2}   # tiled kernel; the Block_ kernels (ws, ring) are 1-pass fp16                    # bf16 MFMA MACs issued per algorithmic MAC
 KID_NAMES = ["conv3x3_wide", "conv3x3_narrow", "conv1x1", "conv3x3_s2", "stem", "layernorm", "dwconv", "flow_warp",
              "resample", "scale", "conv_last", "small_conv", "spatial_gate", "chan_sum", "gram", "fold", "rdab_prep",
-             "colconv9", "attn_row", "attn_col", "attn_win", "layout", "pack", "dcn"]
+             "colconv9", "attn_row", "attn_col", "attn_win", "layout", "pack", "dcn", "conv3x3_ws", "conv3x3_ring"]
+# kernel families on the 16-bit matrix cores -> (kernel symbol in the rocprofv3 stats, MFMA passes per algorithmic MAC)
+MFMA16 = {"conv3x3_wide": ("conv3x3_mma16_kernel", None),   # None: the --precision mode's passes (fp16x2: 2, or 3 for the feature cache) "conv3x3_ws": ("conv3x3_c64_ws_kernel", 1),
+          "conv3x3_ring": ("conv3x3_ring_kernel", 1)}
 
 
 def flops_per_clip(H, W):
@@ -140,8 +143,21 @@ def main():
         dom = max(range(nk), key=lambda k: ms[k])
         dom_avg_ms = ms[dom] / max(1, launches[dom])
         achieved = (fl[dom] / max(1, launches[dom])) / (dom_avg_ms * 1e-3) / 1e12 if dom_avg_ms > 0 else 0.0
-        peak = PEAK_TFLOPS[args.precision] if KID_NAMES[dom].startswith("conv3x3_wide") else PEAK_TFLOPS["f32"]
-        passes = MFMA_PASSES[args.precision] if KID_NAMES[dom].startswith("conv3x3_wide") else 1
+        def fam(k):
+            name = KID_NAMES[k]
+            avg_ms = ms[k] / max(1, launches[k])
+            ach = (fl[k] / max(1, launches[k])) / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
+            if name in MFMA16:
+                symbol, passes = MFMA16[name]
+                peak = PEAK_TFLOPS[args.precision if passes is None else "fp16x2"]
+                passes = MFMA_PASSES[args.precision] if passes is None else passes
+            else:
+                symbol, passes, peak = name, 1, PEAK_TFLOPS["f32"]
+            return {"kernel": name, "kernel_symbol": symbol, "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
+                    "frac": round(ach / peak, 4), "mfma_passes_per_mac": passes,
+                    "algorithmic_flop_per_launch": round(fl[k] / max(1, launches[k]), 0),
+                    "launches_per_step": launches[k] // max(1, args.steps), "avg_launch_ms": round(avg_ms, 4),
+                    "share_of_gpu_time": round(ms[k] / max(1e-9, sum(ms)), 4)}
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic_r01.json")
         if os.path.exists(tpath):            # HBM bytes per launch from rocprofv3 PMC passes (tools/collect_traffic.py)
@@ -151,13 +167,10 @@ def main():
                     traffic = tj.get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
-        roofline = {"bound": "mfma", "kernel": KID_NAMES[dom], "achieved": round(achieved, 2), "peak": peak,
-                    "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": traffic,
-                    "mfma_passes_per_mac": passes, "mfma_issue_frac": round(passes * achieved / peak, 4),
-                    "algorithmic_flop_per_launch": round(fl[dom] / max(1, launches[dom]), 0),
-                    "launches_per_step": launches[dom] // max(1, args.steps), "avg_launch_ms": round(dom_avg_ms, 4),
-                    "share_of_gpu_time": round(ms[dom] / max(1e-9, sum(ms)), 4),
-                    "whole_forward_tflops": round(F * B * args.steps / t_max / 1e12, 2)}
+        roofline = {"bound": "mfma", **fam(dom), "traffic": traffic,
+                    "whole_forward_tflops": round(F * B * args.steps / t_max / 1e12, 2),
+                    # the other matrix-core convolution kernels of the step, same definitions (not the headline entry)
+                    "other_mfma_kernels": [fam(k) for k in range(nk) if KID_NAMES[k] in MFMA16 and k != dom and launches[k]]}
         cpu = None
         if not args.no_cpu_baseline:
             cpu = cpu_baseline(sd, Hp, Wp)

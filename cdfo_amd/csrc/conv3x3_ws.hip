@@ -343,7 +343,7 @@ extern "C" int cdfo_conv3x3_c64_ws(const void* src_cp16, int B, int H, int W, co
   a.bias = bias; a.Cout = Cout; a.act = act;
   a.out = static_cast<_Float16*>(out_cp16); a.s2d = store_mode == CDFO_STORE_S2D;
   const double px = (double)B * H * W;
-  CdfoProfScope prof(st, KID_CONV3_WIDE, 2.0 * px * Cout * 64 * 9, 2.0 * (px * Cout + px * 64) + 2.0 * 9 * 64 * Cout);
+  CdfoProfScope prof(st, KID_CONV3_WS, 2.0 * px * Cout * 64 * 9, 2.0 * (px * Cout + px * 64) + 2.0 * 9 * 64 * Cout);
   int rc;
   switch (dbg) {
     case 0: rc = ws_launch<0>(a, grid, st); break;

@@ -205,67 +205,110 @@ __global__ __launch_bounds__(64) void seq_attn_kernel(const float* __restrict__ 
 
 
 // ---------------------------------------------------------------------------------------------------------------
-// Row / column attention on the fp32 matrix cores (exact fp32, v_mfma_f32_32x32x2_f32), flash style.
+// Row / column attention on the matrix cores, flash style.
 // One wave owns 32 queries; 4 waves (128 queries of ONE sequence) share the key/value tiles staged in LDS.
-//   S^T[key][query] = K Q^T : A = K (rows = keys), B = Q^T.  Lane (r, h) keeps Q[r][32h .. 32h+31] in registers and reads
-//                     K[r][32h .. 32h+31] from LDS (the k order inside the dot product is free, so each lane takes a
-//                     contiguous half row: 8 ds_read_b128, conflict-free at the 272-byte row pitch).
+//   S^T[key][query] = K Q^T : A = K (rows = keys), B = Q^T, on the fp16 matrix cores with BOTH operands split into
+//                     fp16 hi + fp16 lo (22 significant bits; hi*hi + lo*hi + hi*lo, the 2^-22 lo*lo term dropped):
+//                     12 v_mfma_f32_32x32x16_f16 (384 cycles) per 32x32 tile instead of 32 v_mfma_f32_32x32x2_f32
+//                     (2048 cycles), scores exact to ~1e-6 relative.  Lane (r, h) keeps Q[r][16s + 8h .. +7] (s = 0..3)
+//                     in registers and reads the same channels of K[r] from LDS (hi | lo halves of a 272-byte row).
 //   softmax          : the accumulator holds, per lane, 16 keys of ITS query (column) -> the running max needs one
 //                     cross-half shuffle, the exponentials are lane-local.
-//   O^T[ch][query]  += V^T P^T : the probabilities are already the B operand (register e of half h is key
-//                     (e&3)+8(e>>2)+4h of query r): no data movement between the two products; A = V[that key][ch].
-template <int MODE>   // 0: sequence = image row, 1: image column
+//   O^T[ch][query]  += V^T P^T, also fp16 hi/lo x 3 passes: the probabilities are already the B operand -- register
+//                     8u + j of half h is key 16u + 4h + 8(j>>2) + (j&3) of query r, and the key order inside a dot
+//                     product is free, so V is staged TRANSPOSED ([channel][key slot], slot = 16u + 8h + j) in that
+//                     same order: a staging thread loads 4 keys x 4 channels, transposes 4x4 in registers and writes
+//                     8-byte runs of 4 keys; no data movement between the two products.
+typedef _Float16 attn_f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 attn_f16x4 __attribute__((ext_vector_type(4)));
+
+template <int MODE>   // 0: sequence = image row, 1: image column, 2: 8x8 window (64 pixels, row-major inside the window)
 __global__ __launch_bounds__(256) void seq_attn_mfma_kernel(const float* __restrict__ q, int ldq,
                                                             const float* __restrict__ v, int ldv,
                                                             float* __restrict__ out, int ldo, int B, int H, int W) {
-  constexpr int KS_ = 68;                                   // floats per staged key row (272 B)
-  __shared__ __attribute__((aligned(16))) float sK[2][32 * KS_];
-  __shared__ __attribute__((aligned(16))) float sV[2][32 * 64];
+  constexpr int KROW = 272;                                 // bytes per staged key row: 128 B hi | 128 B lo | 16 B pad
+  __shared__ __attribute__((aligned(16))) unsigned char sK[2][32 * KROW];
+  // V^T: row = channel (128 B: four 16-byte hi slots 2u+h, four lo slots 4+2u+h), slot index XORed with (ch>>1)&7 so
+  // that the 16 channels of a ds_read_b128 lane group hit 16 distinct 16-byte slots
+  __shared__ __attribute__((aligned(16))) unsigned char sV[2][64 * 128];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, h = lane >> 5, r = lane & 31;
-  const int L = MODE == 0 ? W : H;
+  const int L = MODE == 0 ? W : (MODE == 1 ? H : 64);
   const int nb = (L + 127) / 128;
   const int blk = blockIdx.x % nb;
   const long long seq = blockIdx.x / nb;
-  long long kbase, kstep;
-  if (MODE == 0) { kbase = seq * W; kstep = 1; }            // seq = b*H + y
-  else { const long long b = seq / W, x = seq - b * W; kbase = b * H * W + x; kstep = W; }
+  long long kbase;
+  if (MODE == 0) kbase = seq * W;                           // seq = b*H + y
+  else if (MODE == 1) { const long long b = seq / W, x = seq - b * W; kbase = b * H * W + x; }
+  else {                                                    // seq = (b*(H/8) + wy)*(W/8) + wx
+    const int wpr = W >> 3;
+    const long long t = seq / wpr;
+    const int wx = (int)(seq - t * wpr);
+    kbase = (t * 8) * W + wx * 8;                           // t*8 = b*H + wy*8
+  }
+  auto pix_of = [&](int i) -> long long {                   // pixel of element i of the sequence
+    return MODE == 0 ? kbase + i : (MODE == 1 ? kbase + (long long)i * W : kbase + (long long)(i >> 3) * W + (i & 7));
+  };
   const int q0 = blk * 128 + wave * 32;                     // this wave's first query
   const bool wave_active = q0 < L;
   int qi = q0 + r;
   const bool q_ok = qi < L;
   if (!q_ok) qi = L - 1;
-  const long long qpix = kbase + (long long)qi * kstep;
+  const long long qpix = pix_of(qi);
 
-  float qr[32];
+  attn_f16x8 qh[4], ql[4];                                  // Q[r][16s + 8h + j], fp16 hi / lo
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const f32x4 t = *reinterpret_cast<const f32x4*>(q + qpix * ldq + 32 * h + 4 * i);
+  for (int s = 0; s < 4; ++s) {
+    const f32x4 t0 = *reinterpret_cast<const f32x4*>(q + qpix * ldq + 16 * s + 8 * h);
+    const f32x4 t1 = *reinterpret_cast<const f32x4*>(q + qpix * ldq + 16 * s + 8 * h + 4);
 #pragma unroll
-    for (int e = 0; e < 4; ++e) qr[4 * i + e] = t[e];
+    for (int e = 0; e < 4; ++e) {
+      qh[s][e] = (_Float16)t0[e];      ql[s][e] = (_Float16)(t0[e] - (float)qh[s][e]);
+      qh[s][4 + e] = (_Float16)t1[e];  ql[s][4 + e] = (_Float16)(t1[e] - (float)qh[s][4 + e]);
+    }
   }
   f32x16 o0, o1;
 #pragma unroll
   for (int e = 0; e < 16; ++e) { o0[e] = 0.f; o1[e] = 0.f; }
   float m = -INFINITY, l = 0.f;
 
-  // staging: 32 keys x 16 float4 per tensor = 512 float4 -> 2 per thread per tensor
-  const int skey = tid >> 4, sc4 = tid & 15;
-  f32x4 rk[2], rv[2];
+  // staging (4 float4 loads per thread): threads 0-127 take V -- keys 4m..4m+3 x channels 4c..4c+3 each --, threads
+  // 128-255 take K -- keys kk + 8s (s = 0..3) x channels 4c..4c+3
+  const bool st_v = tid < 128;
+  const int sm = (tid >> 4) & 7, sc4 = tid & 15;
+  f32x4 rs[4];
   auto load_tile = [&](int t0) {
 #pragma unroll
-    for (int s = 0; s < 2; ++s) {
-      int key = t0 + skey + 16 * s;
+    for (int s = 0; s < 4; ++s) {
+      int key = t0 + (st_v ? 4 * sm + s : sm + 8 * s);
       key = key < L ? key : L - 1;                          // clamped (masked below), always loaded
-      const long long kp = kbase + (long long)key * kstep;
-      rk[s] = *reinterpret_cast<const f32x4*>(q + kp * ldq + sc4 * 4);
-      rv[s] = *reinterpret_cast<const f32x4*>(v + kp * ldv + sc4 * 4);
+      const long long kp = pix_of(key);
+      rs[s] = *reinterpret_cast<const f32x4*>((st_v ? v + kp * ldv : q + kp * ldq) + sc4 * 4);
     }
   };
   auto write_tile = [&](int buf) {
+    if (st_v) {
+      // keys 4m..4m+3 = slots 16u + 8hh + 4g + (0..3) with u = m>>2, hh = m&1, g = (m&3)>>1
+      const int c = 2 * (sm >> 2) + (sm & 1), g = (sm & 3) >> 1;
 #pragma unroll
-    for (int s = 0; s < 2; ++s) {
-      *reinterpret_cast<f32x4*>(&sK[buf][(skey + 16 * s) * KS_ + sc4 * 4]) = rk[s];
-      *reinterpret_cast<f32x4*>(&sV[buf][(skey + 16 * s) * 64 + sc4 * 4]) = rv[s];
+      for (int e = 0; e < 4; ++e) {
+        const int ch = 4 * sc4 + e, swz = (ch >> 1) & 7;
+        attn_f16x4 vh, vl;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { vh[k] = (_Float16)rs[k][e]; vl[k] = (_Float16)(rs[k][e] - (float)vh[k]); }
+        unsigned char* row = &sV[buf][ch * 128 + g * 8];
+        *reinterpret_cast<attn_f16x4*>(row + ((c ^ swz) * 16)) = vh;
+        *reinterpret_cast<attn_f16x4*>(row + (((4 + c) ^ swz) * 16)) = vl;
+      }
+    } else {
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        attn_f16x4 kh, kl;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { kh[e] = (_Float16)rs[s][e]; kl[e] = (_Float16)(rs[s][e] - (float)kh[e]); }
+        unsigned char* row = &sK[buf][(sm + 8 * s) * KROW + sc4 * 8];
+        *reinterpret_cast<attn_f16x4*>(row) = kh;
+        *reinterpret_cast<attn_f16x4*>(row + 128) = kl;
+      }
     }
   };
 
@@ -282,10 +325,13 @@ __global__ __launch_bounds__(256) void seq_attn_mfma_kernel(const float* __restr
 #pragma unroll
       for (int e = 0; e < 16; ++e) sacc[e] = 0.f;
 #pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const f32x4 kf = *reinterpret_cast<const f32x4*>(&sK[buf][r * KS_ + 32 * h + 4 * i]);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[e], qr[4 * i + e], sacc, 0, 0, 0);
+      for (int s = 0; s < 4; ++s) {
+        const unsigned char* row = &sK[buf][r * KROW + (16 * s + 8 * h) * 2];
+        const attn_f16x8 kh = *reinterpret_cast<const attn_f16x8*>(row);
+        const attn_f16x8 kl = *reinterpret_cast<const attn_f16x8*>(row + 128);
+        sacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl, qh[s], sacc, 0, 0, 0);
+        sacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, ql[s], sacc, 0, 0, 0);
+        sacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, qh[s], sacc, 0, 0, 0);
       }
       // ---- online softmax over this tile's 32 keys (16 here, 16 in the partner half-wave)
       const int kv_left = L - t * 32;                       // keys beyond L are masked
@@ -308,11 +354,20 @@ __global__ __launch_bounds__(256) void seq_attn_mfma_kernel(const float* __restr
       for (int e = 0; e < 16; ++e) { o0[e] *= alpha; o1[e] *= alpha; }
       // ---- O^T += V^T P^T
 #pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int key = (e & 3) + 8 * (e >> 2) + 4 * h;
-        const float v0 = sV[buf][key * 64 + r], v1 = sV[buf][key * 64 + 32 + r];
-        o0 = __builtin_amdgcn_mfma_f32_32x32x2f32(v0, sacc[e], o0, 0, 0, 0);
-        o1 = __builtin_amdgcn_mfma_f32_32x32x2f32(v1, sacc[e], o1, 0, 0, 0);
+      for (int u = 0; u < 2; ++u) {
+        attn_f16x8 ph, pl;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { ph[j] = (_Float16)sacc[8 * u + j]; pl[j] = (_Float16)(sacc[8 * u + j] - (float)ph[j]); }
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {              // channels 0-31 -> o0, 32-63 -> o1
+          const int ch = 32 * half + r, swz = (ch >> 1) & 7, c = 2 * u + h;
+          const attn_f16x8 vh = *reinterpret_cast<const attn_f16x8*>(&sV[buf][ch * 128 + ((c ^ swz) * 16)]);
+          const attn_f16x8 vl = *reinterpret_cast<const attn_f16x8*>(&sV[buf][ch * 128 + (((4 + c) ^ swz) * 16)]);
+          f32x16& o = half ? o1 : o0;
+          o = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl, ph, o, 0, 0, 0);
+          o = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, pl, o, 0, 0, 0);
+          o = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, ph, o, 0, 0, 0);
+        }
       }
     }
     if (t + 1 < ntiles) write_tile(buf ^ 1);
@@ -381,6 +436,10 @@ extern "C" int cdfo_seq_attn(const float* q, int ldq, const float* v, int ldv, f
     hipLaunchKernelGGL(seq_attn_kernel<1>, dim3((unsigned)((long long)B * W * cdiv(H, 64))), dim3(64), 0, st, q, ldq, v,
                        ldv, out, ldo, B, H, W);
   } else if (mode == 2) {
+    if ((H & 7) || (W & 7)) return CDFO_EINVAL;
+    hipLaunchKernelGGL(seq_attn_mfma_kernel<2>, dim3((unsigned)((long long)B * (H / 8) * (W / 8))), dim3(256), 0, st, q,
+                       ldq, v, ldv, out, ldo, B, H, W);
+  } else if (mode == 12) {   // VALU reference form of mode 2
     if ((H & 7) || (W & 7)) return CDFO_EINVAL;
     hipLaunchKernelGGL(seq_attn_kernel<2>, dim3((unsigned)((long long)B * (H / 8) * (W / 8))), dim3(64), 0, st, q, ldq, v,
                        ldv, out, ldo, B, H, W);

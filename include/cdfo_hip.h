@@ -159,7 +159,9 @@ int cdfo_rdab_prep(const float* xq, int ldx, const float* vmax, const float* noi
                    int B, long long P, float* sq, int lds_, float* vrow, int ldv, float* qwin, int ldw, void* stream);
 int cdfo_colconv9(const float* in, int ldi, const float* wH, const float* bH, int B, int H, int W, float* out, int ldo,
                   void* stream);
-/* out = softmax(Q Q^T) V per row (mode 0), column (1) or 8x8 window (2). */
+/* out = softmax(Q Q^T) V per row (mode 0), column (1) or 8x8 window (2) (arch.py:2179-2249), flash style on the matrix
+ * cores: both products with fp16 hi + fp16 lo operands, three passes, fp32 accumulate (scores exact to ~1e-6 relative).
+ * Modes 10 / 11 / 12: the plain-VALU forms of 0 / 1 / 2 (kept as A/B references for the tests). */
 int cdfo_seq_attn(const float* q, int ldq, const float* v, int ldv, float* out, int ldo, int B, int H, int W, int mode,
                   void* stream);
 

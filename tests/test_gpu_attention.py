@@ -22,7 +22,7 @@ def _ref(q, v, mode):
 
 
 @pytest.mark.parametrize("H,W", [(8, 8), (16, 40), (40, 136), (136, 72)])
-@pytest.mark.parametrize("mode", [0, 1, 2, 10, 11])
+@pytest.mark.parametrize("mode", [0, 1, 2, 10, 11, 12])
 def test_seq_attn(H, W, mode):
     from cdfo_amd import kernels as K
     g = torch.Generator().manual_seed(H * 100 + W + mode)

@@ -216,6 +216,8 @@ class CVSR_V8(nn.Module):
                 fused = K.pack_conv(wf, wdn @ b2 + bdn)
                 fused.tap_mask = tap_mask
                 w[bp + "down_fused"] = fused
+        fe = "transformer_feature_extraction.path1."
+        w[fe + "qkv_dw"] = K.pack_qkv_dw(sd[fe + "attn.qkv.weight"], sd[fe + "norm1.body.weight"], sd[fe + "norm1.body.bias"])
         pc("upconv1", shuffle2=True)
         pc("upconv2", shuffle2=True)
         w["raw"] = {k: v.contiguous() for k, v in sd.items()}
@@ -254,8 +256,11 @@ class CVSR_V8(nn.Module):
         p = "transformer_feature_extraction.path1."
         for rnd in range(3):
             x2 = self._udsa(w, x2, x1 if rnd == 0 else x2)
-            qkv = self._conv(x1, w[p + "attn.qkv"], ln=(raw[p + "norm1.body.weight"], raw[p + "norm1.body.bias"]))
-            qkv = K.dwconv3x3(qkv, raw[p + "attn.qkv_dwconv.weight"])
+            if self.precision == "f32":
+                qkv = self._conv(x1, w[p + "attn.qkv"], ln=(raw[p + "norm1.body.weight"], raw[p + "norm1.body.bias"]))
+                qkv = K.dwconv3x3(qkv, raw[p + "attn.qkv_dwconv.weight"])
+            else:   # LayerNorm + qkv + depthwise 3x3 in one pass (split-bf16 MFMA, fp32-grade)
+                qkv = K.qkv_dw(x1, w[p + "qkv_dw"], raw[p + "attn.qkv_dwconv.weight"])
             part, n = K.gram_partial(qkv[..., 0:64], qkv[..., 64:128], 8)
             fold = K.mdta_fold(part, n, raw[p + "attn.temperature"], raw[p + "attn.project_out.weight"])
             x1 = self._conv(qkv[..., 128:192], fold, res1=x1)

@@ -331,6 +331,26 @@ def layernorm64(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor) -> tor
     return out
 
 
+def pack_qkv_dw(w_qkv: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor):
+    """LayerNorm's affine folded into the 1x1 qkv weights: (split-bf16 packing [hi|lo][4][2][192][8], bias W @ beta)."""
+    w = w_qkv.detach().float().reshape(192, 64)
+    wg = w * gamma.detach().float()[None, :]
+    hi = wg.bfloat16()
+    lo = (wg - hi.float()).bfloat16()
+    pack = lambda t: t.view(192, 4, 2, 8).permute(1, 2, 0, 3).contiguous().view(-1)
+    return torch.cat([pack(hi), pack(lo)]).contiguous(), (w @ beta.detach().float()).contiguous()
+
+
+def qkv_dw(x: torch.Tensor, packed, dw_w: torch.Tensor, eps: float = 1e-5) -> torch.Tensor:
+    """depthwise3x3(conv1x1_64->192(LayerNorm64(x))) in one kernel; packed = pack_qkv_dw(...)."""
+    B, H, W, Cc, ld = _chk_act(x)
+    assert Cc == 64
+    out = empty_act(B, H, W, 192, x.device)
+    check(_lib.lib().cdfo_qkv_dw(_vp(x), ld, B, H, W, _vp(packed[0]), _vp(packed[1]), _vp(dw_w), C.c_float(eps), _vp(out),
+                                 192, _stream()), "cdfo_qkv_dw")
+    return out
+
+
 def dwconv3x3(x: torch.Tensor, w: torch.Tensor) -> torch.Tensor:
     B, H, W, Cc, ld = _chk_act(x)
     out = empty_act(B, H, W, Cc, x.device)

@@ -159,6 +159,11 @@ int cdfo_rdab_prep(const float* xq, int ldx, const float* vmax, const float* noi
                    int B, long long P, float* sq, int lds_, float* vrow, int ldv, float* qwin, int ldw, void* stream);
 int cdfo_colconv9(const float* in, int ldi, const float* wH, const float* bH, int B, int H, int W, float* out, int ldo,
                   void* stream);
+/* MDTA front end in one pass (arch.py:1169-1198 LayerNorm, :1551-1552 qkv + qkv_dwconv): out[B][H][W][192] =
+ * depthwise3x3(conv1x1(LayerNorm64(x))).  w_bf16: split-bf16 weights [hi|lo][4][2][192][8], element (s,h,n,j) =
+ * W[n][16s+8h+j] * gamma[16s+8h+j]; bias[192] = W @ beta (may be NULL); dw_w: raw [192][1][3][3] taps.  */
+int cdfo_qkv_dw(const float* x, int ldx, int B, int H, int W, const void* w_bf16, const float* bias, const float* dw_w,
+                float eps, float* out, int ldo, void* stream);
 /* out = softmax(Q Q^T) V per row (mode 0), column (1) or 8x8 window (2) (arch.py:2179-2249), flash style on the matrix
  * cores: both products with fp16 hi + fp16 lo operands, three passes, fp32 accumulate (scores exact to ~1e-6 relative).
  * Modes 10 / 11 / 12: the plain-VALU forms of 0 / 1 / 2 (kept as A/B references for the tests). */

@@ -46,3 +46,22 @@ def test_dwconv3x3(C, H, W):
     out = K.dwconv3x3(x.permute(0, 2, 3, 1).contiguous().cuda(), w.cuda())
     torch.cuda.synchronize()
     assert (out.permute(0, 3, 1, 2).cpu() - ref).abs().max().item() < 1e-5
+
+
+@pytest.mark.parametrize("B,H,W", [(2, 12, 30), (1, 17, 45), (3, 8, 64)])
+def test_qkv_dw_fused(B, H, W):
+    """LayerNorm -> 1x1 (64->192) -> depthwise 3x3 in one kernel vs the same chain in torch-cpu fp32."""
+    import torch.nn.functional as F
+    from cdfo_amd import kernels as K
+    g = torch.Generator().manual_seed(B * 1000 + H * 10 + W)
+    x = torch.randn(B, 64, H, W, generator=g) * 2 + 0.3
+    gamma, beta = torch.rand(64, generator=g) + 0.5, torch.randn(64, generator=g) * 0.1
+    wq = torch.randn(192, 64, 1, 1, generator=g) / 8.0
+    wd = torch.randn(192, 1, 3, 3, generator=g) / 3.0
+    ln = F.layer_norm(x.permute(0, 2, 3, 1), (64,), gamma, beta, 1e-5).permute(0, 3, 1, 2)
+    ref = F.conv2d(F.conv2d(ln, wq), wd, padding=1, groups=192)
+    packed = K.pack_qkv_dw(wq.cuda(), gamma.cuda(), beta.cuda())
+    out = K.qkv_dw(x.permute(0, 2, 3, 1).contiguous().cuda(), packed, wd.cuda().contiguous())
+    torch.cuda.synchronize()
+    err = (out.cpu().permute(0, 3, 1, 2) - ref).abs().max().item()
+    assert err < 2e-5 * max(1.0, ref.abs().max().item()), err

@@ -50,6 +50,7 @@ struct ws_args {
   const float* bias;
   int Cout, act;
   _Float16* out; int s2d;
+  unsigned long long* clk;      // developer probe (dbg 128): {shader-clock ticks, 100 MHz real-time ticks} of workgroup 0
 };
 
 // five 1 KiB LDS-DMA pieces: lane l of piece k writes LDS bytes lds + 1024 k + 16 l from (buffer base + voff[k] + soff)
@@ -81,6 +82,8 @@ __global__ __launch_bounds__(WS_THREADS) void conv3x3_c64_ws_kernel(ws_args a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, r = lane & 31;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  unsigned long long clk0 = 0, rt0 = 0;
+  if (DBG & 128) { clk0 = __builtin_readcyclecounter(); rt0 = __builtin_amdgcn_s_memrealtime(); }
   // workgroups are dealt round-robin over the 8 XCDs: the nco output-channel blocks of one pixel partition share an L2
   const int nco = a.Cout >> 6;
   const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
@@ -272,6 +275,10 @@ __global__ __launch_bounds__(WS_THREADS) void conv3x3_c64_ws_kernel(ws_args a) {
         }
     }
   }
+  if ((DBG & 128) && a.clk && blockIdx.x == 0 && tid == 0) {
+    a.clk[0] = __builtin_readcyclecounter() - clk0;
+    a.clk[1] = __builtin_amdgcn_s_memrealtime() - rt0;
+  }
 }
 
 int ws_num_cus() {
@@ -322,7 +329,7 @@ __global__ __launch_bounds__(256) void to_cp16_kernel(const float* __restrict__ 
 
 extern "C" int cdfo_conv3x3_c64_ws(const void* src_cp16, int B, int H, int W, const void* w_f16, int CoutP,
                                    const float* bias, int Cout, int act, void* out_cp16, int store_mode, int dbg,
-                                   void* stream) {
+                                   void* clk_probe, void* stream) {
   hipStream_t st = static_cast<hipStream_t>(stream);
   if (B <= 0 || H <= 0 || W <= 0 || (H & 1) || Cout <= 0 || Cout % 64 || CoutP < Cout || CoutP % 64) return CDFO_EINVAL;
   if (act == CDFO_ACT_SIGMOID || (store_mode != CDFO_STORE_PLAIN && store_mode != CDFO_STORE_S2D)) return CDFO_EINVAL;
@@ -342,6 +349,7 @@ extern "C" int cdfo_conv3x3_c64_ws(const void* src_cp16, int B, int H, int W, co
   a.w = static_cast<const unsigned short*>(w_f16); a.CoutP = CoutP;
   a.bias = bias; a.Cout = Cout; a.act = act;
   a.out = static_cast<_Float16*>(out_cp16); a.s2d = store_mode == CDFO_STORE_S2D;
+  a.clk = static_cast<unsigned long long*>(clk_probe);
   const double px = (double)B * H * W;
   CdfoProfScope prof(st, KID_CONV3_WS, 2.0 * px * Cout * 64 * 9, 2.0 * (px * Cout + px * 64) + 2.0 * 9 * 64 * Cout);
   int rc;
@@ -356,6 +364,8 @@ extern "C" int cdfo_conv3x3_c64_ws(const void* src_cp16, int B, int H, int W, co
     case 16: rc = ws_launch<16>(a, grid, st); break;
     case 64: rc = ws_launch<64>(a, grid, st); break;
     case 72: rc = ws_launch<72>(a, grid, st); break;
+    case 128: rc = ws_launch<128>(a, grid, st); break;
+    case 136: rc = ws_launch<136>(a, grid, st); break;
     default: return CDFO_EINVAL;
   }
   if (rc) return rc;

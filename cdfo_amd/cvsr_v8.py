@@ -216,6 +216,8 @@ class CVSR_V8(nn.Module):
                 fused = K.pack_conv(wf, wdn @ b2 + bdn)
                 fused.tap_mask = tap_mask
                 w[bp + "down_fused"] = fused
+                w[bp + "pro"] = K.pack_block_prologue(sd[bp + "up.0.weight"], sd[bp + "up.0.bias"],
+                                                      sd[bp + "down.0.weight"], sd[bp + "down.0.bias"])
         fe = "transformer_feature_extraction.path1."
         w[fe + "qkv_dw"] = K.pack_qkv_dw(sd[fe + "attn.qkv.weight"], sd[fe + "norm1.body.weight"], sd[fe + "norm1.body.bias"])
         pc("upconv1", shuffle2=True)
@@ -324,11 +326,11 @@ class CVSR_V8(nn.Module):
             c1 = lambda src, **kw: K.conv3x3_ws(src, b0, act=K.ACT_LRELU, **kw)
             if x16 is None:
                 x16 = K.to_cp16(x)
+            u16, d16 = K.block_prologue(x, w[p + "pro"])      # sources of the x2 and x1/2 branches, one read of x
             out = K.conv_ring(c1(x16), b2, res1=x)
-            d = self._conv(K.resample2(x, up=False), dn)
-            d = K.conv_ring(c1(K.to_cp16(d)), b2)
+            d = K.conv_ring(c1(d16), b2)
             K.resample2(self._conv(d, up), up=True, out=out, accumulate=True)
-            t = c1(K.resample2(self._conv(x, up), up=True, cp16=True), s2d=True)
+            t = c1(u16, s2d=True)
             y16 = torch.empty_like(x16) if want16 else None
             y = K.conv_ring(t, w[p + "down_fused"], res1=out, out2_cp16=y16)
             return (y, y16) if want16 else y

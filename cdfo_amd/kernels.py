@@ -206,7 +206,7 @@ def to_cp16(x: torch.Tensor) -> torch.Tensor:
 
 
 def conv3x3_ws(src: torch.Tensor, pc: PackedConv, *, act: int = ACT_NONE, s2d: bool = False,
-               out: Optional[torch.Tensor] = None, dbg: int = 0) -> torch.Tensor:
+               out: Optional[torch.Tensor] = None, dbg: int = 0, clk: Optional[torch.Tensor] = None) -> torch.Tensor:
     """Block_.body[0]-shaped convolution (3x3, 64 input channels, Cout % 64 == 0) on the weights-stationary kernel.
     src: fp16 chunk-planar [B,4,H,W,16]; result: fp16 chunk-planar [B,Cout/16,H,W,16], or with s2d its space-to-depth
     form [B,4*Cout/16,H/2,W/2,16] (chunk = phase*Cout/16 + channel/16, phase = (y&1)*2 + (x&1))."""
@@ -223,7 +223,7 @@ def conv3x3_ws(src: torch.Tensor, pc: PackedConv, *, act: int = ACT_NONE, s2d: b
     elif out.shape != shape or out.dtype != torch.float16 or not out.is_contiguous():
         raise ValueError(f"conv3x3_ws: out must be a contiguous fp16 tensor of shape {shape}")
     check(_lib.lib().cdfo_conv3x3_c64_ws(_vp(src), B, H, W, _vp(pc.wh), pc.CoutP16, _vp(pc.bias), pc.Cout, act, _vp(out),
-                                         2 if s2d else 0, dbg, _stream()), "cdfo_conv3x3_c64_ws")
+                                         2 if s2d else 0, dbg, _vp(clk), _stream()), "cdfo_conv3x3_c64_ws")
     return out
 
 
@@ -329,6 +329,26 @@ def layernorm64(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor) -> tor
     check(_lib.lib().cdfo_layernorm64(_vp(x), ld, _vp(gamma), _vp(beta), C.c_longlong(B * H * W), _vp(out), 64,
                                       _stream()), "cdfo_layernorm64")
     return out
+
+
+def pack_block_prologue(w_up: torch.Tensor, b_up: torch.Tensor, w_dn: torch.Tensor, b_dn: torch.Tensor):
+    """Split-bf16 packing [hi|lo][4][2][128][8] of Block_'s two 1x1 convs (rows 0-63 up.0, 64-127 down.0) + bias[128]."""
+    w = torch.cat([w_up.detach().float().reshape(64, 64), w_dn.detach().float().reshape(64, 64)], 0)
+    hi = w.bfloat16()
+    lo = (w - hi.float()).bfloat16()
+    pack = lambda t: t.view(128, 4, 2, 8).permute(1, 2, 0, 3).contiguous().view(-1)
+    return torch.cat([pack(hi), pack(lo)]).contiguous(), torch.cat([b_up.detach().float(), b_dn.detach().float()]).contiguous()
+
+
+def block_prologue(x: torch.Tensor, packed):
+    """(u16, d16): fp16 chunk-planar bilinear_x2(up.0(x)) [B,4,2H,2W,16] and down.0(mean2x2(x)) [B,4,H/2,W/2,16]."""
+    B, H, W, Cc, ld = _chk_act(x)
+    assert Cc == 64 and H % 2 == 0 and W % 2 == 0
+    u16 = torch.empty((B, 4, 2 * H, 2 * W, 16), dtype=torch.float16, device=x.device)
+    d16 = torch.empty((B, 4, H // 2, W // 2, 16), dtype=torch.float16, device=x.device)
+    check(_lib.lib().cdfo_block_prologue(_vp(x), ld, B, H, W, _vp(packed[0]), _vp(packed[1]), _vp(u16), _vp(d16),
+                                         _stream()), "cdfo_block_prologue")
+    return u16, d16
 
 
 def pack_qkv_dw(w_qkv: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor):

@@ -83,9 +83,10 @@ int cdfo_pack_conv3x3_f16(const float* w_oihw, void* packed, int Cout, int Cin, 
  * cdfo_resample2 with out_f16 = 2); w_f16/CoutP: cdfo_pack_conv3x3_f16 packing and its padded channel count;
  * out_cp16: fp16 chunk-planar [B][Cout/16][H][W][16] (CDFO_STORE_PLAIN) or its space-to-depth form
  * [B][4*Cout/16][H/2][W/2][16], chunk = ((y&1)*2+(x&1))*Cout/16 + channel/16 (CDFO_STORE_S2D).
- * H even, Cout % 64 == 0, the source smaller than 2 GiB.  dbg: 0 (developer ablation flags otherwise).  */
+ * H even, Cout % 64 == 0, the source smaller than 2 GiB.  dbg: 0 (developer ablation flags otherwise; with dbg 128
+ * clk_probe receives {shader-clock cycles, 100 MHz real-time ticks} of workgroup 0, else pass NULL).  */
 int cdfo_conv3x3_c64_ws(const void* src_cp16, int B, int H, int W, const void* w_f16, int CoutP, const float* bias,
-                        int Cout, int act, void* out_cp16, int store_mode, int dbg, void* stream);
+                        int Cout, int act, void* out_cp16, int store_mode, int dbg, void* clk_probe, void* stream);
 /* 3x3 / stride 1 / pad 1 convolution of an fp16 chunk-planar source (a->src[0] = [B][Cin/16][H][W][16], a->src_f16 = 1,
  * a->ld[0] = 16, a->cs[0] = Cin) as a persistent kernel fed by an LDS-DMA ring: Block_.body[2] (256 -> 64) and the
  * composed stride-2 convolution of Block_'s double-resolution branch.  a->w: fp16 [Cin/16][taps][2][CoutP][8] with
@@ -159,6 +160,12 @@ int cdfo_rdab_prep(const float* xq, int ldx, const float* vmax, const float* noi
                    int B, long long P, float* sq, int lds_, float* vrow, int ldv, float* qwin, int ldw, void* stream);
 int cdfo_colconv9(const float* in, int ldi, const float* wH, const float* bH, int B, int H, int W, float* out, int ldo,
                   void* stream);
+/* Block_ prologue (arch.py:378-406): from one read of the block input x [B][H][W][64] (H, W even) the fp16 chunk-planar
+ * sources of its two resampled branches: u16 [B][4][2H][2W][16] = bilinear_x2(up.0(x)) and d16 [B][4][H/2][W/2][16] =
+ * down.0(mean2x2(x)).  w_bf16: split-bf16 1x1 weights [hi|lo][4][2][128][8], rows 0-63 = up.0, 64-127 = down.0,
+ * element (s,h,n,j) = W[n][16s+8h+j]; bias128 = [up.0 bias | down.0 bias].  */
+int cdfo_block_prologue(const float* x, int ldx, int B, int H, int W, const void* w_bf16, const float* bias128, void* u16,
+                        void* d16, void* stream);
 /* MDTA front end in one pass (arch.py:1169-1198 LayerNorm, :1551-1552 qkv + qkv_dwconv): out[B][H][W][192] =
  * depthwise3x3(conv1x1(LayerNorm64(x))).  w_bf16: split-bf16 weights [hi|lo][4][2][192][8], element (s,h,n,j) =
  * W[n][16s+8h+j] * gamma[16s+8h+j]; bias[192] = W @ beta (may be NULL); dw_w: raw [192][1][3][3] taps.  */

@@ -349,3 +349,20 @@ def test_conv3x3_ring_second_output_chunk_planar():
     out = K.conv_ring(K.to_cp16(_nhwc(x).cuda()), pc, res1=res, out2_cp16=o16)
     torch.cuda.synchronize()
     assert torch.equal(K.from_cp16(o16), out.half())
+
+
+@pytest.mark.parametrize("B,H,W", [(2, 12, 30), (1, 16, 44), (2, 8, 64)])
+def test_block_prologue(B, H, W):
+    """u16 = bilinear_x2(up.0(x)), d16 = down.0(mean2x2(x)) vs the reference order of operations in torch-cpu
+    (arch.py:378-406: up.0 / down.0 are applied AFTER the resampling there; they commute with it)."""
+    from cdfo_amd import kernels as K
+    g = torch.Generator().manual_seed(B + H + W)
+    x = torch.randn(B, 64, H, W, generator=g)
+    wu, bu = torch.randn(64, 64, 1, 1, generator=g) / 8.0, torch.randn(64, generator=g)
+    wd, bd = torch.randn(64, 64, 1, 1, generator=g) / 8.0, torch.randn(64, generator=g)
+    ref_u = F.conv2d(F.interpolate(x, scale_factor=2, mode="bilinear", align_corners=False), wu, bu)
+    ref_d = F.conv2d(F.interpolate(x, scale_factor=0.5, mode="bilinear", align_corners=False), wd, bd)
+    u16, d16 = K.block_prologue(_nhwc(x).cuda(), K.pack_block_prologue(wu.cuda(), bu.cuda(), wd.cuda(), bd.cuda()))
+    torch.cuda.synchronize()
+    _cmp(K.from_cp16(u16).float(), ref_u, 1.5e-3, "block prologue, x2 branch")
+    _cmp(K.from_cp16(d16).float(), ref_d, 1.5e-3, "block prologue, x1/2 branch")

@@ -27,6 +27,12 @@ def main():
             line += f" ws[dbg {d}] {ms:6.3f} ms {fl/ms/1e9:6.1f} TF/s"
             if d == 0:
                 line += f" (max diff vs tiled {(K.from_cp16(out).float() - ref.float()).abs().max().item():.2e})"
+        clk = torch.zeros(2, dtype=torch.int64, device="cuda")
+        for d in (128, 136):
+            K.conv3x3_ws(src, pc, act=1, s2d=s2d, out=out, dbg=d, clk=clk)
+            torch.cuda.synchronize()
+            c = clk.tolist()
+            line += f" | dbg{d}: shader clock {c[0] / (c[1] / 100.0):.0f} MHz over {c[1] / 100.0:.0f} us"
         ms = timeit(lambda: K.to_cp16(x))
         print(line + f" | to_cp16 {ms:.3f} ms", flush=True)
 

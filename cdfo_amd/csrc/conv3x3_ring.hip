@@ -385,6 +385,18 @@ __global__ __launch_bounds__(RG_THREADS) void conv3x3_ring_kernel(cdfo_conv_args
           v += rv[mi][ni][it];      // unconditional use: no residual load may stay "pending" across the tile loop
           if (!nok || oy >= H || ox0 + xi >= W) continue;
           if (a.res2) v += *reinterpret_cast<const f32x4*>(a.res2 + (pixrow + xi) * a.ldr2 + n);
+          if (a.res_up2) {      // + bilinear x2 of a half-resolution tensor: taps (Q-1, Q) x (P-1, P), clamped
+            const int Hd = H >> 1, Wd = W >> 1, X = ox0 + xi;
+            const int Q = (oy + 1) >> 1, P = (X + 1) >> 1;
+            const int ya = Q > 0 ? Q - 1 : 0, yb = Q < Hd ? Q : Hd - 1, xa = P > 0 ? P - 1 : 0, xb = P < Wd ? P : Wd - 1;
+            const float ly = (oy & 1) ? 0.25f : 0.75f, lx = (X & 1) ? 0.25f : 0.75f;
+            const float* eb = a.res_up2 + (long long)b * Hd * Wd * a.ldru + n;
+            const f32x4 eaa = *reinterpret_cast<const f32x4*>(eb + ((long long)ya * Wd + xa) * a.ldru);
+            const f32x4 eab = *reinterpret_cast<const f32x4*>(eb + ((long long)ya * Wd + xb) * a.ldru);
+            const f32x4 eba = *reinterpret_cast<const f32x4*>(eb + ((long long)yb * Wd + xa) * a.ldru);
+            const f32x4 ebb = *reinterpret_cast<const f32x4*>(eb + ((long long)yb * Wd + xb) * a.ldru);
+            v += (1.f - ly) * ((1.f - lx) * eaa + lx * eab) + ly * ((1.f - lx) * eba + lx * ebb);
+          }
           const long long o = (pixrow + xi) * a.ldo + n;
           typedef _Float16 f16x4_t __attribute__((ext_vector_type(4)));
           f16x4_t hv;
@@ -438,6 +450,7 @@ extern "C" int cdfo_conv3x3_ring(const cdfo_conv_args* pa, void* stream) {
   if (a.CoutP % 64 || a.CoutP > 1024 || a.CoutP < a.Cout || a.Cout <= 0 || a.Ho != a.H || a.Wo != a.W || a.w_bstride != 0) return CDFO_EINVAL;
   if (a.store_mode != CDFO_STORE_PLAIN) return CDFO_EINVAL;
   if (a.out2_cp16 && (a.Cout % 16 || !aligned16(a.out2_cp16))) return CDFO_EINVAL;
+  if (a.res_up2 && ((a.H | a.W) & 1 || a.ldru % 4 || a.ldru < a.Cout || !aligned16(a.res_up2))) return CDFO_EINVAL;
   if (!aligned16(a.src[0]) || !aligned16(a.w) || a.Cout % 4 || a.ldo % 4 || !aligned16(a.out) ||
       (a.bias && !aligned16(a.bias)))
     return CDFO_EALIGN;

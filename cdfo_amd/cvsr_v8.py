@@ -329,10 +329,10 @@ class CVSR_V8(nn.Module):
             u16, d16 = K.block_prologue(x, w[p + "pro"])      # sources of the x2 and x1/2 branches, one read of x
             out = K.conv_ring(c1(x16), b2, res1=x)
             d = K.conv_ring(c1(d16), b2)
-            K.resample2(self._conv(d, up), up=True, out=out, accumulate=True)
             t = c1(u16, s2d=True)
             y16 = torch.empty_like(x16) if want16 else None
-            y = K.conv_ring(t, w[p + "down_fused"], res1=out, out2_cp16=y16)
+            # the x1/2 branch (up.0 of d, bilinear x2) is added by the last convolution's epilogue
+            y = K.conv_ring(t, w[p + "down_fused"], res1=out, res_up2=self._conv(d, up), out2_cp16=y16)
             return (y, y16) if want16 else y
         out = self._conv(self._conv(x, b0, pad=1, act=K.ACT_LRELU, out_f16=t16, inner=True), b2, pad=1, res1=x)
         # half-resolution branch

@@ -251,7 +251,8 @@ def sparse_taps_f16(pc: PackedConv) -> torch.Tensor:
 
 def conv_ring(src: torch.Tensor, pc: PackedConv, *, act: int = ACT_NONE, res1: Optional[torch.Tensor] = None,
               res2: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None,
-              out_f16: bool = False, out2_cp16: Optional[torch.Tensor] = None, dbg: int = 0) -> torch.Tensor:
+              out_f16: bool = False, out2_cp16: Optional[torch.Tensor] = None,
+              res_up2: Optional[torch.Tensor] = None, dbg: int = 0) -> torch.Tensor:
     """3x3/s1/p1 convolution of an fp16 chunk-planar source [B,Cin/16,H,W,16] on the LDS-DMA ring kernel
     (Block_.body[2] and the composed stride-2 convolution).  Result: pixel-major fp32 (or fp16) [B,H,W,Cout]."""
     if not src.is_cuda:
@@ -286,6 +287,11 @@ def conv_ring(src: torch.Tensor, pc: PackedConv, *, act: int = ACT_NONE, res1: O
                 raise ValueError(f"{nm} shape {tuple(r.shape)} does not match the conv output")
             setattr(a, nm, r.data_ptr())
             setattr(a, "ldr" + nm[-1], rld)
+    if res_up2 is not None:         # half-resolution residual, added after bilinear x2
+        rb, rh, rw, rc, rld = _chk_act(res_up2, "res_up2")
+        if (rb, rh * 2, rw * 2) != (B, H, W) or rc < pc.Cout:
+            raise ValueError(f"res_up2 shape {tuple(res_up2.shape)} is not the half-resolution of the conv output")
+        a.res_up2, a.ldru = res_up2.data_ptr(), rld
     if out2_cp16 is not None:       # second, fp16 chunk-planar copy of the result (the next Block_'s body[0] source)
         if (out2_cp16.dtype != torch.float16 or tuple(out2_cp16.shape) != (B, pc.Cout // 16, H, W, 16)
                 or not out2_cp16.is_contiguous()):

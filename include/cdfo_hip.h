@@ -55,6 +55,8 @@ typedef struct {
   int out_f16;                /* cdfo_conv3x3_bf16 only: store the result as fp16 (ldo in halves); no residual inputs */
   void* out2_cp16;            /* optional, cdfo_conv3x3_ring only: second copy of the result as an fp16 chunk-planar tensor
                                  [B][Cout/16][H][W][16] (the next Block_'s body[0] source), Cout % 16 == 0 */
+  const float* res_up2; int ldru;   /* optional, cdfo_conv3x3_ring only: a HALF-resolution residual [B][H/2][W/2][ldru] that is
+                                 added after bilinear x2 up-sampling (align_corners=False), i.e. Block_'s x1/2 branch */
 } cdfo_conv_args;
 int cdfo_conv_igemm(const cdfo_conv_args* a, void* stream);
 

@@ -366,3 +366,19 @@ def test_block_prologue(B, H, W):
     torch.cuda.synchronize()
     _cmp(K.from_cp16(u16).float(), ref_u, 1.5e-3, "block prologue, x2 branch")
     _cmp(K.from_cp16(d16).float(), ref_d, 1.5e-3, "block prologue, x1/2 branch")
+
+
+def test_conv3x3_ring_half_resolution_residual():
+    """res_up2: the ring kernel adds bilinear_x2 of a half-resolution tensor in its epilogue."""
+    from cdfo_amd import kernels as K
+    g = torch.Generator().manual_seed(17)
+    B, H, W, Cin, Cout = 2, 20, 36, 64, 64
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / 24.0
+    b = torch.randn(Cout, generator=g)
+    e = torch.randn(B, Cout, H // 2, W // 2, generator=g)
+    ref = F.conv2d(x.half().float(), w.half().float(), b, padding=1) + \
+        F.interpolate(e, scale_factor=2, mode="bilinear", align_corners=False)
+    out = K.conv_ring(K.to_cp16(_nhwc(x).cuda()), K.pack_conv(w.cuda(), b.cuda()), res_up2=_nhwc(e).cuda())
+    torch.cuda.synchronize()
+    _cmp(out, ref, 1e-4, "ring conv + half-resolution residual")

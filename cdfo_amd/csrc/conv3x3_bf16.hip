@@ -77,7 +77,9 @@ __device__ __forceinline__ float round16(float a) { return F16 ? (float)(_Float1
 
 // DBG (developer ablations, never used by the product path): 1 = skip the MFMAs, 2 = skip the per-chunk global loads,
 // 4 = skip the per-chunk convert + LDS writes, 8 = skip the epilogue (store one value), 16 = skip the barriers
-template <int MODE, int WAVES_PER_SIMD, int DBG>
+// NT: 32-channel output tiles per workgroup (2 = 64 output channels; 1 for convolutions with <= 32 output channels, e.g.
+// UDSA's 64 -> 16: half the MFMAs and half the weight-fragment reads of the padded 64-wide tile)
+template <int MODE, int WAVES_PER_SIMD, int DBG, int NT = 2>
 __global__ __launch_bounds__(256, WAVES_PER_SIMD) void conv3x3_mma16_kernel(cdfo_conv_args a) {
   using F = Fmt<MODE>;
   using frag_t = typename F::frag;
@@ -89,7 +91,7 @@ __global__ __launch_bounds__(256, WAVES_PER_SIMD) void conv3x3_mma16_kernel(cdfo
   constexpr int LDS_W = F::WLO ? 2 * W_HALF : W_HALF;
   constexpr int NWU = LDS_W / 16;                 // 16-byte units in the weight slab
   constexpr int NWS = (NWU + 255) / 256;          // per-thread weight loads per chunk (9 or 5)
-  constexpr int EPI = ConvEpi<2>::BLOCK_BYTES;
+  constexpr int EPI = ConvEpi<NT>::BLOCK_BYTES;
   constexpr int SMEM = (A_BYTES + LDS_W) > EPI ? (A_BYTES + LDS_W) : EPI;
   __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM];
   unsigned char* sA = smem;
@@ -124,11 +126,11 @@ __global__ __launch_bounds__(256, WAVES_PER_SIMD) void conv3x3_mma16_kernel(cdfo
     a_lds[s] = idx < NPIX * PER ? p * PIXB + q * (SRC16 ? 16 : 8) : -1;
   }
 
-  f32x16 acc[2][2];
+  f32x16 acc[2][NT];
 #pragma unroll
   for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-    for (int ni = 0; ni < 2; ++ni)
+    for (int ni = 0; ni < NT; ++ni)
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[mi][ni][e] = 0.f;
 
@@ -209,7 +211,7 @@ __global__ __launch_bounds__(256, WAVES_PER_SIMD) void conv3x3_mma16_kernel(cdfo
       if (F::ALO) fal[par][mi] = *reinterpret_cast<const frag_t*>(sA + a_off[mi] + (dy * IW + dx) * PIXB + 32);
     }
 #pragma unroll
-    for (int ni = 0; ni < 2; ++ni) {
+    for (int ni = 0; ni < NT; ++ni) {
       fbh[par][ni] = *reinterpret_cast<const frag_t*>(sW + (t * 2 * 64 + ni * 32) * 16 + b_off);
       if (F::WLO) fbl[par][ni] = *reinterpret_cast<const frag_t*>(sW + W_HALF + (t * 2 * 64 + ni * 32) * 16 + b_off);
     }
@@ -219,13 +221,13 @@ __global__ __launch_bounds__(256, WAVES_PER_SIMD) void conv3x3_mma16_kernel(cdfo
 #pragma unroll
       for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-        for (int ni = 0; ni < 2; ++ni) acc[mi][ni][0] += (float)fah[par][mi][0] * (float)fbh[par][ni][0];
+        for (int ni = 0; ni < NT; ++ni) acc[mi][ni][0] += (float)fah[par][mi][0] * (float)fbh[par][ni][0];
       return;
     }
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-      for (int ni = 0; ni < 2; ++ni) {
+      for (int ni = 0; ni < NT; ++ni) {
         if (F::ALO) acc[mi][ni] = mma(fal[par][mi], fbh[par][ni], acc[mi][ni]);
         if (F::WLO) acc[mi][ni] = mma(fah[par][mi], fbl[par][ni], acc[mi][ni]);
         acc[mi][ni] = mma(fah[par][mi], fbh[par][ni], acc[mi][ni]);
@@ -279,15 +281,15 @@ __global__ __launch_bounds__(256, WAVES_PER_SIMD) void conv3x3_mma16_kernel(cdfo
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-      for (int ni = 0; ni < 2; ++ni)
+      for (int ni = 0; ni < NT; ++ni)
 #pragma unroll
         for (int e = 0; e < 16; ++e) t += acc[mi][ni][e];
     if (t == 123.456f) a.out[0] = t;
     return;
   }
-  float* wl = reinterpret_cast<float*>(smem) + wave * ConvEpi<2>::WAVE_FLOATS;
+  float* wl = reinterpret_cast<float*>(smem) + wave * ConvEpi<NT>::WAVE_FLOATS;
 #pragma unroll
-  for (int mi = 0; mi < 2; ++mi) conv_tile_epilogue_row32<2>(a, wl, acc[mi], lane, b, oy0 + wave * 2 + mi, ox0, n0);
+  for (int mi = 0; mi < 2; ++mi) conv_tile_epilogue_row32<NT>(a, wl, acc[mi], lane, b, oy0 + wave * 2 + mi, ox0, n0);
 }
 
 // OIHW fp32 -> 16-bit weights [Cin/16][9][2][CoutP][8]  (k = 16*chunk + 8*h + j):
@@ -352,6 +354,10 @@ extern "C" int cdfo_conv3x3_bf16(const cdfo_conv_args* pa, void* stream) {
       default: return CDFO_EINVAL;
     }
 #undef CDFO_DBG_CASE
+  } else if (prec == CDFO_PREC_BF16X3 && a.Cout <= 32 && a.CoutP == 64) {
+    hipLaunchKernelGGL((conv3x3_mma16_kernel<M_BF16X3, 2, 0, 1>), grid, dim3(256), 0, st, a);
+  } else if (prec == CDFO_PREC_FP16X2 && a.Cout <= 32 && a.CoutP == 64) {
+    hipLaunchKernelGGL((conv3x3_mma16_kernel<M_FP16X2, 2, 0, 1>), grid, dim3(256), 0, st, a);
   } else if (prec == CDFO_PREC_BF16X3) {
     hipLaunchKernelGGL((conv3x3_mma16_kernel<M_BF16X3, 2, 0>), grid, dim3(256), 0, st, a);
   } else if (prec == CDFO_PREC_BF16) {

@@ -295,12 +295,27 @@ __global__ __launch_bounds__(256) void scale_channels_kernel(const float* __rest
 
 // ------------------------------------------------------------------------------------------------------------
 // conv_last (3x3, 64 -> 1, +bias) fused with `out += bilinear_x4(x_center)` (arch.py:4476-4480).
-// 16 lanes per HR pixel (a float4 of channels each), 9 taps, then a 16-lane shuffle reduction.
+// The 64-channel HR feature map (4.3 GB at c3) is read ONCE: a workgroup takes a 16 x 64 pixel tile, and for every
+// pixel of its 18 x 66 halo region 16 lanes (a float4 of channels each) form the nine per-tap channel sums
+// t_k(p) = sum_c w[c][k] in[p][c] (DPP row reduction, no LDS traffic), lane 0 parks them in LDS; an output pixel is
+// then the sum of nine parked values at its shifted positions.  (First cut: every output pixel gathered its 3x3
+// neighbourhood itself, 9 x 256 B per pixel through the caches: 1.3 TB/s.)
+constexpr int CL_TY = 16, CL_TX = 64, CL_HX = CL_TX + 2, CL_NP = (CL_TY + 2) * CL_HX;    // 1188 halo pixels
+
+__device__ __forceinline__ float row16_sum(float v) {     // sum over the 16 lanes of a DPP row, result in every lane
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));   // quad_perm [1,0,3,2]
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));   // quad_perm [2,3,0,1]
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x124, 0xF, 0xF, true));  // row_ror:4
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xF, 0xF, true));  // row_ror:8
+  return v;
+}
+
 __global__ __launch_bounds__(256) void conv_last_kernel(const float* __restrict__ in, int ldi,
                                                         const float* __restrict__ w, const float* __restrict__ bias,
                                                         const float* __restrict__ xc, long long xc_bstride, int B,
                                                         int Hh, int Wh, float* __restrict__ out) {
-  const int cg = threadIdx.x & 15;
+  __shared__ float sT[9][CL_NP];
+  const int tid = threadIdx.x, cg = tid & 15, grp = tid >> 4;
   f32x4 wr[9];
 #pragma unroll
   for (int t = 0; t < 9; ++t)
@@ -308,39 +323,53 @@ __global__ __launch_bounds__(256) void conv_last_kernel(const float* __restrict_
     for (int j = 0; j < 4; ++j) wr[t][j] = w[(cg * 4 + j) * 9 + t];
   const float b0 = bias[0];
   const int H = Hh >> 2, W = Wh >> 2;
-  const long long npix = (long long)B * Hh * Wh;
-  for (long long p = (blockIdx.x * (long long)blockDim.x + threadIdx.x) >> 4; p < npix;
-       p += ((long long)gridDim.x * blockDim.x) >> 4) {
-    const int x = p % Wh;
-    const int y = (p / Wh) % Hh;
-    const long long b = p / ((long long)Wh * Hh);
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  const int tiles_x = (Wh + CL_TX - 1) / CL_TX, tiles_y = (Hh + CL_TY - 1) / CL_TY;
+  const int ntiles = B * tiles_y * tiles_x;
+  for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
+    const int tx = t % tiles_x, t2 = t / tiles_x;
+    const int ty = t2 % tiles_y, b = t2 / tiles_y;
+    const int y0 = ty * CL_TY, x0 = tx * CL_TX;
+    // ---- per-tap channel sums of the halo pixels (zero outside the image = the conv's zero padding)
+    for (int p = grp; p < CL_NP; p += 16) {
+      const int iy = p / CL_HX, ix = p - iy * CL_HX;
+      const int gy = y0 - 1 + iy, gx = x0 - 1 + ix;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (gy >= 0 && gy < Hh && gx >= 0 && gx < Wh)
+        v = *reinterpret_cast<const f32x4*>(in + (((long long)b * Hh + gy) * Wh + gx) * ldi + cg * 4);
+      float tk[9];
 #pragma unroll
-    for (int dy = 0; dy < 3; ++dy) {
-      const int yy = y + dy - 1;
-      if (yy < 0 || yy >= Hh) continue;
+      for (int k = 0; k < 9; ++k) {
+        const f32x4 pr = v * wr[k];
+        tk[k] = row16_sum((pr[0] + pr[1]) + (pr[2] + pr[3]));
+      }
+      if (cg == 0) {
 #pragma unroll
-      for (int dx = 0; dx < 3; ++dx) {
-        const int xx = x + dx - 1;
-        if (xx < 0 || xx >= Wh) continue;
-        acc += *reinterpret_cast<const f32x4*>(in + ((b * Hh + yy) * Wh + xx) * ldi + cg * 4) * wr[dy * 3 + dx];
+        for (int k = 0; k < 9; ++k) sT[k][p] = tk[k];
       }
     }
-    float s = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+    __syncthreads();
+    // ---- outputs: 4 per thread
+    for (int o = tid; o < CL_TY * CL_TX; o += 256) {
+      const int oy = o / CL_TX, ox = o - oy * CL_TX;
+      const int y = y0 + oy, x = x0 + ox;
+      if (y >= Hh || x >= Wh) continue;
+      float s = 0.f;
 #pragma unroll
-    for (int o = 8; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
-    if (cg == 0) {
+      for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) s += sT[dy * 3 + dx][(oy + dy) * CL_HX + ox + dx];
       float sy = ((float)y + 0.5f) * 0.25f - 0.5f, sx = ((float)x + 0.5f) * 0.25f - 0.5f;
       sy = sy < 0.f ? 0.f : sy;
       sx = sx < 0.f ? 0.f : sx;
-      const int y0 = (int)sy, x0 = (int)sx;
-      const int y1 = y0 + (y0 < H - 1 ? 1 : 0), x1 = x0 + (x0 < W - 1 ? 1 : 0);
-      const float ly = sy - (float)y0, lx = sx - (float)x0;
+      const int yy0 = (int)sy, xx0 = (int)sx;
+      const int yy1 = yy0 + (yy0 < H - 1 ? 1 : 0), xx1 = xx0 + (xx0 < W - 1 ? 1 : 0);
+      const float ly = sy - (float)yy0, lx = sx - (float)xx0;
       const float* c = xc + b * xc_bstride;
-      const float base = (1.f - ly) * ((1.f - lx) * c[(long long)y0 * W + x0] + lx * c[(long long)y0 * W + x1]) +
-                         ly * ((1.f - lx) * c[(long long)y1 * W + x0] + lx * c[(long long)y1 * W + x1]);
-      out[p] = (s + b0) + base;
+      const float base = (1.f - ly) * ((1.f - lx) * c[(long long)yy0 * W + xx0] + lx * c[(long long)yy0 * W + xx1]) +
+                         ly * ((1.f - lx) * c[(long long)yy1 * W + xx0] + lx * c[(long long)yy1 * W + xx1]);
+      out[((long long)b * Hh + y) * Wh + x] = (s + b0) + base;
     }
+    __syncthreads();
   }
 }
 
@@ -443,7 +472,8 @@ extern "C" int cdfo_conv_last(const float* in, int ldi, const float* w, const fl
   if (B <= 0 || (Hh & 3) || (Wh & 3) || ldi % 4) return CDFO_EINVAL;
   if (!aligned16(in)) return CDFO_EALIGN;
   CdfoProfScope prof(static_cast<hipStream_t>(stream), KID_CONV_LAST, 2.0*9*64*(double)B*Hh*Wh, 4.0*65*(double)B*Hh*Wh);
-  hipLaunchKernelGGL(conv_last_kernel, dim3(grid_for((long long)B * Hh * Wh * 16)), dim3(256), 0,
+  const long long ntiles = (long long)B * cdiv(Hh, CL_TY) * cdiv(Wh, CL_TX);
+  hipLaunchKernelGGL(conv_last_kernel, dim3((unsigned)(ntiles < 4096 ? ntiles : 4096)), dim3(256), 0,
                      static_cast<hipStream_t>(stream), in, ldi, w, bias, xc, xc_bstride, B, Hh, Wh, out);
   CDFO_LAUNCH_CHECK();
   return 0;

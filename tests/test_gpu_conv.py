@@ -382,3 +382,19 @@ def test_conv3x3_ring_half_resolution_residual():
     out = K.conv_ring(K.to_cp16(_nhwc(x).cuda()), K.pack_conv(w.cuda(), b.cuda()), res_up2=_nhwc(e).cuda())
     torch.cuda.synchronize()
     _cmp(out, ref, 1e-4, "ring conv + half-resolution residual")
+
+
+@pytest.mark.parametrize("B,H,W", [(2, 8, 24), (1, 12, 40)])
+def test_conv_last(B, H, W):
+    """conv_last (3x3, 64 -> 1) + bilinear x4 of the centre LR frame (arch.py:4476-4480)."""
+    from cdfo_amd import kernels as K
+    g = torch.Generator().manual_seed(B + H + W)
+    feat = torch.randn(B, 64, 4 * H, 4 * W, generator=g)
+    w = torch.randn(1, 64, 3, 3, generator=g) / 24.0
+    b = torch.randn(1, generator=g)
+    xc = torch.rand(B, 1, H, W, generator=g)
+    ref = F.conv2d(feat, w, b, padding=1) + F.interpolate(xc, scale_factor=4, mode="bilinear", align_corners=False)
+    out = K.conv_last(_nhwc(feat).cuda(), w.cuda().contiguous(), b.cuda(), xc.cuda().contiguous(), H * W)
+    torch.cuda.synchronize()
+    err = (out.cpu() - ref).abs().max().item()
+    assert err < 2e-5 * max(1.0, ref.abs().max().item()), err

@@ -35,7 +35,8 @@ constexpr int WS_W_BYTES = 4 * 9 * 2 * 64 * 16;            // 73,728: [chunk][ta
 constexpr int WS_BIAS_OFF = WS_W_BYTES;                    // 64 floats
 constexpr int WS_STG_OFF = WS_W_BYTES + 256;
 constexpr int WS_BUF = 5 * 1024;                           // one 16-channel chunk of a wave's halo: 136 px x 32 B in 5 DMA pieces
-constexpr int WS_LDS = WS_STG_OFF + 8 * 2 * WS_BUF;        // 155,904 bytes
+constexpr int WS_CNT_OFF = WS_STG_OFF + 8 * 2 * WS_BUF;    // work counter of the workgroup
+constexpr int WS_LDS = WS_CNT_OFF + 16;                    // 155,920 bytes
 constexpr int WS_IW = 34, WS_NPIX = 4 * 34;
 
 typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
@@ -50,7 +51,7 @@ struct ws_args {
   const float* bias;
   int Cout, act;
   _Float16* out; int s2d;
-  unsigned long long* clk;      // developer probe (dbg 128): {shader-clock ticks, 100 MHz real-time ticks} of workgroup 0
+  unsigned long long* clk;      // developer probe (dbg 128): per wave {shader-clock cycles, start, end in 100 MHz real-time ticks}
 };
 
 // five 1 KiB LDS-DMA pieces: lane l of piece k writes LDS bytes lds + 1024 k + 16 l from (buffer base + voff[k] + soff)
@@ -102,6 +103,8 @@ __global__ __launch_bounds__(WS_THREADS) void conv3x3_c64_ws_kernel(ws_args a) {
         *reinterpret_cast<const u32x4*>(a.w + ((long long)row * a.CoutP + n0 + chan_of_row(n)) * 8);
   }
   if (tid < 64) reinterpret_cast<float*>(smem + WS_BIAS_OFF)[tid] = a.bias ? a.bias[n0 + chan_of_row(tid)] : 0.f;
+  unsigned* s_next = reinterpret_cast<unsigned*>(smem + WS_CNT_OFF);
+  if (tid == 0) *s_next = 8;                     // tiles 0..7 of the workgroup go to waves 0..7, the rest first come first served
   __syncthreads();
 
   // ---- per-lane constants
@@ -139,8 +142,16 @@ __global__ __launch_bounds__(WS_THREADS) void conv3x3_c64_ws_kernel(ws_args a) {
   const int tiles_x = (W + 31) >> 5, hp = H >> 1;
   const int total = a.B * hp * tiles_x;
   const unsigned plane = (unsigned)(H * W) * 32u;        // bytes of one 16-channel plane of one image
-  const int ustride = nparts * 8;
-  int u = part * 8 + wave;
+  // The workgroup's i-th tile is tile (i & 7) of its (i >> 3)-th group of 8 consecutive tiles.  Tiles are handed out
+  // through an LDS counter: the two waves of a SIMD do not progress at the same rate (the older wave wins the issue
+  // arbitration), and with a static split the faster waves idled for the last ~10 % of the launch.
+  auto tile_of = [&](int i) { return ((i >> 3) * nparts + part) * 8 + (i & 7); };
+  auto grab = [&]() {
+    unsigned i = 0;
+    if (lane == 0) i = __hip_atomic_fetch_add(s_next, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    return tile_of((int)__builtin_amdgcn_readfirstlane(i));
+  };
+  int u = tile_of(wave), unext = 0;
 
   unsigned voff[5], soff0 = 0;
   int ub = 0, uy0 = 0, ux0 = 0;
@@ -174,7 +185,7 @@ __global__ __launch_bounds__(WS_THREADS) void conv3x3_c64_ws_kernel(ws_args a) {
     for (int i = 0; i < naps; ++i) __builtin_amdgcn_s_sleep(9);
   }
   bool prev_full = false;
-  for (; u < total; u += ustride) {
+  for (; u < total; u = unext) {
     const int cb = ub, cy0 = uy0, cx0 = ux0;     // this unit (make_desc below moves on to the next one)
     f32x16 acc[2][2];                            // [ni: 32-channel block][mi: image row]
 #pragma unroll
@@ -216,8 +227,8 @@ __global__ __launch_bounds__(WS_THREADS) void conv3x3_c64_ws_kernel(ws_args a) {
           asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
           if (c < 3) {
             if (!(DBG & 2)) ws_dma5(voff, rsrc, soff0 + (unsigned)(c + 1) * plane, stg_lds + ((c + 1) & 1) * WS_BUF);
-          } else if (u + ustride < total) {
-            make_desc(u + ustride);
+          } else if ((unext = grab()) < total) {
+            make_desc(unext);
             if (!(DBG & 2)) ws_dma5(voff, rsrc, soff0, stg_lds);
           }
         }
@@ -269,15 +280,17 @@ __global__ __launch_bounds__(WS_THREADS) void conv3x3_c64_ws_kernel(ws_args a) {
 #pragma unroll
           for (int q = 0; q < 8; ++q) {
             const float v = acc[ni][mi][8 * jj + q];
-            hv[q] = (_Float16)(fmaxf(v, 0.f) + slope * fminf(v, 0.f));
+            hv[q] = (_Float16)fmaxf(v, slope * v);      // slope in [0, 1]: identity / LeakyReLU / ReLU
           }
           if (xok) *reinterpret_cast<f16x8_t*>(a.out + (pos + (ni * 2 + jj) * cstride) * 16 + h * 8) = hv;
         }
     }
   }
-  if ((DBG & 128) && a.clk && blockIdx.x == 0 && tid == 0) {
-    a.clk[0] = __builtin_readcyclecounter() - clk0;
-    a.clk[1] = __builtin_amdgcn_s_memrealtime() - rt0;
+  if ((DBG & 128) && a.clk && (tid & 63) == 0) {       // per wave: {shader cycles, start, end} (100 MHz real-time ticks)
+    unsigned long long* c = a.clk + (blockIdx.x * 8 + wave) * 3;
+    c[0] = __builtin_readcyclecounter() - clk0;
+    c[1] = rt0;
+    c[2] = __builtin_amdgcn_s_memrealtime();
   }
 }
 

@@ -86,7 +86,8 @@ int cdfo_pack_conv3x3_f16(const float* w_oihw, void* packed, int Cout, int Cin, 
  * out_cp16: fp16 chunk-planar [B][Cout/16][H][W][16] (CDFO_STORE_PLAIN) or its space-to-depth form
  * [B][4*Cout/16][H/2][W/2][16], chunk = ((y&1)*2+(x&1))*Cout/16 + channel/16 (CDFO_STORE_S2D).
  * H even, Cout % 64 == 0, the source smaller than 2 GiB.  dbg: 0 (developer ablation flags otherwise; with dbg 128
- * clk_probe receives {shader-clock cycles, 100 MHz real-time ticks} of workgroup 0, else pass NULL).  */
+ * clk_probe receives, per wave of the grid, {shader-clock cycles, start, end in 100 MHz real-time ticks}: 3 x 8 x 256
+ * 64-bit words; else pass NULL).  */
 int cdfo_conv3x3_c64_ws(const void* src_cp16, int B, int H, int W, const void* w_f16, int CoutP, const float* bias,
                         int Cout, int act, void* out_cp16, int store_mode, int dbg, void* clk_probe, void* stream);
 /* 3x3 / stride 1 / pad 1 convolution of an fp16 chunk-planar source (a->src[0] = [B][Cin/16][H][W][16], a->src_f16 = 1,

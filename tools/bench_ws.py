@@ -27,12 +27,20 @@ def main():
             line += f" ws[dbg {d}] {ms:6.3f} ms {fl/ms/1e9:6.1f} TF/s"
             if d == 0:
                 line += f" (max diff vs tiled {(K.from_cp16(out).float() - ref.float()).abs().max().item():.2e})"
-        clk = torch.zeros(2, dtype=torch.int64, device="cuda")
-        for d in (128, 136):
+        clk = torch.zeros(256 * 8 * 3, dtype=torch.int64, device="cuda")
+        for d in (128,):
             K.conv3x3_ws(src, pc, act=1, s2d=s2d, out=out, dbg=d, clk=clk)
             torch.cuda.synchronize()
-            c = clk.tolist()
-            line += f" | dbg{d}: shader clock {c[0] / (c[1] / 100.0):.0f} MHz over {c[1] / 100.0:.0f} us"
+            c = clk.view(256, 8, 3).cpu().double()
+            t0 = c[:, :, 1].min()
+            dur = (c[:, :, 2] - c[:, :, 1]) / 100.0                  # us per wave
+            end = (c[:, :, 2] - t0) / 100.0
+            start = (c[:, :, 1] - t0) / 100.0
+            mhz = (c[:, :, 0] / dur).mean().item()
+            wg_end = end.max(dim=1).values
+            line += (f" | dbg{d}: clock {mhz:.0f} MHz; wave busy us min/mean/max {dur.min():.0f}/{dur.mean():.0f}/{dur.max():.0f};"
+                     f" start max {start.max():.0f}; WG end min/mean/max {wg_end.min():.0f}/{wg_end.mean():.0f}/{wg_end.max():.0f};"
+                     f" slowest XCD means {[round(wg_end[x::8].mean().item()) for x in range(8)]}")
         ms = timeit(lambda: K.to_cp16(x))
         print(line + f" | to_cp16 {ms:.3f} ms", flush=True)
 

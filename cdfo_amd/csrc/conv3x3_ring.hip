@@ -16,12 +16,13 @@
 //     out-of-range buffer offset = hardware zero fill = the zero padding;
 //   * the dense 32-byte pixel records are made conflict-free for ds_read_b128 by swapping the two 16-byte halves of
 //     every second group of 8 pixels (on the DMA source side and on the read side);
-//   * epilogue (bias, activation, residuals, fp32 or fp16 pixel-major store) 32 output channels at a time through
-//     wave-private scratch that aliases the ring stage just consumed; the residual rows are fetched into registers
-//     while the tile's last chunk computes, so their memory latency is not paid four times per tile.
+//   * transposed product (M = output channels, weight rows permuted by the DMA source address) so that a lane's
+//     accumulators are 8 consecutive channels of one pixel: the epilogue (bias, activation, residuals, bilinear x2 of a
+//     half-resolution residual, fp32 / fp16 pixel-major store, optional fp16 chunk-planar copy) works straight from
+//     registers, 32 contiguous bytes per lane -- no LDS transpose, no extra barrier; the residual values are fetched
+//     while the tile's last chunk computes.
 // DMA completion is hand-counted (hipcc does not see inline-asm memory operations); the rules sit next to each wait.
 #include "common.h"
-#include "conv_epilogue.h"
 
 namespace {
 
@@ -29,14 +30,11 @@ constexpr int RG_THREADS = 512;
 constexpr int RG_TH = 16, RG_IW = 34, RG_NPIX = 18 * 34;   // 612 staged pixels per chunk
 constexpr int RG_ACT = 20 * 1024;                          // 20 DMA pieces (612 x 32 B = 19,584 B + pad slots)
 constexpr int RG_NS = 4;                                   // ring stages: three chunk batches in flight
-constexpr int RG_SCR = ConvEpi<1>::WAVE_FLOATS * 4;        // 4,608 B of epilogue scratch per wave (8 x = 36,864 B)
-// LDS map.  dense (18 KB of weights per chunk): 4 x 38 KB ring (the epilogue scratch aliases the stage just consumed)
-// | 1 KB dump | 4 KB bias = 160,768 B;  four-tap form (8 KB): 4 x 28 KB ring | 36 KB scratch | dump | bias = 156,672 B
+// LDS map: RG_NS ring stages (dense 38 KB, four-tap form 28 KB) | 1 KB dump | 4 KB bias
 template <bool SPARSE> struct RingLds {
   static constexpr int WGT = (SPARSE ? 8 : 18) * 1024;
   static constexpr int STAGE = RG_ACT + WGT;
-  static constexpr int SCRATCH = RG_NS * STAGE;                                   // used when SPARSE
-  static constexpr int DUMP = RG_NS * STAGE + (SPARSE ? 8 * RG_SCR : 0);          // target of the padding DMA pieces
+  static constexpr int DUMP = RG_NS * STAGE;                                      // target of the padding DMA pieces
   static constexpr int BIAS = DUMP + 1024;
   static constexpr int TOTAL = BIAS + 4096;
 };
@@ -127,7 +125,12 @@ __global__ __launch_bounds__(RG_THREADS) void conv3x3_ring_kernel(cdfo_conv_args
       const int q = (wave - ACT_WAVES) * PPW + j;
       d_iy[j] = q < TAPS * 2 ? 0 : 1 << 20;
       d_ix[j] = 0;
-      d_rel[j] = (q * e.CoutP + lane) * 16;
+      // LDS position `lane` of a slab row = MFMA row m of 32-channel block (lane >> 5); it holds output channel
+      // (m>>4)*16 + ((m>>2)&1)*8 + ((m>>3)&1)*4 + (m&3), so that the accumulator registers of a lane are 8 consecutive
+      // channels of each 16-channel chunk (see the epilogue)
+      const int m = lane & 31;
+      const int chan = (lane & 32) + ((m >> 4) & 1) * 16 + ((m >> 2) & 1) * 8 + ((m >> 3) & 1) * 4 + (m & 3);
+      d_rel[j] = (q * e.CoutP + chan) * 16;
       dst_off[j] = q < TAPS * 2 ? RG_ACT + q * 1024 : -1;      // padding piece -> dump
     }
   }
@@ -208,22 +211,23 @@ __global__ __launch_bounds__(RG_THREADS) void conv3x3_ring_kernel(cdfo_conv_args
   bool prev_full = false, prev_res = false;
 
   const float slope = a.act == CDFO_ACT_NONE ? 1.f : (a.act == CDFO_ACT_LRELU ? 0.1f : 0.f);
-  const int c4 = lane & 7, pr = lane >> 3;    // epilogue read-back: 4 channels c4*4.. of pixel it*8 + pr
 
   int g = 0;                          // batch being consumed
   for (int ord = 0; ord < my_units; ++ord) {
+    // transposed product: M = output channels (weights = A operand), N = pixels -> acc[ni][mi][8jj + q] is channel
+    // ni*32 + jj*16 + h*8 + q of pixel r in tile row 2w + mi
     f32x16 acc[2][2];
 #pragma unroll
-    for (int mi = 0; mi < 2; ++mi)
+    for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
-      for (int ni = 0; ni < 2; ++ni)
+      for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-        for (int q = 0; q < 16; ++q) acc[mi][ni][q] = 0.f;
+        for (int q = 0; q < 16; ++q) acc[ni][mi][q] = 0.f;
     int b, oy0, ox0, n0;
     unit_coords(ord, b, oy0, ox0, n0);
     const int oyw = oy0 + wave * 2;
     // a full tile issues at least 16 epilogue stores (+ 16 residual loads) per wave: counted in the next wait
-    const bool full = ox0 + 32 <= W && oyw + 2 <= H && n0 + 64 <= a.Cout;
+    const bool full = ox0 + 32 <= W && oyw + 2 <= H && n0 + 64 <= a.Cout && !a.out_f16;
 
     // one chunk: wait + barrier, then the taps' MFMAs with the pieces of batch g+3 issued between them (a DMA
     // instruction takes 100-200 cycles to issue; behind a tap's four MFMAs that time is covered by the matrix pipe)
@@ -252,11 +256,11 @@ __global__ __launch_bounds__(RG_THREADS) void conv3x3_ring_kernel(cdfo_conv_args
       f16x8_t fa[2][2], fb[2][2];                      // [parity][tile]: fragments are read one tap ahead
       auto mma_tap = [&](int par) {
 #pragma unroll
-        for (int mi = 0; mi < 2; ++mi)
+        for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
-          for (int ni = 0; ni < 2; ++ni) {
-            if (DBG & 1) acc[mi][ni][0] += (float)fa[par][mi][0] * (float)fb[par][ni][0];
-            else acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[par][mi], fb[par][ni], acc[mi][ni], 0, 0, 0);
+          for (int mi = 0; mi < 2; ++mi) {
+            if (DBG & 1) acc[ni][mi][0] += (float)fa[par][mi][0] * (float)fb[par][ni][0];
+            else acc[ni][mi] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fb[par][ni], fa[par][mi], acc[ni][mi], 0, 0, 0);
           }
       };
       if (SPARSE) {
@@ -306,29 +310,27 @@ __global__ __launch_bounds__(RG_THREADS) void conv3x3_ring_kernel(cdfo_conv_args
     };
 
     for (int c = 0; c < nc - 1; ++c, ++g) chunk(c, c == 0 && prev_full, prev_res);
-    // ---- last chunk of the tile (peeled so that the residual registers are live only here): the residual rows are
-    // fetched while its MFMAs run
-    f32x4 rv[2][2][4];
+    // ---- last chunk of the tile (peeled so that the residual registers are live only here): the residual values are
+    // fetched while its MFMAs run.  A lane owns pixel (row oyw + mi, column ox0 + r) and, per (ni, jj), the 8 channels
+    // n0 + ni*32 + jj*16 + h*8 .. + 7 = 32 contiguous bytes of every fp32 pixel-major operand.
     const bool has_res = a.res1 != nullptr && !(DBG & 8);
+    const bool px_ok[2] = {oyw < H && ox0 + r < W, oyw + 1 < H && ox0 + r < W};
+    f32x4 rv[2][2][2][2];                     // [mi][ni][jj][half]
 #pragma unroll
-    for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-      for (int ni = 0; ni < 2; ++ni)
-#pragma unroll
-        for (int it = 0; it < 4; ++it) rv[mi][ni][it] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i < 16; ++i) (&rv[0][0][0][0])[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     auto load_res = [&]() {
       if (!has_res) return;
 #pragma unroll
       for (int mi = 0; mi < 2; ++mi) {
-        const float* rrow = a.res1 + ((long long)(b * H + oyw + mi) * W + ox0) * a.ldr1 + n0 + c4 * 4;
+        const float* rp = a.res1 + ((long long)(b * H + oyw + mi) * W + ox0 + r) * a.ldr1 + n0 + h * 8;
 #pragma unroll
         for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
-          for (int it = 0; it < 4; ++it) {
-            const int xi = it * 8 + pr;
-            if (oyw + mi < H && ox0 + xi < W && n0 + ni * 32 + c4 * 4 < a.Cout)
-              rv[mi][ni][it] = *reinterpret_cast<const f32x4*>(rrow + xi * a.ldr1 + ni * 32);
-          }
+          for (int jj = 0; jj < 2; ++jj)
+            if (px_ok[mi] && n0 + ni * 32 + jj * 16 + h * 8 < a.Cout) {
+              rv[mi][ni][jj][0] = *reinterpret_cast<const f32x4*>(rp + ni * 32 + jj * 16);
+              rv[mi][ni][jj][1] = *reinterpret_cast<const f32x4*>(rp + ni * 32 + jj * 16 + 4);
+            }
       }
     };
     // (four-tap form: 64 chunks per tile, the window switch needs the registers -> fetch after the last chunk)
@@ -337,81 +339,77 @@ __global__ __launch_bounds__(RG_THREADS) void conv3x3_ring_kernel(cdfo_conv_args
     ++g;
     if (SPARSE) load_res();
 
-    // ---- epilogue: +bias -> act -> +res1 -> +res2 -> store, 32 channels x 32 pixels at a time through wave-private
-    // scratch.  Dense form: the scratch aliases the stage of the tile's last batch (g-1): every wave must be done
-    // reading it (barrier), and the next DMA into that stage is issued only after the NEXT barrier, which every wave
-    // reaches after its epilogue.  Four-tap form: dedicated scratch, no barrier.
-    if (!SPARSE) {
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
-    }
-    prev_full = full && !(DBG & 8);
+    // ---- epilogue straight from the accumulators: +bias -> act -> +res1 -> +res2 -> +bilinear x2 of res_up2 -> stores
+    // (32 contiguous bytes per lane and channel group; the fp16 chunk-planar copy: 16 bytes per lane, 1 KiB per wave)
+    prev_full = full && !(DBG & 8) && !a.res2 && !a.res_up2;
     prev_res = has_res;
     if (DBG & 8) {
       float t = 0.f;
 #pragma unroll
-      for (int mi = 0; mi < 2; ++mi)
+      for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
-        for (int ni = 0; ni < 2; ++ni)
+        for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-          for (int q = 0; q < 16; ++q) t += acc[mi][ni][q];
+          for (int q = 0; q < 16; ++q) t += acc[ni][mi][q];
       if (t == 123.456f) a.out[0] = t;
       continue;
     }
-    constexpr int RS = ConvEpi<1>::RS;
-    float* wl = reinterpret_cast<float*>(smem + (SPARSE ? L::SCRATCH : ((g - 1) % RG_NS) * STAGE) + wave * RG_SCR);
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi) {
-      const int oy = oyw + mi;
-      const long long pixrow = (long long)(b * H + oy) * W + ox0;
+      const int oy = oyw + mi, X = ox0 + r;
+      const long long pix = (long long)(b * H + oy) * W + X;
 #pragma unroll
-      for (int ni = 0; ni < 2; ++ni) {
-        const int n = n0 + ni * 32 + c4 * 4;
-        const bool nok = n < a.Cout;
+      for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
-        for (int q = 0; q < 16; ++q) wl[((q & 3) + 8 * (q >> 2) + 4 * h) * RS + r] = acc[mi][ni][q];
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        // from LDS: a conditional global load here would make hipcc drain vmcnt -- and with it the DMA ring -- at
-        // the top of every tile
-        const f32x4 bias = *reinterpret_cast<const f32x4*>(smem + L::BIAS + (n0 + ni * 32 + c4 * 4) * 4);
+        for (int jj = 0; jj < 2; ++jj) {
+          const int n = n0 + ni * 32 + jj * 16 + h * 8;
+          const f32x4 b0 = *reinterpret_cast<const f32x4*>(smem + L::BIAS + n * 4);
+          const f32x4 b1 = *reinterpret_cast<const f32x4*>(smem + L::BIAS + n * 4 + 16);
+          f32x4 v0, v1;
 #pragma unroll
-        for (int it = 0; it < 4; ++it) {
-          const int xi = it * 8 + pr;
-          f32x4 v = *reinterpret_cast<const f32x4*>(wl + xi * RS + c4 * 4) + bias;
-#pragma unroll
-          for (int k = 0; k < 4; ++k) v[k] = fmaxf(v[k], 0.f) + slope * fminf(v[k], 0.f);
-          v += rv[mi][ni][it];      // unconditional use: no residual load may stay "pending" across the tile loop
-          if (!nok || oy >= H || ox0 + xi >= W) continue;
-          if (a.res2) v += *reinterpret_cast<const f32x4*>(a.res2 + (pixrow + xi) * a.ldr2 + n);
+          for (int k = 0; k < 4; ++k) {
+            const float t0 = acc[ni][mi][8 * jj + k] + b0[k], t1 = acc[ni][mi][8 * jj + 4 + k] + b1[k];
+            v0[k] = fmaxf(t0, slope * t0);      // slope in [0, 1]: identity / LeakyReLU / ReLU
+            v1[k] = fmaxf(t1, slope * t1);
+          }
+          v0 += rv[mi][ni][jj][0];              // unconditional use: no residual load may stay "pending" across tiles
+          v1 += rv[mi][ni][jj][1];
+          if (!px_ok[mi] || n >= a.Cout) continue;
+          if (a.res2) {
+            const float* p2 = a.res2 + pix * a.ldr2 + n;
+            v0 += *reinterpret_cast<const f32x4*>(p2);
+            v1 += *reinterpret_cast<const f32x4*>(p2 + 4);
+          }
           if (a.res_up2) {      // + bilinear x2 of a half-resolution tensor: taps (Q-1, Q) x (P-1, P), clamped
-            const int Hd = H >> 1, Wd = W >> 1, X = ox0 + xi;
+            const int Hd = H >> 1, Wd = W >> 1;
             const int Q = (oy + 1) >> 1, P = (X + 1) >> 1;
             const int ya = Q > 0 ? Q - 1 : 0, yb = Q < Hd ? Q : Hd - 1, xa = P > 0 ? P - 1 : 0, xb = P < Wd ? P : Wd - 1;
             const float ly = (oy & 1) ? 0.25f : 0.75f, lx = (X & 1) ? 0.25f : 0.75f;
             const float* eb = a.res_up2 + (long long)b * Hd * Wd * a.ldru + n;
-            const f32x4 eaa = *reinterpret_cast<const f32x4*>(eb + ((long long)ya * Wd + xa) * a.ldru);
-            const f32x4 eab = *reinterpret_cast<const f32x4*>(eb + ((long long)ya * Wd + xb) * a.ldru);
-            const f32x4 eba = *reinterpret_cast<const f32x4*>(eb + ((long long)yb * Wd + xa) * a.ldru);
-            const f32x4 ebb = *reinterpret_cast<const f32x4*>(eb + ((long long)yb * Wd + xb) * a.ldru);
-            v += (1.f - ly) * ((1.f - lx) * eaa + lx * eab) + ly * ((1.f - lx) * eba + lx * ebb);
-          }
-          const long long o = (pixrow + xi) * a.ldo + n;
-          typedef _Float16 f16x4_t __attribute__((ext_vector_type(4)));
-          f16x4_t hv;
+            const float* paa = eb + ((long long)ya * Wd + xa) * a.ldru;
+            const float* pab = eb + ((long long)ya * Wd + xb) * a.ldru;
+            const float* pba = eb + ((long long)yb * Wd + xa) * a.ldru;
+            const float* pbb = eb + ((long long)yb * Wd + xb) * a.ldru;
 #pragma unroll
-          for (int k = 0; k < 4; ++k) hv[k] = (_Float16)v[k];
-          if (a.out_f16) *reinterpret_cast<f16x4_t*>(reinterpret_cast<_Float16*>(a.out) + o) = hv;
-          else *reinterpret_cast<f32x4*>(a.out + o) = v;
-          if (a.out2_cp16)   // chunk-planar fp16 copy: record (image, chunk n/16, pixel), halves n%16 ..
-            *reinterpret_cast<f16x4_t*>(static_cast<_Float16*>(a.out2_cp16) +
-                                        (((long long)b * (a.Cout >> 4) + (n >> 4)) * H * W + (long long)oy * W + ox0 + xi) * 16 +
-                                        (n & 15)) = hv;
+            for (int hf = 0; hf < 2; ++hf) {
+              const f32x4 eaa = *reinterpret_cast<const f32x4*>(paa + 4 * hf), eab = *reinterpret_cast<const f32x4*>(pab + 4 * hf);
+              const f32x4 eba = *reinterpret_cast<const f32x4*>(pba + 4 * hf), ebb = *reinterpret_cast<const f32x4*>(pbb + 4 * hf);
+              (hf ? v1 : v0) += (1.f - ly) * ((1.f - lx) * eaa + lx * eab) + ly * ((1.f - lx) * eba + lx * ebb);
+            }
+          }
+          f16x8_t hv;
+#pragma unroll
+          for (int k = 0; k < 4; ++k) { hv[k] = (_Float16)v0[k]; hv[4 + k] = (_Float16)v1[k]; }
+          if (a.out_f16) {
+            *reinterpret_cast<f16x8_t*>(reinterpret_cast<_Float16*>(a.out) + pix * a.ldo + n) = hv;
+          } else {
+            *reinterpret_cast<f32x4*>(a.out + pix * a.ldo + n) = v0;
+            *reinterpret_cast<f32x4*>(a.out + pix * a.ldo + n + 4) = v1;
+          }
+          if (a.out2_cp16)   // chunk-planar fp16 copy: record (image, chunk n/16, pixel), halves h*8 .. h*8+7
+            *reinterpret_cast<f16x8_t*>(static_cast<_Float16*>(a.out2_cp16) +
+                                        (((long long)b * (a.Cout >> 4) + (n >> 4)) * H * W + (long long)oy * W + X) * 16 + h * 8) = hv;
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-      }
     }
   }
 }
@@ -449,6 +447,7 @@ extern "C" int cdfo_conv3x3_ring(const cdfo_conv_args* pa, void* stream) {
   if (a.act == CDFO_ACT_SIGMOID || a.Cin <= 0 || a.Cin % 16 || a.cs[0] != a.Cin || a.ld[0] != 16) return CDFO_EINVAL;
   if (a.CoutP % 64 || a.CoutP > 1024 || a.CoutP < a.Cout || a.Cout <= 0 || a.Ho != a.H || a.Wo != a.W || a.w_bstride != 0) return CDFO_EINVAL;
   if (a.store_mode != CDFO_STORE_PLAIN) return CDFO_EINVAL;
+  if (a.Cout % 8) return CDFO_EINVAL;
   if (a.out2_cp16 && (a.Cout % 16 || !aligned16(a.out2_cp16))) return CDFO_EINVAL;
   if (a.res_up2 && ((a.H | a.W) & 1 || a.ldru % 4 || a.ldru < a.Cout || !aligned16(a.res_up2))) return CDFO_EINVAL;
   if (!aligned16(a.src[0]) || !aligned16(a.w) || a.Cout % 4 || a.ldo % 4 || !aligned16(a.out) ||

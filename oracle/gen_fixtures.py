@@ -230,7 +230,44 @@ def run_module_case(ref, ref_att, name, kind, B, H, W, wseed, iseed):
     print(f"{name}: out {tuple(out.shape)} absmean {out.abs().mean():.5f} -> {path} ({os.path.getsize(path)/1024:.0f} KiB)")
 
 
+def gen_streaming_helpers():
+    """Golden vectors of the reference's streaming-loop helpers (test_LD_22_FPS.py:14-17,100-122,200-225).  The script
+    itself cannot be imported (module-level cv2 / dataset paths), so the three FunctionDefs are compiled from its
+    source in place; nothing is copied into the repo but their outputs."""
+    import ast
+    src = open(os.path.join(REF, "test_LD_22_FPS.py")).read()
+    wanted = {"generate_input_index", "mv2mvs", "modify_mv_for_end_frames"}
+    mod = ast.Module([n for n in ast.parse(src).body if isinstance(n, ast.FunctionDef) and n.name in wanted], [])
+    ns = {"np": np, "torch": torch}
+    exec(compile(mod, "test_LD_22_FPS.py", "exec"), ns)
+    rs = np.random.RandomState(7)
+    rec = {}
+    idx_cases = [(c, 7, m) for m in (0, 2, 5, 9) for c in range(m + 1)]
+    rec["index_cases"] = np.array(idx_cases)
+    rec["index_out"] = np.stack([ns["generate_input_index"](*c) for c in idx_cases])
+    mv = rs.randint(-64, 64, size=(3, 6, 10, 3)).astype(np.float32)
+    mv[..., 2] = rs.choice([-2.0, -1.0, 0.0, 1.0, 4.0], size=mv.shape[:-1])      # 0 distance: 0/0 -> NaN -> 0, x/0 -> inf
+    mv[0, 0, 0] = (0.0, 0.0, 0.0)
+    rec["mv_in"] = mv
+    with np.errstate(divide="ignore", invalid="ignore"):
+        rec["mv_out"] = np.stack([ns["mv2mvs"](m.copy()).numpy() for m in mv])
+    mod_cases, mod_out = [], []
+    base = rs.randn(1, 7, 2, 3, 4).astype(np.float32)
+    for T in (1, 2, 3, 4, 5, 8):
+        for i in range(T):
+            t = torch.from_numpy(base.copy())
+            ns["modify_mv_for_end_frames"](i, t, T)
+            mod_cases.append((i, T))
+            mod_out.append(t.numpy())
+    rec["mod_base"], rec["mod_cases"], rec["mod_out"] = base, np.array(mod_cases), np.stack(mod_out)
+    path = os.path.join(REPO, "tests", "golden", "streaming_helpers.npz")
+    np.savez_compressed(path, **rec)
+    print(f"streaming helpers -> {path} ({os.path.getsize(path)/1024:.0f} KiB)")
+
+
 def main():
+    if sys.argv[1:] == ["streaming"]:
+        return gen_streaming_helpers()
     ref = load_reference()
     only = sys.argv[1:]
     for name, cfg in CASES.items():
@@ -242,6 +279,8 @@ def main():
         if only and name not in only:
             continue
         run_module_case(ref, ref_att, name, *cfg)
+    if not only:
+        gen_streaming_helpers()
 
 
 if __name__ == "__main__":

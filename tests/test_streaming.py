@@ -1,0 +1,83 @@
+"""Streaming evaluation loop: host helpers vs golden vectors of the reference's own functions
+(CPU), the oracle restatement vs the same vectors (CPU), and the device-resident loop vs the oracle loop (GPU)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden", "streaming_helpers.npz")
+
+
+def test_oracle_helpers_match_reference_vectors():
+    from oracle.streaming_ref import generate_input_index, modify_mv_for_end_frames, mv2mvs
+    g = np.load(GOLD)
+    for c, o in zip(g["index_cases"], g["index_out"]):
+        assert (generate_input_index(*c) == o).all()
+    for m, o in zip(g["mv_in"], g["mv_out"]):
+        assert np.array_equal(mv2mvs(m), o, equal_nan=True)
+    for (i, T), o in zip(g["mod_cases"], g["mod_out"]):
+        assert np.array_equal(modify_mv_for_end_frames(int(i), g["mod_base"].copy(), int(T)), o)
+
+
+def test_host_helpers_match_reference_vectors():
+    from cdfo_amd.streaming import generate_input_index, modify_mv_for_end_frames, mv2mvs
+    g = np.load(GOLD)
+    for c, o in zip(g["index_cases"], g["index_out"]):
+        assert (generate_input_index(*[int(v) for v in c]).numpy() == o).all()
+    for m, o in zip(g["mv_in"], g["mv_out"]):
+        got = mv2mvs(torch.from_numpy(m)).permute(0, 2, 3, 1).numpy()            # reference layout [7,H,W,2]
+        assert np.array_equal(got, o, equal_nan=True)
+    for (i, T), o in zip(g["mod_cases"], g["mod_out"]):
+        got = modify_mv_for_end_frames(int(i), torch.from_numpy(g["mod_base"].copy()), int(T)).numpy()
+        assert np.array_equal(got, o)
+
+
+def _sequence(T, H, W, seed):
+    rs = np.random.RandomState(seed)
+    lr = rs.randint(0, 256, size=(T, H, W)).astype(np.float32)
+    pms = rs.randint(0, 256, size=(T, H, W)).astype(np.float32)
+    ufs = rs.randint(0, 256, size=(T, H, W)).astype(np.float32)
+    rms = np.clip(np.round(rs.randn(T, H, W) * 6), -128, 127).astype(np.float32)
+    mv = rs.randint(-64, 64, size=(2, T, H // 8, W // 8, 3)).astype(np.float32)
+    mv[..., 2] = rs.choice([-2.0, -1.0, 1.0], size=mv.shape[:-1])
+    mv = np.repeat(np.repeat(mv, 8, axis=2), 8, axis=3)                          # constant on 8x8 blocks
+    return lr, pms, rms, ufs, mv[0], mv[1]
+
+
+@pytest.mark.gpu
+def test_streaming_loop_matches_oracle_loop():
+    """T = 5 frames of 16 x 24: every boundary rule of modify_mv_for_end_frames fires; the device loop (feature cache,
+    index-gathered windows) against the oracle's restatement of the reference loop, and against fresh forwards."""
+    from arch.SIDECVSR_our import CVSR_V8
+    from cdfo_amd.streaming import StreamingSR
+    from oracle.cvsr_v8_ref import make_inputs, make_state_dict
+    from oracle.streaming_ref import stream_sequence
+    T, H, W = 5, 16, 24
+    sd = make_state_dict(21, perturb=True)
+    lr, pms, rms, ufs, mvl0, mvl1 = _sequence(T, H, W, 5)
+    noise = [make_inputs(1, H, W, 300 + i)["gumbel_u"] for i in range(T)]
+    ref = stream_sequence(sd, lr / 255.0, pms / 255.0, rms / 255.0, ufs / 255.0, mvl0, mvl1, noise)
+    model = CVSR_V8()
+    model.load_state_dict(sd, strict=True)
+    model = model.cuda().eval()
+    s = StreamingSR(model, lr, pms, rms, ufs, mvl0, mvl1, gumbel_uniform=[[u.cuda() for u in n] for n in noise])
+    outs = s.run()
+    assert s.fps > 0
+    for i, (o, r) in enumerate(zip(outs, ref)):
+        err = (o.cpu() - r).abs().max().item()
+        assert err <= 1e-3, f"frame {i}: max-abs {err}"
+    # the cached path equals a fresh forward on the same window (feature extraction is per frame)
+    for i in range(T):
+        assert (_fresh_step(s, i) - outs[i]).abs().max().item() <= 2e-5
+
+
+def _fresh_step(s, i):
+    from cdfo_amd.streaming import NFRAMES, generate_input_index
+    o = generate_input_index(i, NFRAMES, s.T - 1).to(s.dev)
+    po = o.clamp_min(1) if s.T > 1 else o
+    win = lambda t, idx: t.index_select(0, idx)[None, :, None]
+    with torch.no_grad():
+        out, _ = s.model(win(s.lr, o), s._mvs(s.mvl0, i), s._mvs(s.mvl1, i), win(s.pms, po), win(s.rms, po),
+                         win(s.ufs, po), None, gumbel_uniform=None if s.noise is None else s.noise[i])
+    return out[..., :4 * s.H, :4 * s.W]

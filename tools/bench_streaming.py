@@ -1,0 +1,32 @@
+"""Developer benchmark (GPU box only): the reference's real evaluation scenario -- ONE sequence, one new frame per
+forward, feature cache (test_LD_22_FPS.py:155-192) -- through cdfo_amd.streaming.StreamingSR on synthetic data."""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+from arch.SIDECVSR_our import CVSR_V8
+from cdfo_amd.streaming import StreamingSR
+from oracle.cvsr_v8_ref import make_state_dict
+
+
+def main():
+    T, H, W = int(sys.argv[1]) if len(sys.argv) > 1 else 24, 270, 480
+    rs = np.random.RandomState(0)
+    u8 = lambda: rs.randint(0, 256, size=(T, H, W)).astype(np.uint8)
+    lr, pms, ufs = u8(), u8(), u8()
+    rms = np.clip(np.round(rs.randn(T, H, W) * 6), -128, 127).astype(np.float32)
+    mv = rs.randint(-64, 64, size=(2, T, (H + 7) // 8, (W + 7) // 8, 3)).astype(np.float32)
+    mv[..., 2] = rs.choice([-2.0, -1.0, 1.0], size=mv.shape[:-1])
+    mv = np.repeat(np.repeat(mv, 8, axis=2), 8, axis=3)[:, :, :H, :W]
+    model = CVSR_V8()
+    model.load_state_dict(make_state_dict(0, perturb=False), strict=True)
+    model = model.cuda().eval()
+    s = StreamingSR(model, lr, pms, rms, ufs, mv[0], mv[1])
+    s.run()                                   # warm-up (weight packing, first-touch allocations)
+    outs = s.run()
+    print(f"streaming, 1 sequence of {T} frames {H}x{W} -> {tuple(outs[0].shape)}: {s.fps:.2f} frames/s "
+          f"({1e3 * s.seconds / T:.1f} ms per frame, forward only, B=1)")
+
+
+if __name__ == "__main__":
+    main()

@@ -67,6 +67,11 @@ def test_streaming_loop_matches_oracle_loop():
     for i, (o, r) in enumerate(zip(outs, ref)):
         err = (o.cpu() - r).abs().max().item()
         assert err <= 1e-3, f"frame {i}: max-abs {err}"
+    # HIP-graph replay of the cached-path forward gives the same frames
+    sg = StreamingSR(model, lr, pms, rms, ufs, mvl0, mvl1, gumbel_uniform=[[u.cuda() for u in n] for n in noise],
+                     use_graph=True)
+    for o, og in zip(outs, sg.run()):
+        assert (o - og).abs().max().item() <= 2e-5
     # the cached path equals a fresh forward on the same window (feature extraction is per frame)
     for i in range(T):
         assert (_fresh_step(s, i) - outs[i]).abs().max().item() <= 2e-5

@@ -163,6 +163,13 @@ int cdfo_rdab_prep(const float* xq, int ldx, const float* vmax, const float* noi
                    int B, long long P, float* sq, int lds_, float* vrow, int ldv, float* qwin, int ldw, void* stream);
 int cdfo_colconv9(const float* in, int ldi, const float* wH, const float* bH, int B, int H, int W, float* out, int ldo,
                   void* stream);
+/* Evaluation metrics on the device (metric/psnr_ssim.py:278-317 calculate_psnr, :320-399 _ssim / calculate_ssim): fp64
+ * partial sums over [N][H][W] fp32 planes, values = plane * scale (optionally clamped to [0,255] / rounded to integers),
+ * `crop` border pixels dropped.  metric 0: sum (a-b)^2;  metric 1: sum of the SSIM map (11x11 Gaussian, sigma 1.5,
+ * valid positions).  partial receives [N][*nblocks_out] doubles (partial_cap = its capacity in doubles); the caller
+ * adds them up in order and divides by the number of positions.  */
+int cdfo_metric_partials(const float* a, const float* b, int N, int H, int W, int crop, float scale, int clamp, int round8,
+                         int metric, double* partial, int partial_cap, int* nblocks_out, void* stream);
 /* Block_ prologue (arch.py:378-406): from one read of the block input x [B][H][W][64] (H, W even) the fp16 chunk-planar
  * sources of its two resampled branches: u16 [B][4][2H][2W][16] = bilinear_x2(up.0(x)) and d16 [B][4][H/2][W/2][16] =
  * down.0(mean2x2(x)).  w_bf16: split-bf16 1x1 weights [hi|lo][4][2][128][8], rows 0-63 = up.0, 64-127 = down.0,

@@ -265,9 +265,28 @@ def gen_streaming_helpers():
     print(f"streaming helpers -> {path} ({os.path.getsize(path)/1024:.0f} KiB)")
 
 
+def gen_metrics_psnr():
+    """Golden vectors of the reference's calculate_psnr (metric/psnr_ssim.py:278-317; numpy only, compiled in place
+    from its source -- the module itself imports cv2)."""
+    import ast
+    src = open(os.path.join(REF, "metric", "psnr_ssim.py")).read()
+    mod = ast.Module([n for n in ast.parse(src).body if isinstance(n, ast.FunctionDef) and n.name == "calculate_psnr"], [])
+    ns = {"np": np}
+    exec(compile(mod, "psnr_ssim.py", "exec"), ns)
+    rs = np.random.RandomState(3)
+    a = rs.randint(0, 256, size=(4, 40, 56, 1)).astype(np.float64)
+    b = np.clip(a + np.round(rs.randn(*a.shape) * np.array([0.0, 1.0, 4.0, 20.0])[:, None, None, None]), 0, 255)
+    out = np.array([[ns["calculate_psnr"](x, y, c) for c in (0, 4)] for x, y in zip(a, b)])
+    path = os.path.join(REPO, "tests", "golden", "metrics_psnr.npz")
+    np.savez_compressed(path, a=a.astype(np.uint8), b=b.astype(np.uint8), crops=np.array([0, 4]), psnr=out)
+    print(f"metrics psnr -> {path}: {out.tolist()}")
+
+
 def main():
     if sys.argv[1:] == ["streaming"]:
         return gen_streaming_helpers()
+    if sys.argv[1:] == ["metrics"]:
+        return gen_metrics_psnr()
     ref = load_reference()
     only = sys.argv[1:]
     for name, cfg in CASES.items():
@@ -281,6 +300,7 @@ def main():
         run_module_case(ref, ref_att, name, *cfg)
     if not only:
         gen_streaming_helpers()
+        gen_metrics_psnr()
 
 
 if __name__ == "__main__":

@@ -465,7 +465,7 @@ extern "C" int cdfo_conv3x3_ring(const cdfo_conv_args* pa, void* stream) {
   e.src = a.src[0]; e.nc = nc; e.w = a.w; e.CoutP = a.CoutP; e.tap_mask = a.tap_mask; e.w_bytes = (int)w_bytes;
   const int grid = cus / 8 * 8;
   const double px = (double)a.B * a.Ho * a.Wo;
-  CdfoProfScope prof(st, KID_CONV3_RING, 2.0 * px * a.Cout * a.Cin * taps,
+  CdfoProfScope prof(st, a.tap_mask ? KID_CONV3_RING4 : KID_CONV3_RING, 2.0 * px * a.Cout * a.Cin * taps,
                      2.0 * px * a.Cin + (a.out_f16 ? 2.0 : 4.0) * px * a.Cout + 2.0 * taps * a.Cin * a.Cout);
   int rc;
   switch (a.prec >> 8) {

@@ -222,8 +222,16 @@ def conv3x3_ws(src: torch.Tensor, pc: PackedConv, *, act: int = ACT_NONE, s2d: b
         out = torch.empty(shape, dtype=torch.float16, device=src.device)
     elif out.shape != shape or out.dtype != torch.float16 or not out.is_contiguous():
         raise ValueError(f"conv3x3_ws: out must be a contiguous fp16 tensor of shape {shape}")
-    check(_lib.lib().cdfo_conv3x3_c64_ws(_vp(src), B, H, W, _vp(pc.wh), pc.CoutP16, _vp(pc.bias), pc.Cout, act, _vp(out),
-                                         2 if s2d else 0, dbg, _vp(clk), _stream()), "cdfo_conv3x3_c64_ws")
+    # the kernel addresses its source with 32-bit buffer offsets (< 2 GiB per launch): split the batch if needed
+    per_img = 4 * H * W * 32
+    step = max(1, min(B, ((1 << 31) - 1) // per_img))
+    if per_img >= (1 << 31):
+        raise ValueError(f"conv3x3_ws: one {H}x{W} image exceeds the 2 GiB source limit of a launch")
+    for b0 in range(0, B, step):
+        nb = min(step, B - b0)
+        check(_lib.lib().cdfo_conv3x3_c64_ws(_vp(src[b0:b0 + nb]), nb, H, W, _vp(pc.wh), pc.CoutP16, _vp(pc.bias), pc.Cout,
+                                             act, _vp(out[b0:b0 + nb]), 2 if s2d else 0, dbg, _vp(clk), _stream()),
+              "cdfo_conv3x3_c64_ws")
     return out
 
 

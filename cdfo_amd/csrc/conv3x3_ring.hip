@@ -208,7 +208,6 @@ __global__ __launch_bounds__(RG_THREADS) void conv3x3_ring_kernel(cdfo_conv_args
       for (int j = 0; j < PPW; ++j) issue_piece(j);
       issue_end();
     }
-  bool prev_full = false, prev_res = false;
 
   const float slope = a.act == CDFO_ACT_NONE ? 1.f : (a.act == CDFO_ACT_LRELU ? 0.1f : 0.f);
 
@@ -226,28 +225,19 @@ __global__ __launch_bounds__(RG_THREADS) void conv3x3_ring_kernel(cdfo_conv_args
     int b, oy0, ox0, n0;
     unit_coords(ord, b, oy0, ox0, n0);
     const int oyw = oy0 + wave * 2;
-    // a full tile issues at least 16 epilogue stores (+ 16 residual loads) per wave: counted in the next wait
-    const bool full = ox0 + 32 <= W && oyw + 2 <= H && n0 + 64 <= a.Cout && !a.out_f16;
 
     // one chunk: wait + barrier, then the taps' MFMAs with the pieces of batch g+3 issued between them (a DMA
     // instruction takes 100-200 cycles to issue; behind a tap's four MFMAs that time is covered by the matrix pipe)
-    auto chunk = [&](int c, bool first_after_full_tile, bool had_res) {
-      // (1) my pieces of batch g have landed.  Younger vector-memory operations: the DMA batches g+1, g+2 (2 PPW
-      //     instructions) and, on the first chunk after a full tile, that tile's 16 epilogue stores and 16 residual
-      //     loads, all issued after batch g (gfx9 retires loads and stores in issue order, the rule hipcc's own
-      //     vmcnt(N) rely on).  (2) my fragment reads of batch g-1 have RETURNED (its stage is overwritten after the
-      //     barrier).  Then the barrier: everyone's pieces of g are in LDS, nobody still reads the stage of g-1.
+    auto chunk = [&](int c) {
+      // (1) my pieces of batch g have landed: the younger DMA batches g+1, g+2 are 2 PPW instructions, and DMA pieces
+      //     retire in issue order among themselves.  Other vector-memory operations (epilogue stores, residual loads) are
+      //     NOT counted: LDS-DMA loads do not retire in order relative to VGPR loads (measured in conv3x3_ws.hip), so
+      //     "at most 2 PPW outstanding" is the only bound that implies batch g has landed whatever else is in flight.
+      //     (2) my fragment reads of batch g-1 have RETURNED (its stage is overwritten after the barrier).  Then the
+      //     barrier: everyone's pieces of g are in LDS, nobody still reads the stage of g-1.
       if (g + 2 >= total) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-      else if (first_after_full_tile && had_res) {
-        if (PPW == 5) asm volatile("s_waitcnt vmcnt(42) lgkmcnt(0)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(40) lgkmcnt(0)" ::: "memory");
-      } else if (first_after_full_tile) {
-        if (PPW == 5) asm volatile("s_waitcnt vmcnt(26) lgkmcnt(0)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(24) lgkmcnt(0)" ::: "memory");
-      } else {
-        if (PPW == 5) asm volatile("s_waitcnt vmcnt(10) lgkmcnt(0)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
-      }
+      else if (PPW == 5) asm volatile("s_waitcnt vmcnt(10) lgkmcnt(0)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
       const bool do_issue = g + RG_NS - 1 < total;     // batch g+3 -> the stage batch g-1 lived in
       if (do_issue) issue_begin();
@@ -309,7 +299,7 @@ __global__ __launch_bounds__(RG_THREADS) void conv3x3_ring_kernel(cdfo_conv_args
       if (do_issue) issue_end();
     };
 
-    for (int c = 0; c < nc - 1; ++c, ++g) chunk(c, c == 0 && prev_full, prev_res);
+    for (int c = 0; c < nc - 1; ++c, ++g) chunk(c);
     // ---- last chunk of the tile (peeled so that the residual registers are live only here): the residual values are
     // fetched while its MFMAs run.  A lane owns pixel (row oyw + mi, column ox0 + r) and, per (ni, jj), the 8 channels
     // n0 + ni*32 + jj*16 + h*8 .. + 7 = 32 contiguous bytes of every fp32 pixel-major operand.
@@ -335,14 +325,12 @@ __global__ __launch_bounds__(RG_THREADS) void conv3x3_ring_kernel(cdfo_conv_args
     };
     // (four-tap form: 64 chunks per tile, the window switch needs the registers -> fetch after the last chunk)
     if (!SPARSE) load_res();
-    chunk(nc - 1, nc == 1 && prev_full, prev_res);
+    chunk(nc - 1);
     ++g;
     if (SPARSE) load_res();
 
     // ---- epilogue straight from the accumulators: +bias -> act -> +res1 -> +res2 -> +bilinear x2 of res_up2 -> stores
     // (32 contiguous bytes per lane and channel group; the fp16 chunk-planar copy: 16 bytes per lane, 1 KiB per wave)
-    prev_full = full && !(DBG & 8) && !a.res2 && !a.res_up2;
-    prev_res = has_res;
     if (DBG & 8) {
       float t = 0.f;
 #pragma unroll

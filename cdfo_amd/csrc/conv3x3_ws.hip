@@ -50,7 +50,10 @@ struct ws_args {
   const unsigned short* w; int CoutP;       // cdfo_pack_conv3x3_f16 packing, CoutP = its padded channel count
   const float* bias;
   int Cout, act;
-  _Float16* out; int s2d;
+  _Float16* out; int s2d;        // fp16 chunk-planar result (optional when out32 is given)
+  float* out32; int ldo32;       // RES form: fp32 pixel-major result = act(conv + bias) + res1 (+ res2)
+  const float* res1; int ldr1;
+  const float* res2; int ldr2;
   unsigned long long* clk;      // developer probe (dbg 128): per wave {shader-clock cycles, start, end in 100 MHz real-time ticks}
 };
 
@@ -76,9 +79,13 @@ __device__ __forceinline__ void ws_dma5(const unsigned (&voff)[5], i32x4 rsrc, u
       : "memory", "scc");
 }
 
-// DBG (developer ablations): 1 = skip the MFMAs, 2 = skip the DMA, 8 = skip the epilogue, 16 = drain every DMA wait
-// (vmcnt(0)), 64 = no start-up stagger
-template <int DBG>
+// DBG (developer ablations): 1 = skip the MFMAs, 2 = skip the DMA, 8 = skip the epilogue, 64 = no start-up stagger,
+// 128 = clock probe
+// RES: residual form -- fp32 pixel-major output with one or two fp32 residual inputs (ResidualBlock_noBN's second
+// convolution, arch.py:261-262), optionally also the fp16 chunk-planar copy.  The residual values of a tile are fetched
+// by inline-asm loads while its last chunk computes (hipcc would wait for a visible load with vmcnt(0) and so drain the
+// DMA that is in flight behind it) and consumed behind a counted wait.
+template <int DBG, bool RES = false>
 __global__ __launch_bounds__(WS_THREADS) void conv3x3_c64_ws_kernel(ws_args a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, r = lane & 31;
@@ -184,7 +191,6 @@ __global__ __launch_bounds__(WS_THREADS) void conv3x3_c64_ws_kernel(ws_args a) {
     const int naps = (wave >> 2) * 4 + (wave & 3);          // x 576 cycles (tile MFMA time ~4,600 cycles)
     for (int i = 0; i < naps; ++i) __builtin_amdgcn_s_sleep(9);
   }
-  bool prev_full = false;
   for (; u < total; u = unext) {
     const int cb = ub, cy0 = uy0, cx0 = ux0;     // this unit (make_desc below moves on to the next one)
     f32x16 acc[2][2];                            // [ni: 32-channel block][mi: image row]
@@ -197,13 +203,15 @@ __global__ __launch_bounds__(WS_THREADS) void conv3x3_c64_ws_kernel(ws_args a) {
         for (int k = 0; k < 4; ++k) { acc[ni][0][4 * j + k] = bv[k]; acc[ni][1][4 * j + k] = bv[k]; }
       }
 
+    f32x4 rv[RES ? 16 : 1];
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
-      // wait for this chunk's image.  It was issued during the previous chunk (below); the only younger vector-memory
-      // operations are the previous tile's 8 epilogue stores (all 8 are issued when that tile was full width), and
-      // gfx9 retires loads and stores in issue order -- the same rule hipcc's own vmcnt(N) waits rely on.
-      if (c == 0 && prev_full && !(DBG & 16)) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      // wait for this chunk's image, issued during the previous chunk (below): no DMA is younger than it, so the wait
+      // is vmcnt(0).  (A counted wait that lets the previous tile's epilogue stores stay in flight would assume that
+      // stores and LDS-DMA loads retire in issue order; measured: VGPR loads and LDS-DMA loads do NOT -- a vmcnt(5)
+      // behind 16 residual loads + 5 DMA pieces returned before the older residual loads had landed -- so counted waits
+      // here only ever count younger DMA pieces, which do retire in order among themselves.)
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       const unsigned char* sA = stg + (c & 1) * WS_BUF;
       const unsigned char* sWc = sWl + c * (9 * 2 * 64 * 16);
       f16x8_t fp[2][2], fw[2][2];                // [parity][mi / ni]: fragments are read one tap ahead
@@ -225,6 +233,17 @@ __global__ __launch_bounds__(WS_THREADS) void conv3x3_c64_ws_kernel(ws_args a) {
           // order and the 8 reads of taps 0 and 1 above are younger than all of them, so "at most 8 outstanding"
           // is enough -- and free, those 8 are about to be waited for anyway.
           asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
+          if (RES && c == 3) {
+            // 16 residual loads: pixel (row cy0 + mi, column cx0 + r), channels n0 + ni*32 + jj*16 + h*8 + 4*hf .. +3.
+            // Always issued (a masked pixel reads its clamped neighbour), so that the wait below can count them.
+            const int xc = cx0 + r < W ? cx0 + r : W - 1;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+              const int mi = i >> 3, ni = (i >> 2) & 1, jj = (i >> 1) & 1, hf = i & 1;
+              const float* rp = a.res1 + ((long long)(cb * H + cy0 + mi) * W + xc) * a.ldr1 + n0 + ni * 32 + jj * 16 + h * 8 + hf * 4;
+              asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(rv[i]) : "v"(rp) : "memory");
+            }
+          }
           if (c < 3) {
             if (!(DBG & 2)) ws_dma5(voff, rsrc, soff0 + (unsigned)(c + 1) * plane, stg_lds + ((c + 1) & 1) * WS_BUF);
           } else if ((unext = grab()) < total) {
@@ -242,7 +261,6 @@ __global__ __launch_bounds__(WS_THREADS) void conv3x3_c64_ws_kernel(ws_args a) {
           }
       }
     }
-    prev_full = cx0 + 32 <= W;
 
     // ---- epilogue: act -> fp16 -> 16-byte stores.  acc[ni][mi][8jj + 4b + k] = channel ni*32 + jj*16 + h*8 + b*4 + k of
     // pixel r in image row mi, i.e. halves [h*8, h*8+8) of chunk nb*4 + ni*2 + jj.
@@ -259,6 +277,49 @@ __global__ __launch_bounds__(WS_THREADS) void conv3x3_c64_ws_kernel(ws_args a) {
     }
     const int nck = a.Cout >> 4;                     // 16-channel chunks of the result
     const bool xok = cx0 + r < W;
+    if (RES) {
+      // Everything outstanding is waited for: the residual loads AND the DMA of the next tile's first chunk, issued right
+      // after them a whole chunk of MFMAs ago (so it has landed; a counted vmcnt(5) here returned garbage residuals:
+      // LDS-DMA loads and VGPR loads do not retire in issue order relative to each other).
+      asm volatile("s_waitcnt vmcnt(0)" : "+v"(rv[0]), "+v"(rv[1]), "+v"(rv[2]), "+v"(rv[3]), "+v"(rv[4]), "+v"(rv[5]), "+v"(rv[6]),
+                   "+v"(rv[7]), "+v"(rv[8]), "+v"(rv[9]), "+v"(rv[10]), "+v"(rv[11]), "+v"(rv[12]), "+v"(rv[13]), "+v"(rv[14]),
+                   "+v"(rv[15]) : : "memory");
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi) {
+        const int y = cy0 + mi, x = cx0 + r;
+        const long long pix = (long long)(cb * H + y) * W + x;
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+          for (int jj = 0; jj < 2; ++jj) {
+            const int n = n0 + ni * 32 + jj * 16 + h * 8;
+            f32x4 v0, v1;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+              const float t0 = acc[ni][mi][8 * jj + k], t1 = acc[ni][mi][8 * jj + 4 + k];
+              v0[k] = fmaxf(t0, slope * t0);
+              v1[k] = fmaxf(t1, slope * t1);
+            }
+            v0 += rv[mi * 8 + ni * 4 + jj * 2];
+            v1 += rv[mi * 8 + ni * 4 + jj * 2 + 1];
+            if (!xok) continue;
+            if (a.res2) {
+              const float* p2 = a.res2 + pix * a.ldr2 + n;
+              v0 += *reinterpret_cast<const f32x4*>(p2);
+              v1 += *reinterpret_cast<const f32x4*>(p2 + 4);
+            }
+            *reinterpret_cast<f32x4*>(a.out32 + pix * a.ldo32 + n) = v0;
+            *reinterpret_cast<f32x4*>(a.out32 + pix * a.ldo32 + n + 4) = v1;
+            if (a.out) {
+              f16x8_t hv;
+#pragma unroll
+              for (int k = 0; k < 4; ++k) { hv[k] = (_Float16)v0[k]; hv[4 + k] = (_Float16)v1[k]; }
+              *reinterpret_cast<f16x8_t*>(a.out + ((((long long)cb * nck + nb * 4 + ni * 2 + jj) * H + y) * W + x) * 16 + h * 8) = hv;
+            }
+          }
+      }
+      continue;
+    }
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi) {
       const int y = cy0 + mi, x = cx0 + r;
@@ -305,16 +366,16 @@ int ws_num_cus() {
   return cus;
 }
 
-template <int DBG>
+template <int DBG, bool RES = false>
 int ws_launch(const ws_args& a, int grid, hipStream_t st) {
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_c64_ws_kernel<DBG>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_c64_ws_kernel<DBG, RES>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, WS_LDS);
     if (e != hipSuccess) return (int)e;
     attr_set = true;
   }
-  hipLaunchKernelGGL((conv3x3_c64_ws_kernel<DBG>), dim3(grid), dim3(WS_THREADS), WS_LDS, st, a);
+  hipLaunchKernelGGL((conv3x3_c64_ws_kernel<DBG, RES>), dim3(grid), dim3(WS_THREADS), WS_LDS, st, a);
   return 0;
 }
 
@@ -362,6 +423,7 @@ extern "C" int cdfo_conv3x3_c64_ws(const void* src_cp16, int B, int H, int W, co
   a.w = static_cast<const unsigned short*>(w_f16); a.CoutP = CoutP;
   a.bias = bias; a.Cout = Cout; a.act = act;
   a.out = static_cast<_Float16*>(out_cp16); a.s2d = store_mode == CDFO_STORE_S2D;
+  a.out32 = nullptr; a.ldo32 = 0; a.res1 = nullptr; a.ldr1 = 0; a.res2 = nullptr; a.ldr2 = 0;
   a.clk = static_cast<unsigned long long*>(clk_probe);
   const double px = (double)B * H * W;
   CdfoProfScope prof(st, KID_CONV3_WS, 2.0 * px * Cout * 64 * 9, 2.0 * (px * Cout + px * 64) + 2.0 * 9 * 64 * Cout);
@@ -381,6 +443,39 @@ extern "C" int cdfo_conv3x3_c64_ws(const void* src_cp16, int B, int H, int W, co
     case 136: rc = ws_launch<136>(a, grid, st); break;
     default: return CDFO_EINVAL;
   }
+  if (rc) return rc;
+  CDFO_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int cdfo_conv3x3_c64_ws_res(const void* src_cp16, int B, int H, int W, const void* w_f16, int CoutP,
+                                       const float* bias, int Cout, int act, float* out, int ldo, const float* res1,
+                                       int ldr1, const float* res2, int ldr2, void* out2_cp16, void* stream) {
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (B <= 0 || H <= 0 || W <= 0 || (H & 1) || Cout <= 0 || Cout % 64 || CoutP < Cout || CoutP % 64) return CDFO_EINVAL;
+  if (act == CDFO_ACT_SIGMOID || !out || !res1 || ldo % 4 || ldo < Cout || ldr1 % 4 || ldr1 < Cout) return CDFO_EINVAL;
+  if (res2 && (ldr2 % 4 || ldr2 < Cout)) return CDFO_EINVAL;
+  const long long src_bytes = (long long)B * 4 * H * W * 32;
+  if (src_bytes >= (1ll << 31)) return CDFO_EINVAL;
+  if (!aligned16(src_cp16) || !aligned16(w_f16) || !aligned16(out) || !aligned16(res1) || (res2 && !aligned16(res2)) ||
+      (out2_cp16 && !aligned16(out2_cp16)))
+    return CDFO_EALIGN;
+  const int cus = ws_num_cus();
+  if (cus < 8) return CDFO_EINVAL;
+  const int nco = Cout / 64;
+  int qn = (cus / 8) / nco;
+  if (qn < 1) qn = 1;
+  ws_args a;
+  a.src = src_cp16; a.src_bytes = (unsigned)src_bytes;
+  a.B = B; a.H = H; a.W = W;
+  a.w = static_cast<const unsigned short*>(w_f16); a.CoutP = CoutP;
+  a.bias = bias; a.Cout = Cout; a.act = act;
+  a.out = static_cast<_Float16*>(out2_cp16); a.s2d = 0;
+  a.out32 = out; a.ldo32 = ldo; a.res1 = res1; a.ldr1 = ldr1; a.res2 = res2; a.ldr2 = ldr2;
+  a.clk = nullptr;
+  const double px = (double)B * H * W;
+  CdfoProfScope prof(st, KID_CONV3_WS, 2.0 * px * Cout * 64 * 9, px * (2.0 * 64 + 8.0 * Cout + (res2 ? 4.0 * Cout : 0.0)));
+  const int rc = ws_launch<0, true>(a, 8 * qn * nco, st);
   if (rc) return rc;
   CDFO_LAUNCH_CHECK();
   return 0;

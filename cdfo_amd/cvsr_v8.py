@@ -308,12 +308,12 @@ class CVSR_V8(nn.Module):
         rb = [w[a + n] for n in ("ResidualBlock.conv1", "ResidualBlock.conv2", "ResidualBlock1.conv1", "ResidualBlock1.conv2")]
         if self.precision == "fp16x2" and H % 2 == 0 and all(c.wh is not None for c in rb):
             # the two ResidualBlock_noBN (arch.py:261-262) on the Block_ kernels: conv1 + ReLU weights-stationary (fp16
-            # chunk-planar in and out), conv2 + residual on the LDS-DMA ring kernel; single-pass fp16 MFMA like the
+            # chunk-planar in and out), conv2 + residual on its residual form (fp32 pixel-major out); single-pass fp16 MFMA like the
             # convolutions inside Block_ (no measurable change of the forward's error: 2.80e-4 with and without)
             o16 = K.to_cp16(o)
             n16 = torch.empty_like(o16)
-            o = K.conv_ring(K.conv3x3_ws(o16, rb[0], act=K.ACT_RELU), rb[1], res1=o, out2_cp16=n16)
-            return K.conv_ring(K.conv3x3_ws(n16, rb[2], act=K.ACT_RELU), rb[3], res1=o, res2=xc, out=out)
+            o = K.conv3x3_ws_res(K.conv3x3_ws(o16, rb[0], act=K.ACT_RELU), rb[1], res1=o, out2_cp16=n16)
+            return K.conv3x3_ws_res(K.conv3x3_ws(n16, rb[2], act=K.ACT_RELU), rb[3], res1=o, res2=xc, out=out)
         r = self._conv(o, rb[0], pad=1, act=K.ACT_RELU)
         o = self._conv(r, rb[1], pad=1, res1=o)
         r = self._conv(o, rb[2], pad=1, act=K.ACT_RELU)

@@ -235,6 +235,46 @@ def conv3x3_ws(src: torch.Tensor, pc: PackedConv, *, act: int = ACT_NONE, s2d: b
     return out
 
 
+def conv3x3_ws_res(src: torch.Tensor, pc: PackedConv, *, res1: torch.Tensor, res2: Optional[torch.Tensor] = None,
+                   act: int = ACT_NONE, out: Optional[torch.Tensor] = None,
+                   out2_cp16: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Residual form of conv3x3_ws: fp32 pixel-major act(conv + bias) + res1 (+ res2); optionally also the fp16
+    chunk-planar copy of the result (out2_cp16 [B,Cout/16,H,W,16])."""
+    if not src.is_cuda:
+        raise NotImplementedError("conv3x3_ws_res: the HIP path needs device tensors (no CPU fallback)")
+    if src.dtype != torch.float16 or src.dim() != 5 or src.shape[1] != 4 or src.shape[4] != 16 or not src.is_contiguous():
+        raise ValueError(f"conv3x3_ws_res: expected a contiguous fp16 [B,4,H,W,16] source, got {src.dtype} {tuple(src.shape)}")
+    if pc.wh is None or pc.Cin != 64 or pc.ks != 3 or pc.Cout % 64:
+        raise ValueError("conv3x3_ws_res: needs a 3x3 weight with 64 input channels and Cout % 64 == 0")
+    B, _, H, W, _ = src.shape
+    if out is None:
+        out = empty_act(B, H, W, pc.Cout, src.device)
+    _, _, _, _, ldo = _chk_act(out, "out")
+    lds = []
+    for nm, t in (("res1", res1), ("res2", res2)):
+        if t is None:
+            lds.append(0)
+            continue
+        rb, rh, rw, rc, rld = _chk_act(t, nm)
+        if (rb, rh, rw) != (B, H, W) or rc < pc.Cout:
+            raise ValueError(f"{nm} shape {tuple(t.shape)} does not match the conv output")
+        lds.append(rld)
+    if out2_cp16 is not None and (out2_cp16.dtype != torch.float16 or not out2_cp16.is_contiguous()
+                                  or tuple(out2_cp16.shape) != (B, pc.Cout // 16, H, W, 16)):
+        raise ValueError("conv3x3_ws_res: out2_cp16 must be a contiguous fp16 [B,Cout/16,H,W,16] tensor")
+    per_img = 4 * H * W * 32
+    if per_img >= (1 << 31):
+        raise ValueError(f"conv3x3_ws_res: one {H}x{W} image exceeds the 2 GiB source limit of a launch")
+    step = max(1, min(B, ((1 << 31) - 1) // per_img))
+    for b0 in range(0, B, step):
+        sl = slice(b0, min(B, b0 + step))
+        check(_lib.lib().cdfo_conv3x3_c64_ws_res(
+            _vp(src[sl]), sl.stop - b0, H, W, _vp(pc.wh), pc.CoutP16, _vp(pc.bias), pc.Cout, act, _vp(out[sl]), ldo,
+            _vp(res1[sl]), lds[0], _vp(None if res2 is None else res2[sl]), lds[1],
+            _vp(None if out2_cp16 is None else out2_cp16[sl]), _stream()), "cdfo_conv3x3_c64_ws_res")
+    return out
+
+
 def from_cp16(t: torch.Tensor) -> torch.Tensor:
     """chunk-planar [B,C/16,H,W,16] -> pixel-major [B,H,W,C] (torch ops; tests and tools only)."""
     B, nc, H, W, _ = t.shape

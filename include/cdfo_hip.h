@@ -90,6 +90,12 @@ int cdfo_pack_conv3x3_f16(const float* w_oihw, void* packed, int Cout, int Cin, 
  * 64-bit words; else pass NULL).  */
 int cdfo_conv3x3_c64_ws(const void* src_cp16, int B, int H, int W, const void* w_f16, int CoutP, const float* bias,
                         int Cout, int act, void* out_cp16, int store_mode, int dbg, void* clk_probe, void* stream);
+/* Residual form of cdfo_conv3x3_c64_ws (ResidualBlock_noBN's second convolution, arch.py:261-262):
+ * out[B][H][W][ldo] (fp32, pixel-major) = act(conv + bias) + res1 (+ res2), res* fp32 pixel-major; optionally also the
+ * fp16 chunk-planar copy out2_cp16 [B][Cout/16][H][W][16] (NULL to skip).  */
+int cdfo_conv3x3_c64_ws_res(const void* src_cp16, int B, int H, int W, const void* w_f16, int CoutP, const float* bias,
+                            int Cout, int act, float* out, int ldo, const float* res1, int ldr1, const float* res2,
+                            int ldr2, void* out2_cp16, void* stream);
 /* 3x3 / stride 1 / pad 1 convolution of an fp16 chunk-planar source (a->src[0] = [B][Cin/16][H][W][16], a->src_f16 = 1,
  * a->ld[0] = 16, a->cs[0] = Cin) as a persistent kernel fed by an LDS-DMA ring: Block_.body[2] (256 -> 64) and the
  * composed stride-2 convolution of Block_'s double-resolution branch.  a->w: fp16 [Cin/16][taps][2][CoutP][8] with

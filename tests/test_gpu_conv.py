@@ -398,3 +398,21 @@ def test_conv_last(B, H, W):
     torch.cuda.synchronize()
     err = (out.cpu() - ref).abs().max().item()
     assert err < 2e-5 * max(1.0, ref.abs().max().item()), err
+
+
+@pytest.mark.parametrize("B,H,W,two", [(2, 16, 40, False), (1, 24, 70, True), (2, 272, 480, True)])
+def test_conv3x3_ws_residual_form(B, H, W, two):
+    """conv3x3_ws_res: fp32 pixel-major act(conv + bias) + res1 (+ res2) and the fp16 chunk-planar copy."""
+    from cdfo_amd import kernels as K
+    g = torch.Generator().manual_seed(B + H + W)
+    x = torch.randn(B, 64, H, W, generator=g)
+    w = torch.randn(64, 64, 3, 3, generator=g) / 24.0
+    b = torch.randn(64, generator=g)
+    r1, r2 = torch.randn(B, 64, H, W, generator=g), torch.randn(B, 64, H, W, generator=g)
+    ref = F.conv2d(x.half().float(), w.half().float(), b, padding=1) + r1 + (r2 if two else 0)
+    o16 = torch.zeros(B, 4, H, W, 16, dtype=torch.float16, device="cuda")
+    out = K.conv3x3_ws_res(K.to_cp16(_nhwc(x).cuda()), K.pack_conv(w.cuda(), b.cuda()), res1=_nhwc(r1).cuda(),
+                           res2=_nhwc(r2).cuda() if two else None, out2_cp16=o16)
+    torch.cuda.synchronize()
+    _cmp(out, ref, 1e-4, "ws conv, residual form")
+    assert torch.equal(K.from_cp16(o16), out.half())

@@ -8,7 +8,7 @@
 //     halo (20 pieces of 1 KiB) and the chunk's weight slab (18 pieces; 8 when only four taps carry weights) are
 //     copied global -> LDS by LDS-DMA (buffer_load_dwordx4 ... lds), four or five instructions per wave and chunk,
 //     issued one at a time BETWEEN the taps' MFMAs -- no staging registers, no ds_write pass;
-//   * four ring stages, three chunks (85-115 KB per CU) in flight -- the activations come from HBM, and at its ~4 us
+//   * three or four ring stages, two or three chunks (56-115 KB per CU) in flight -- the activations come from HBM, and at its ~4 us
 //     loaded latency two chunks in flight capped the chip at ~3.5 TB/s --, ONE workgroup barrier per chunk (the tiled
 //     kernel needs two and restages through VGPRs); the ring runs across tile boundaries, so the epilogue of one
 //     tile overlaps the loads of the next;
@@ -29,12 +29,16 @@ namespace {
 constexpr int RG_THREADS = 512;
 constexpr int RG_TH = 16, RG_IW = 34, RG_NPIX = 18 * 34;   // 612 staged pixels per chunk
 constexpr int RG_ACT = 20 * 1024;                          // 20 DMA pieces (612 x 32 B = 19,584 B + pad slots)
-constexpr int RG_NS = 4;                                   // ring stages: three chunk batches in flight
-// LDS map: RG_NS ring stages (dense 38 KB, four-tap form 28 KB) | 1 KB dump | 4 KB bias
+constexpr int RG_ET_ROWS = 10, RG_ET_COLS = 18;            // half-resolution residual region of a 16 x 32 tile (+ taps)
+constexpr int RG_ET_PIECES = 48;                           // 180 pixels x 256 B = 45 KiB, 6 DMA pieces per wave
+// LDS map: NS ring stages (dense: 4 x 38 KB; four-tap form: 3 x 28 KB) | [four-tap form: 48 KB half-resolution residual
+// tile] | 1 KB dump | 4 KB bias
 template <bool SPARSE> struct RingLds {
+  static constexpr int NS = SPARSE ? 3 : 4;                                       // NS - 1 chunk batches in flight
   static constexpr int WGT = (SPARSE ? 8 : 18) * 1024;
   static constexpr int STAGE = RG_ACT + WGT;
-  static constexpr int DUMP = RG_NS * STAGE;                                      // target of the padding DMA pieces
+  static constexpr int ETILE = NS * STAGE;
+  static constexpr int DUMP = ETILE + (SPARSE ? RG_ET_PIECES * 1024 : 0);         // target of the padding DMA pieces
   static constexpr int BIAS = DUMP + 1024;
   static constexpr int TOTAL = BIAS + 4096;
 };
@@ -84,7 +88,7 @@ __global__ __launch_bounds__(RG_THREADS) void conv3x3_ring_kernel(cdfo_conv_args
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int TAPS = SPARSE ? 4 : 9;
   using L = RingLds<SPARSE>;
-  constexpr int STAGE = L::STAGE;
+  constexpr int STAGE = L::STAGE, RG_NS = L::NS;
   // DMA pieces per wave and chunk.  dense: waves 0-3 copy the 20 activation pieces, waves 4-7 the 18 weight pieces
   // (+2 padding pieces into the dump kilobyte, so that every loader issues exactly PPW instructions per chunk);
   // four-tap form: waves 0-4 the activations, waves 5-6 the 8 weight pieces, wave 7 none.
@@ -225,19 +229,41 @@ __global__ __launch_bounds__(RG_THREADS) void conv3x3_ring_kernel(cdfo_conv_args
     int b, oy0, ox0, n0;
     unit_coords(ord, b, oy0, ox0, n0);
     const int oyw = oy0 + wave * 2;
+    // half-resolution residual tile: local pixel (i, j) = clamped source pixel (oy0/2 - 1 + i, ox0/2 - 1 + j); LDS slot
+    // (pixel, 16-byte part q ^ (pixel & 15)) so that the epilogue's b128 reads of neighbouring pixels do not conflict
+    unsigned evoff[RG_ET_PIECES / 8];
+    i32x4 ersrc = rsrc_w;
+    const unsigned edst = lds0 + (unsigned)L::ETILE + (unsigned)(wave * (RG_ET_PIECES / 8)) * 1024u;
+    if (SPARSE && a.res_up2) {
+      const int Hd = H >> 1, Wd = W >> 1;
+      ersrc = rg_rsrc(a.res_up2 + (long long)b * Hd * Wd * a.ldru, (unsigned)(Hd * Wd * a.ldru) * 4u);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) ersrc[k] = __builtin_amdgcn_readfirstlane(ersrc[k]);
+#pragma unroll
+      for (int j = 0; j < RG_ET_PIECES / 8; ++j) {
+        const int slot = (wave * (RG_ET_PIECES / 8) + j) * 64 + lane;      // 16-byte slot of the tile image
+        const int px = slot >> 4, q = (slot & 15) ^ (px & 15);
+        const int ei = px / RG_ET_COLS, ej = px - ei * RG_ET_COLS;
+        int gy = (oy0 >> 1) - 1 + ei, gx = (ox0 >> 1) - 1 + ej;
+        gy = gy < 0 ? 0 : (gy >= Hd ? Hd - 1 : gy);
+        gx = gx < 0 ? 0 : (gx >= Wd ? Wd - 1 : gx);
+        evoff[j] = px < RG_ET_ROWS * RG_ET_COLS ? (unsigned)((gy * Wd + gx) * a.ldru + n0 + q * 4) * 4u : 0x80000000u;
+      }
+    }
 
     // one chunk: wait + barrier, then the taps' MFMAs with the pieces of batch g+3 issued between them (a DMA
     // instruction takes 100-200 cycles to issue; behind a tap's four MFMAs that time is covered by the matrix pipe)
     auto chunk = [&](int c) {
-      // (1) my pieces of batch g have landed: the younger DMA batches g+1, g+2 are 2 PPW instructions, and DMA pieces
+      // (1) my pieces of batch g have landed: the younger DMA batches are (NS - 2) PPW instructions, and DMA pieces
       //     retire in issue order among themselves.  Other vector-memory operations (epilogue stores, residual loads) are
       //     NOT counted: LDS-DMA loads do not retire in order relative to VGPR loads (measured in conv3x3_ws.hip), so
-      //     "at most 2 PPW outstanding" is the only bound that implies batch g has landed whatever else is in flight.
+      //     "at most (NS - 2) PPW outstanding" is the only bound that implies batch g has landed whatever else is in flight.
       //     (2) my fragment reads of batch g-1 have RETURNED (its stage is overwritten after the barrier).  Then the
       //     barrier: everyone's pieces of g are in LDS, nobody still reads the stage of g-1.
-      if (g + 2 >= total) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-      else if (PPW == 5) asm volatile("s_waitcnt vmcnt(10) lgkmcnt(0)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+      if (g + RG_NS - 2 >= total) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      else if ((RG_NS - 2) * PPW == 10) asm volatile("s_waitcnt vmcnt(10) lgkmcnt(0)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+      static_assert((RG_NS - 2) * PPW == 10 || (RG_NS - 2) * PPW == 4, "counted wait immediates");
       __builtin_amdgcn_s_barrier();
       const bool do_issue = g + RG_NS - 1 < total;     // batch g+3 -> the stage batch g-1 lived in
       if (do_issue) issue_begin();
@@ -297,6 +323,13 @@ __global__ __launch_bounds__(RG_THREADS) void conv3x3_ring_kernel(cdfo_conv_args
         }
       }
       if (do_issue) issue_end();
+      // half-resolution residual tile of THIS output tile (consumed by its epilogue, 60+ chunks from now): 48 DMA
+      // pieces, 6 per wave.  Younger than this chunk's batch, so the counted waits above (which only allow the newest
+      // (NS - 2) PPW pieces to be pending) retire them within the next two chunks.
+      if (SPARSE && c == 0 && a.res_up2 && !(DBG & 2)) {
+#pragma unroll
+        for (int j = 0; j < RG_ET_PIECES / 8; ++j) rg_dma1(evoff[j], ersrc, 0u, __builtin_amdgcn_readfirstlane(edst + j * 1024));
+      }
     };
 
     for (int c = 0; c < nc - 1; ++c, ++g) chunk(c);
@@ -369,20 +402,35 @@ __global__ __launch_bounds__(RG_THREADS) void conv3x3_ring_kernel(cdfo_conv_args
             v1 += *reinterpret_cast<const f32x4*>(p2 + 4);
           }
           if (a.res_up2) {      // + bilinear x2 of a half-resolution tensor: taps (Q-1, Q) x (P-1, P), clamped
-            const int Hd = H >> 1, Wd = W >> 1;
-            const int Q = (oy + 1) >> 1, P = (X + 1) >> 1;
-            const int ya = Q > 0 ? Q - 1 : 0, yb = Q < Hd ? Q : Hd - 1, xa = P > 0 ? P - 1 : 0, xb = P < Wd ? P : Wd - 1;
             const float ly = (oy & 1) ? 0.25f : 0.75f, lx = (X & 1) ? 0.25f : 0.75f;
-            const float* eb = a.res_up2 + (long long)b * Hd * Wd * a.ldru + n;
-            const float* paa = eb + ((long long)ya * Wd + xa) * a.ldru;
-            const float* pab = eb + ((long long)ya * Wd + xb) * a.ldru;
-            const float* pba = eb + ((long long)yb * Wd + xa) * a.ldru;
-            const float* pbb = eb + ((long long)yb * Wd + xb) * a.ldru;
+            if (SPARSE) {       // from the staged tile: local tap rows Q - oy0/2 (+1), columns P - ox0/2 (+1)
+              const int li = ((oy + 1) >> 1) - (oy0 >> 1), lj = ((X + 1) >> 1) - (ox0 >> 1);
+              const unsigned char* et = smem + L::ETILE;
+              const int cq = (ni * 32 + jj * 16 + h * 8) >> 2;          // 16-byte part of the tile's 64 channels
 #pragma unroll
-            for (int hf = 0; hf < 2; ++hf) {
-              const f32x4 eaa = *reinterpret_cast<const f32x4*>(paa + 4 * hf), eab = *reinterpret_cast<const f32x4*>(pab + 4 * hf);
-              const f32x4 eba = *reinterpret_cast<const f32x4*>(pba + 4 * hf), ebb = *reinterpret_cast<const f32x4*>(pbb + 4 * hf);
-              (hf ? v1 : v0) += (1.f - ly) * ((1.f - lx) * eaa + lx * eab) + ly * ((1.f - lx) * eba + lx * ebb);
+              for (int hf = 0; hf < 2; ++hf) {
+                auto tap = [&](int i, int j) {
+                  const int px = i * RG_ET_COLS + j;
+                  return *reinterpret_cast<const f32x4*>(et + px * 256 + (((cq + hf) ^ (px & 15)) << 4));
+                };
+                (hf ? v1 : v0) += (1.f - ly) * ((1.f - lx) * tap(li, lj) + lx * tap(li, lj + 1)) +
+                                  ly * ((1.f - lx) * tap(li + 1, lj) + lx * tap(li + 1, lj + 1));
+              }
+            } else {
+              const int Hd = H >> 1, Wd = W >> 1;
+              const int Q = (oy + 1) >> 1, P = (X + 1) >> 1;
+              const int ya = Q > 0 ? Q - 1 : 0, yb = Q < Hd ? Q : Hd - 1, xa = P > 0 ? P - 1 : 0, xb = P < Wd ? P : Wd - 1;
+              const float* eb = a.res_up2 + (long long)b * Hd * Wd * a.ldru + n;
+              const float* paa = eb + ((long long)ya * Wd + xa) * a.ldru;
+              const float* pab = eb + ((long long)ya * Wd + xb) * a.ldru;
+              const float* pba = eb + ((long long)yb * Wd + xa) * a.ldru;
+              const float* pbb = eb + ((long long)yb * Wd + xb) * a.ldru;
+#pragma unroll
+              for (int hf = 0; hf < 2; ++hf) {
+                const f32x4 eaa = *reinterpret_cast<const f32x4*>(paa + 4 * hf), eab = *reinterpret_cast<const f32x4*>(pab + 4 * hf);
+                const f32x4 eba = *reinterpret_cast<const f32x4*>(pba + 4 * hf), ebb = *reinterpret_cast<const f32x4*>(pbb + 4 * hf);
+                (hf ? v1 : v0) += (1.f - ly) * ((1.f - lx) * eaa + lx * eab) + ly * ((1.f - lx) * eba + lx * ebb);
+              }
             }
           }
           f16x8_t hv;

@@ -384,6 +384,36 @@ def test_conv3x3_ring_half_resolution_residual():
     _cmp(out, ref, 1e-4, "ring conv + half-resolution residual")
 
 
+@pytest.mark.parametrize("B,H,W", [(2, 36, 44), (1, 64, 96), (2, 272, 480)])
+def test_conv3x3_ring_sparse_taps_with_residuals(B, H, W):
+    """Four-tap form with every epilogue input of Block_'s last convolution: res1, the half-resolution residual (staged
+    in LDS by DMA in this form) and the fp16 chunk-planar second output; several tiles per workgroup at 272 x 480."""
+    from cdfo_amd import kernels as K
+    g = torch.Generator().manual_seed(B + H + W)
+    Cin, Cout = 128, 64
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / (Cin * 4) ** 0.5
+    masks = []
+    for c in range(Cin // 16):
+        y0, x0 = (c >> 1) & 1, c & 1
+        masks.append(sum(1 << ((y0 + dy) * 3 + x0 + dx) for dy in range(2) for dx in range(2)))
+        keep = torch.zeros(3, 3)
+        keep[y0:y0 + 2, x0:x0 + 2] = 1
+        w[:, c * 16:(c + 1) * 16] *= keep
+    b = torch.randn(Cout, generator=g)
+    r1 = torch.randn(B, Cout, H, W, generator=g)
+    e = torch.randn(B, Cout, H // 2, W // 2, generator=g)
+    ref = F.conv2d(x.half().float(), w.half().float(), b, padding=1) + r1 + \
+        F.interpolate(e, scale_factor=2, mode="bilinear", align_corners=False)
+    pc = K.pack_conv(w.cuda(), b.cuda())
+    pc.tap_mask = torch.tensor(masks, dtype=torch.int32, device="cuda")
+    o16 = torch.zeros(B, Cout // 16, H, W, 16, dtype=torch.float16, device="cuda")
+    out = K.conv_ring(K.to_cp16(_nhwc(x).cuda()), pc, res1=_nhwc(r1).cuda(), res_up2=_nhwc(e).cuda(), out2_cp16=o16)
+    torch.cuda.synchronize()
+    _cmp(out, ref, 1e-4, "ring conv, four taps + residuals")
+    assert torch.equal(K.from_cp16(o16), out.half())
+
+
 @pytest.mark.parametrize("B,H,W", [(2, 8, 24), (1, 12, 40)])
 def test_conv_last(B, H, W):
     """conv_last (3x3, 64 -> 1) + bilinear x4 of the centre LR frame (arch.py:4476-4480)."""

@@ -43,7 +43,20 @@ __device__ __forceinline__ void split_store(unsigned char* dst_hi, int lo_delta,
   *reinterpret_cast<u32x2*>(dst_hi + lo_delta) = lo;
 }
 
-template <int NCB>   // number of 64-wide output-channel blocks (1..4)
+__device__ __forceinline__ float c1_row16_sum(float v) {  // sum over the 16 lanes of a DPP row, result in every lane
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x124, 0xF, 0xF, true));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xF, 0xF, true));
+  return v;
+}
+
+// NCB: number of 64-wide output-channel blocks (1..4).
+// TAPS (CDFO_STORE_TAPS9, upconv2 of arch.py:4474-4476 only): instead of the pixel-shuffled 64-channel HR feature map,
+// store for every HR pixel the nine per-tap channel sums t_k = sum_c w_last[c][k] * act(y)[c] of the 3x3 conv_last that
+// follows: 36 bytes per HR pixel instead of 256 (the 4.3 GB HR map is never written nor read back).  The 16 lanes that
+// hold one HR pixel's 64 channels are one DPP row.
+template <int NCB, bool TAPS = false>
 __global__ __launch_bounds__(256, 2) void conv1x1_bf16x3_kernel(cdfo_conv_args a) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[A_BYTES + W_BYTES];
   unsigned char* sA = smem;
@@ -136,6 +149,13 @@ __global__ __launch_bounds__(256, 2) void conv1x1_bf16x3_kernel(cdfo_conv_args a
   const int c4 = lane & 15, pr = lane >> 4;                  // 16 float4 columns, 4 pixel rows per wave-instruction
   const bool plain = a.store_mode == CDFO_STORE_PLAIN;
   const int cq = a.Cout >> 2;
+  f32x4 wl9[TAPS ? 9 : 1];                                   // conv_last taps of this lane's 4 channels (a.res2 = [64][9])
+  if (TAPS) {
+#pragma unroll
+    for (int k = 0; k < 9; ++k)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) wl9[k][j] = a.res2[(c4 * 4 + j) * 9 + k];
+  }
 #pragma unroll
   for (int cb = 0; cb < NCB; ++cb) {
 #pragma unroll
@@ -158,6 +178,19 @@ __global__ __launch_bounds__(256, 2) void conv1x1_bf16x3_kernel(cdfo_conv_args a
       const long long pin = p0 + wave * 32 + i;               // pixel inside the image
       if (!nok || pin >= P) continue;
       const long long pix = (long long)b * P + pin;
+      if (TAPS) {        // block cb = sub-pixel (dy, dx) = (cb >> 1, cb & 1); lane c4 < 9 stores tap sum c4
+        float mine = 0.f;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+          const f32x4 pr4 = t * wl9[k];
+          const float sk = c1_row16_sum((pr4[0] + pr4[1]) + (pr4[2] + pr4[3]));
+          mine = c4 == k ? sk : mine;
+        }
+        const int oy = (int)(pin / a.W), ox = (int)(pin - (long long)oy * a.W);
+        const long long opix = ((long long)b * 2 * a.H + 2 * oy + (cb >> 1)) * (2 * a.W) + 2 * ox + (cb & 1);
+        if (c4 < 9) a.out[opix * a.ldo + c4] = mine;
+        continue;
+      }
       if (plain) {
         if (a.res1) t += *reinterpret_cast<const f32x4*>(a.res1 + pix * a.ldr1 + n);
         if (a.res2) t += *reinterpret_cast<const f32x4*>(a.res2 + pix * a.ldr2 + n);
@@ -190,13 +223,20 @@ extern "C" int cdfo_conv1x1_bf16x3(const cdfo_conv_args* pa, void* stream) {
   if (csum != a.Cin || a.CoutP % 64 || a.CoutP > 64 * MAXCB || a.CoutP < a.Cout || a.Cout <= 0 || a.Cout % 4) return CDFO_EINVAL;
   if (a.Ho != a.H || a.Wo != a.W) return CDFO_EINVAL;
   if (a.store_mode == CDFO_STORE_S2D || (a.store_mode == CDFO_STORE_SHUFFLE2 && (a.Cout % 16 || a.res1 || a.res2))) return CDFO_EINVAL;
-  if (!aligned16(a.w) || a.w_bstride % 4 || a.ldo % 4 || !aligned16(a.out) || (a.bias && !aligned16(a.bias))) return CDFO_EALIGN;
-  if ((a.res1 && (a.ldr1 % 4 || !aligned16(a.res1))) || (a.res2 && (a.ldr2 % 4 || !aligned16(a.res2)))) return CDFO_EALIGN;
+  if (a.store_mode == CDFO_STORE_TAPS9 && (a.Cout != 256 || a.CoutP != 256 || a.res1 || !a.res2 || a.ldo < 9 || a.w_bstride)) return CDFO_EINVAL;
+  const bool taps = a.store_mode == CDFO_STORE_TAPS9;
+  if (!aligned16(a.w) || a.w_bstride % 4 || (!taps && a.ldo % 4) || !aligned16(a.out) || (a.bias && !aligned16(a.bias))) return CDFO_EALIGN;
+  if ((a.res1 && (a.ldr1 % 4 || !aligned16(a.res1))) || (!taps && a.res2 && (a.ldr2 % 4 || !aligned16(a.res2)))) return CDFO_EALIGN;
   if (a.ln_gamma && !(a.nsrc == 1 && a.cs[0] == 64 && a.ln_beta && aligned16(a.ln_gamma) && aligned16(a.ln_beta))) return CDFO_EINVAL;
   const long long P = (long long)a.H * a.W;
   dim3 grid((unsigned)((P + PXT - 1) / PXT), a.B);
   const double px = (double)a.B * P;
   CdfoProfScope prof(st, KID_CONV1, 2.0 * px * a.Cout * a.Cin, 4.0 * (px * a.Cout + px * a.Cin + (double)a.Cin * a.Cout));
+  if (taps) {
+    hipLaunchKernelGGL((conv1x1_bf16x3_kernel<4, true>), grid, dim3(256), 0, st, a);
+    CDFO_LAUNCH_CHECK();
+    return 0;
+  }
   switch (a.CoutP / 64) {
     case 1: hipLaunchKernelGGL(conv1x1_bf16x3_kernel<1>, grid, dim3(256), 0, st, a); break;
     case 2: hipLaunchKernelGGL(conv1x1_bf16x3_kernel<2>, grid, dim3(256), 0, st, a); break;

@@ -373,6 +373,43 @@ __global__ __launch_bounds__(256) void conv_last_kernel(const float* __restrict_
   }
 }
 
+// second half of the fused upsampler tail: out = bias + sum_k taps[(y + dy - 1, x + dx - 1)][k] + bilinear_x4(x_center)
+__global__ __launch_bounds__(256) void conv_last_taps_kernel(const float* __restrict__ taps, int ldt,
+                                                             const float* __restrict__ bias,
+                                                             const float* __restrict__ xc, long long xc_bstride, int B,
+                                                             int Hh, int Wh, float* __restrict__ out) {
+  const float b0 = bias[0];
+  const int H = Hh >> 2, W = Wh >> 2;
+  const long long total = (long long)B * Hh * Wh;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int x = i % Wh;
+    const int y = (i / Wh) % Hh;
+    const long long b = i / ((long long)Wh * Hh);
+    float s = 0.f;
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy) {
+      const int yy = y + dy - 1;
+      if (yy < 0 || yy >= Hh) continue;
+#pragma unroll
+      for (int dx = 0; dx < 3; ++dx) {
+        const int xx = x + dx - 1;
+        if (xx < 0 || xx >= Wh) continue;
+        s += taps[((b * Hh + yy) * Wh + xx) * ldt + dy * 3 + dx];
+      }
+    }
+    float sy = ((float)y + 0.5f) * 0.25f - 0.5f, sx = ((float)x + 0.5f) * 0.25f - 0.5f;
+    sy = sy < 0.f ? 0.f : sy;
+    sx = sx < 0.f ? 0.f : sx;
+    const int yy0 = (int)sy, xx0 = (int)sx;
+    const int yy1 = yy0 + (yy0 < H - 1 ? 1 : 0), xx1 = xx0 + (xx0 < W - 1 ? 1 : 0);
+    const float ly = sy - (float)yy0, lx = sx - (float)xx0;
+    const float* c = xc + b * xc_bstride;
+    const float base = (1.f - ly) * ((1.f - lx) * c[(long long)yy0 * W + xx0] + lx * c[(long long)yy0 * W + xx1]) +
+                       ly * ((1.f - lx) * c[(long long)yy1 * W + xx0] + lx * c[(long long)yy1 * W + xx1]);
+    out[i] = (s + b0) + base;
+  }
+}
+
 inline int grid_for(long long threads) {
   long long blocks = (threads + 255) / 256;
   return (int)(blocks < 1 ? 1 : (blocks > 8192 ? 8192 : blocks));
@@ -475,6 +512,16 @@ extern "C" int cdfo_conv_last(const float* in, int ldi, const float* w, const fl
   const long long ntiles = (long long)B * cdiv(Hh, CL_TY) * cdiv(Wh, CL_TX);
   hipLaunchKernelGGL(conv_last_kernel, dim3((unsigned)(ntiles < 4096 ? ntiles : 4096)), dim3(256), 0,
                      static_cast<hipStream_t>(stream), in, ldi, w, bias, xc, xc_bstride, B, Hh, Wh, out);
+  CDFO_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int cdfo_conv_last_taps(const float* taps, int ldt, const float* bias, const float* xc, long long xc_bstride,
+                                   int B, int Hh, int Wh, float* out, void* stream) {
+  if (B <= 0 || (Hh & 3) || (Wh & 3) || ldt < 9 || !taps || !bias || !xc || !out) return CDFO_EINVAL;
+  CdfoProfScope prof(static_cast<hipStream_t>(stream), KID_CONV_LAST, 2.0*9*(double)B*Hh*Wh, 4.0*(ldt + 1)*(double)B*Hh*Wh);
+  hipLaunchKernelGGL(conv_last_taps_kernel, dim3(grid_for((long long)B * Hh * Wh)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), taps, ldt, bias, xc, xc_bstride, B, Hh, Wh, out);
   CDFO_LAUNCH_CHECK();
   return 0;
 }

@@ -439,8 +439,11 @@ class CVSR_V8(nn.Module):
         if self.debug_taps is not None:
             self.debug_taps.update(L1_fea=L1, fused=fused, trunk=t)
         t = self._conv(t, w["upconv1"], act=K.ACT_LRELU)
-        t = self._conv(t, w["upconv2"], act=K.ACT_LRELU)
-        out = K.conv_last(t, raw["conv_last.weight"], raw["conv_last.bias"], x[:, ctr], N * P)
+        if self.precision == "f32":
+            t = self._conv(t, w["upconv2"], act=K.ACT_LRELU)
+            out = K.conv_last(t, raw["conv_last.weight"], raw["conv_last.bias"], x[:, ctr], N * P)
+        else:   # upconv2 writes conv_last's nine per-tap channel sums instead of the 64-channel HR map
+            out = K.upconv_last(t, w["upconv2"], raw["conv_last.weight"], raw["conv_last.bias"], x[:, ctr], N * P)
         return out, L1.permute(0, 3, 1, 2)
 
     @staticmethod

@@ -469,6 +469,29 @@ def scale_channels(x: torch.Tensor, gate: torch.Tensor) -> torch.Tensor:
     return out
 
 
+def upconv_last(x: torch.Tensor, pc: PackedConv, w_last: torch.Tensor, b_last: torch.Tensor, xc: torch.Tensor,
+                xc_bstride: int) -> torch.Tensor:
+    """Upsampler tail (arch.py:4474-4480) without the HR feature map: lrelu(pixel_shuffle(upconv2(x))) -> conv_last ->
+    + bilinear_x4(x_center).  x: [B,2H,2W,64]; pc: upconv2 packed with shuffle2=True; returns [B,1,4H,4W]."""
+    B, H2, W2, Cc, ld = _chk_act(x)
+    if not pc.shuffle2 or pc.Cout != 256 or pc.Cin != Cc or pc.ks != 1:
+        raise ValueError("upconv_last: needs the pixel-shuffle packing of a 1x1 conv with 256 outputs")
+    taps = torch.empty((B, 2 * H2, 2 * W2, 12), dtype=torch.float32, device=x.device)
+    a = ConvArgs()
+    a.src[0], a.ld[0], a.cs[0], a.nsrc = x.data_ptr(), ld, Cc, 1
+    a.B, a.H, a.W, a.Ho, a.Wo = B, H2, W2, H2, W2
+    a.ks, a.stride, a.pad = 1, 1, 0
+    a.Cin, a.Cout, a.CoutP = pc.Cin, pc.Cout, pc.CoutP
+    a.w, a.bias, a.act = pc.w.data_ptr(), _p(pc.bias), ACT_LRELU
+    a.res2 = w_last.detach().contiguous().float().data_ptr()
+    a.out, a.ldo, a.store_mode = taps.data_ptr(), 12, 3
+    check(_lib.lib().cdfo_conv1x1_bf16x3(C.byref(a), _stream()), "cdfo_conv1x1_bf16x3 (tap sums)")
+    out = torch.empty((B, 1, 2 * H2, 2 * W2), dtype=torch.float32, device=x.device)
+    check(_lib.lib().cdfo_conv_last_taps(_vp(taps), 12, _vp(b_last), _vp(xc), C.c_longlong(xc_bstride), B, 2 * H2, 2 * W2,
+                                         _vp(out), _stream()), "cdfo_conv_last_taps")
+    return out
+
+
 def conv_last(x: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, xc: torch.Tensor, xc_bstride: int) -> torch.Tensor:
     B, Hh, Wh, Cc, ld = _chk_act(x)
     assert Cc == 64

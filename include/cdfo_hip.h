@@ -24,7 +24,7 @@ extern "C" {
 #define CDFO_MAXSRC 8
 
 enum { CDFO_ACT_NONE = 0, CDFO_ACT_LRELU = 1, CDFO_ACT_RELU = 2, CDFO_ACT_SIGMOID = 3 };
-enum { CDFO_STORE_PLAIN = 0, CDFO_STORE_SHUFFLE2 = 1, CDFO_STORE_S2D = 2 };
+enum { CDFO_STORE_PLAIN = 0, CDFO_STORE_SHUFFLE2 = 1, CDFO_STORE_S2D = 2, CDFO_STORE_TAPS9 = 3 };
 enum { CDFO_PREC_F32 = 0, CDFO_PREC_BF16X3 = 1, CDFO_PREC_BF16 = 2, CDFO_PREC_FP16X2 = 3, CDFO_PREC_FP16 = 4, CDFO_PREC_FP16X1 = 5 };
 
 /* ABI version / build info.  */
@@ -110,6 +110,12 @@ int cdfo_to_cp16(const float* in, int ldi, int B, long long P, int C, void* out_
  * residuals, pixel-shuffle store).  Every source must be a multiple of 64 channels, CoutP a multiple of 64 (<= 256).  */
 int cdfo_conv1x1_bf16x3(const cdfo_conv_args* a, void* stream);
 
+/* Upsampler tail without the HR feature map (arch.py:4474-4480).  cdfo_conv1x1_bf16x3 with a->store_mode =
+ * CDFO_STORE_TAPS9 (upconv2: Cout = 256, pixel-shuffle weight packing, LeakyReLU; a->res2 = conv_last.weight
+ * [1][64][3][3]) stores for every HR pixel the nine per-tap channel sums of conv_last into out[B][2H][2W][ldo >= 9];
+ * cdfo_conv_last_taps then forms out[b][y][x] = bias + sum_k taps[(y,x) + delta_k][k] + bilinear_x4(x_center).  */
+int cdfo_conv_last_taps(const float* taps, int ldt, const float* bias, const float* xc, long long xc_bstride, int B, int Hh,
+                        int Wh, float* out, void* stream);
 /* Layout changes at the module boundary (reference tensors are NCHW).  */
 int cdfo_nchw_to_nhwc(const float* in, float* out, int B, int C, int H, int W, int ldo, void* stream);
 int cdfo_nhwc_to_nchw(const float* in, int ldi, float* out, int B, int C, int H, int W, void* stream);

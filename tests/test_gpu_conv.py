@@ -446,3 +446,21 @@ def test_conv3x3_ws_residual_form(B, H, W, two):
     torch.cuda.synchronize()
     _cmp(out, ref, 1e-4, "ws conv, residual form")
     assert torch.equal(K.from_cp16(o16), out.half())
+
+
+@pytest.mark.parametrize("B,H,W", [(2, 8, 24), (1, 12, 44)])
+def test_upconv_last_fused_tail(B, H, W):
+    """upconv2 + PixelShuffle + LeakyReLU + conv_last + bilinear x4 skip, without the HR feature map."""
+    from cdfo_amd import kernels as K
+    g = torch.Generator().manual_seed(B + H + W)
+    x2 = torch.randn(B, 64, 2 * H, 2 * W, generator=g)          # features at 2x resolution
+    wu, bu = torch.randn(256, 64, 1, 1, generator=g) / 8.0, torch.randn(256, generator=g) * 0.1
+    wl, bl = torch.randn(1, 64, 3, 3, generator=g) / 24.0, torch.randn(1, generator=g)
+    xc = torch.rand(B, 1, H, W, generator=g)
+    hr = F.leaky_relu(F.pixel_shuffle(F.conv2d(x2, wu, bu), 2), 0.1)
+    ref = F.conv2d(hr, wl, bl, padding=1) + F.interpolate(xc, scale_factor=4, mode="bilinear", align_corners=False)
+    pc = K.pack_conv(wu.cuda(), bu.cuda(), shuffle2=True)
+    out = K.upconv_last(_nhwc(x2).cuda(), pc, wl.cuda(), bl.cuda(), xc.cuda().contiguous(), H * W)
+    torch.cuda.synchronize()
+    err = (out.cpu() - ref).abs().max().item()
+    assert err < 3e-5 * max(1.0, ref.abs().max().item()), err

@@ -48,7 +48,7 @@ def test_dwconv3x3(C, H, W):
     assert (out.permute(0, 3, 1, 2).cpu() - ref).abs().max().item() < 1e-5
 
 
-@pytest.mark.parametrize("B,H,W", [(2, 12, 30), (1, 17, 45), (3, 8, 64)])
+@pytest.mark.parametrize("B,H,W", [(2, 12, 30), (1, 17, 45), (3, 8, 64), (1, 5, 7), (2, 6, 121)])
 def test_qkv_dw_fused(B, H, W):
     """LayerNorm -> 1x1 (64->192) -> depthwise 3x3 in one kernel vs the same chain in torch-cpu fp32."""
     import torch.nn.functional as F

@@ -238,6 +238,8 @@ WS_CASES = [
     (128, 6, 34, 3, False, 2),
     (256, 36, 52, 2, True, 1),
     (256, 272, 480, 2, True, 1),
+    (64, 2, 8, 1, False, 1),       # a single tile row, narrower than a tile
+    (64, 8, 200, 3, False, 0),
 ]
 
 
@@ -274,6 +276,8 @@ RING_CASES = [
     (128, 128, 34, 70, 2, True, False),     # two output blocks, ragged tile edges in both directions
     (64, 64, 48, 96, 2, False, True),
     (256, 64, 272, 480, 2, True, False),    # more tiles than workgroups: ring runs across tile boundaries
+    (64, 64, 8, 8, 1, True, False),         # smaller than one tile
+    (32, 64, 18, 200, 3, True, False),      # two chunks only, ragged right edge
 ]
 
 
@@ -351,7 +355,7 @@ def test_conv3x3_ring_second_output_chunk_planar():
     assert torch.equal(K.from_cp16(o16), out.half())
 
 
-@pytest.mark.parametrize("B,H,W", [(2, 12, 30), (1, 16, 44), (2, 8, 64)])
+@pytest.mark.parametrize("B,H,W", [(2, 12, 30), (1, 16, 44), (2, 8, 64), (1, 8, 8), (3, 10, 202)])
 def test_block_prologue(B, H, W):
     """u16 = bilinear_x2(up.0(x)), d16 = down.0(mean2x2(x)) vs the reference order of operations in torch-cpu
     (arch.py:378-406: up.0 / down.0 are applied AFTER the resampling there; they commute with it)."""

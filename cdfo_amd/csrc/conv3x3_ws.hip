@@ -474,7 +474,7 @@ extern "C" int cdfo_conv3x3_c64_ws_res(const void* src_cp16, int B, int H, int W
   a.out32 = out; a.ldo32 = ldo; a.res1 = res1; a.ldr1 = ldr1; a.res2 = res2; a.ldr2 = ldr2;
   a.clk = nullptr;
   const double px = (double)B * H * W;
-  CdfoProfScope prof(st, KID_CONV3_WS, 2.0 * px * Cout * 64 * 9, px * (2.0 * 64 + 8.0 * Cout + (res2 ? 4.0 * Cout : 0.0)));
+  CdfoProfScope prof(st, KID_CONV3_WS_RES, 2.0 * px * Cout * 64 * 9, px * (2.0 * 64 + 8.0 * Cout + (res2 ? 4.0 * Cout : 0.0)));
   const int rc = ws_launch<0, true>(a, 8 * qn * nco, st);
   if (rc) return rc;
   CDFO_LAUNCH_CHECK();

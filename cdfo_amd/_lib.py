@@ -39,6 +39,7 @@ class ConvArgs(C.Structure):
         ("tap_mask", C.c_void_p),
         ("src_f16", C.c_int), ("out_f16", C.c_int),
         ("out2_cp16", C.c_void_p),
+        ("src_plane_wrap", C.c_int),
         ("res_up2", C.c_void_p), ("ldru", C.c_int),
     ]
 

@@ -325,7 +325,7 @@ extern "C" int cdfo_conv3x3_bf16(const cdfo_conv_args* pa, void* stream) {
   hipStream_t st = static_cast<hipStream_t>(stream);
   if (a.nsrc < 1 || a.nsrc > CDFO_MAXSRC || a.B <= 0 || a.ks != 3 || a.stride != 1 || a.pad != 1) return CDFO_EINVAL;
   if (a.act == CDFO_ACT_SIGMOID) return CDFO_EINVAL;   // conv epilogues support none / LeakyReLU / ReLU
-  if (a.out2_cp16 || a.res_up2) return CDFO_EINVAL;
+  if (a.out2_cp16 || a.res_up2 || a.src_plane_wrap) return CDFO_EINVAL;
   int csum = 0;
   for (int s = 0; s < a.nsrc; ++s) {
     if (a.cs[s] <= 0 || a.cs[s] % 16 || a.ld[s] % 4 || a.ld[s] < a.cs[s]) return CDFO_EINVAL;

@@ -53,6 +53,8 @@ struct ring_extra {
   int CoutP;
   const unsigned* tap_mask;   // nullptr = dense
   int w_bytes;                // size of the weight buffer
+  int plane_wrap;             // chunk c reads source plane c % plane_wrap (0: plane c)
+  int src_planes;             // planes per image in the source tensor
 };
 
 // one 1 KiB LDS-DMA piece: lane l writes LDS bytes lds + 16 l from (buffer base + voff + soff).  rsrc / soff / lds must
@@ -140,7 +142,7 @@ __global__ __launch_bounds__(RG_THREADS) void conv3x3_ring_kernel(cdfo_conv_args
   }
   const unsigned plane = (unsigned)(H * W) * 32u;                 // bytes of one 16-channel plane
   const unsigned wchunk = (unsigned)(TAPS * 2 * e.CoutP) * 16u;   // bytes of one chunk's weight slab (all output blocks)
-  const unsigned img_bytes = plane * (unsigned)nc;
+  const unsigned img_bytes = plane * (unsigned)e.src_planes;
   const i32x4 rsrc_w = rg_rsrc(e.w, (unsigned)e.w_bytes);
 
   // ---- fragment read offsets: tile rows 2w..2w+3 of the halo, column offset dx, this lane's pixel r
@@ -199,9 +201,9 @@ __global__ __launch_bounds__(RG_THREADS) void conv3x3_ring_kernel(cdfo_conv_args
     rg_dma1(voff[j], rsrc_i, soff_i, dst);
   };
   auto issue_end = [&]() {
-    soff_i += loader_w ? wchunk : plane;
     ++gi;
     if (++ic == nc) { ic = 0; ++iu; }
+    soff_i = loader_w ? (unsigned)ic * wchunk : (unsigned)(e.plane_wrap ? ic % e.plane_wrap : ic) * plane;
   };
   const int total = my_units * nc;    // chunk batches of this workgroup
 #pragma unroll
@@ -499,6 +501,9 @@ extern "C" int cdfo_conv3x3_ring(const cdfo_conv_args* pa, void* stream) {
   if (cus < 8) return CDFO_EINVAL;
   ring_extra e;
   e.src = a.src[0]; e.nc = nc; e.w = a.w; e.CoutP = a.CoutP; e.tap_mask = a.tap_mask; e.w_bytes = (int)w_bytes;
+  e.plane_wrap = a.src_plane_wrap;
+  e.src_planes = a.src_plane_wrap ? a.src_plane_wrap : nc;
+  if (a.src_plane_wrap < 0 || a.src_plane_wrap > nc) return CDFO_EINVAL;
   const int grid = cus / 8 * 8;
   const double px = (double)a.B * a.Ho * a.Wo;
   CdfoProfScope prof(st, a.tap_mask ? KID_CONV3_RING4 : KID_CONV3_RING, 2.0 * px * a.Cout * a.Cin * taps,

@@ -79,6 +79,38 @@ __global__ __launch_bounds__(256) void layernorm64_kernel(const float* __restric
   }
 }
 
+// the same, written as fp16 hi | lo planes in chunk-planar layout [B][8][P][16] (split-fp16 source of the ring kernel)
+__global__ __launch_bounds__(256) void layernorm64_cp16hl_kernel(const float* __restrict__ in, int ldi,
+                                                                 const float* __restrict__ gamma,
+                                                                 const float* __restrict__ beta, long long npix, long long P,
+                                                                 _Float16* __restrict__ out) {
+  typedef _Float16 f16x4_t __attribute__((ext_vector_type(4)));
+  const int cg = threadIdx.x & 15;
+  const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + cg * 4);
+  const f32x4 be = *reinterpret_cast<const f32x4*>(beta + cg * 4);
+  for (long long p = (blockIdx.x * (long long)blockDim.x + threadIdx.x) >> 4; p < npix;
+       p += ((long long)gridDim.x * blockDim.x) >> 4) {
+    const f32x4 v = *reinterpret_cast<const f32x4*>(in + p * ldi + cg * 4);
+    float s = (v[0] + v[1]) + (v[2] + v[3]);
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    const float mu = s * (1.f / 64.f);
+    const f32x4 d = v - mu;
+    float q = (d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3]);
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) q += __shfl_xor(q, o, 64);
+    const float rstd = 1.f / sqrtf(q * (1.f / 64.f) + 1e-5f);
+    const f32x4 y = d * rstd * g + be;
+    f16x4_t hi, lo;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { hi[k] = (_Float16)y[k]; lo[k] = (_Float16)(y[k] - (float)hi[k]); }
+    const long long b = p / P, pix = p - b * P;
+    _Float16* o16 = out + ((b * 8 + (cg >> 2)) * P + pix) * 16 + (cg & 3) * 4;
+    *reinterpret_cast<f16x4_t*>(o16) = hi;
+    *reinterpret_cast<f16x4_t*>(o16 + 4 * P * 16) = lo;
+  }
+}
+
 // ------------------------------------------------------------------------------------------------------------
 // depthwise 3x3, pad 1, no bias (qkv_dwconv, arch.py:1552,1559). weights raw [C][1][3][3]; C % 4 == 0, C <= 256.
 // One thread = 4 consecutive pixels of a row x 4 channels: an 18-load 3x6 window serves 4 outputs (4.5 loads per
@@ -522,6 +554,18 @@ extern "C" int cdfo_conv_last_taps(const float* taps, int ldt, const float* bias
   CdfoProfScope prof(static_cast<hipStream_t>(stream), KID_CONV_LAST, 2.0*9*(double)B*Hh*Wh, 4.0*(ldt + 1)*(double)B*Hh*Wh);
   hipLaunchKernelGGL(conv_last_taps_kernel, dim3(grid_for((long long)B * Hh * Wh)), dim3(256), 0,
                      static_cast<hipStream_t>(stream), taps, ldt, bias, xc, xc_bstride, B, Hh, Wh, out);
+  CDFO_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int cdfo_layernorm64_cp16hl(const float* in, int ldi, const float* gamma, const float* beta, int B, long long P,
+                                       void* out, void* stream) {
+  if (B <= 0 || P <= 0 || ldi % 4 || ldi < 64) return CDFO_EINVAL;
+  if (!aligned16(in) || !aligned16(out) || !aligned16(gamma) || !aligned16(beta)) return CDFO_EALIGN;
+  const long long npix = (long long)B * P;
+  CdfoProfScope prof(static_cast<hipStream_t>(stream), KID_LAYERNORM, 0, 4.0*128*(double)npix);
+  hipLaunchKernelGGL(layernorm64_cp16hl_kernel, dim3(grid_for(npix * 16)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     in, ldi, gamma, beta, npix, P, static_cast<_Float16*>(out));
   CDFO_LAUNCH_CHECK();
   return 0;
 }

@@ -219,6 +219,7 @@ class CVSR_V8(nn.Module):
                 w[bp + "pro"] = K.pack_block_prologue(sd[bp + "up.0.weight"], sd[bp + "up.0.bias"],
                                                       sd[bp + "down.0.weight"], sd[bp + "down.0.bias"])
         fe = "transformer_feature_extraction.path1."
+        w[fe + "conv_hl"] = K.pack_conv_hilo(sd[fe + "conv.weight"], sd[fe + "conv.bias"])
         w[fe + "qkv_dw"] = K.pack_qkv_dw(sd[fe + "attn.qkv.weight"], sd[fe + "norm1.body.weight"], sd[fe + "norm1.body.bias"])
         pc("upconv1", shuffle2=True)
         pc("upconv2", shuffle2=True)
@@ -266,8 +267,14 @@ class CVSR_V8(nn.Module):
             part, n = K.gram_partial(qkv[..., 0:64], qkv[..., 64:128], 8)
             fold = K.mdta_fold(part, n, raw[p + "attn.temperature"], raw[p + "attn.project_out.weight"])
             x1 = self._conv(qkv[..., 128:192], fold, res1=x1)
-            ln = K.layernorm64(x1, raw[p + "norm2.body.weight"], raw[p + "norm2.body.bias"])
-            x1 = self._conv(ln, w[p + "conv"], pad=1, res1=x1, res2=x2, exact=True)
+            if self.precision == "fp16x2":
+                # LayerNorm written as fp16 hi | lo planes; the 3x3 conv as a split-fp16 product (a_hi*w_hi + a_lo*w_hi +
+                # a_hi*w_lo, 22-bit operands: fp32-grade like the split-bf16 path it replaces) on the ring kernel
+                ln = K.layernorm64_hl(x1, raw[p + "norm2.body.weight"], raw[p + "norm2.body.bias"])
+                x1 = K.conv_ring(ln, w[p + "conv_hl"], res1=x1, res2=x2, plane_wrap=8)
+            else:
+                ln = K.layernorm64(x1, raw[p + "norm2.body.weight"], raw[p + "norm2.body.bias"])
+                x1 = self._conv(ln, w[p + "conv"], pad=1, res1=x1, res2=x2, exact=True)
         return x1
 
     def _rdab(self, w, res, x, noise):

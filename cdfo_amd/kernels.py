@@ -300,7 +300,7 @@ def sparse_taps_f16(pc: PackedConv) -> torch.Tensor:
 def conv_ring(src: torch.Tensor, pc: PackedConv, *, act: int = ACT_NONE, res1: Optional[torch.Tensor] = None,
               res2: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None,
               out_f16: bool = False, out2_cp16: Optional[torch.Tensor] = None,
-              res_up2: Optional[torch.Tensor] = None, dbg: int = 0) -> torch.Tensor:
+              res_up2: Optional[torch.Tensor] = None, plane_wrap: int = 0, dbg: int = 0) -> torch.Tensor:
     """3x3/s1/p1 convolution of an fp16 chunk-planar source [B,Cin/16,H,W,16] on the LDS-DMA ring kernel
     (Block_.body[2] and the composed stride-2 convolution).  Result: pixel-major fp32 (or fp16) [B,H,W,Cout]."""
     if not src.is_cuda:
@@ -308,7 +308,7 @@ def conv_ring(src: torch.Tensor, pc: PackedConv, *, act: int = ACT_NONE, res1: O
     if src.dtype != torch.float16 or src.dim() != 5 or src.shape[4] != 16 or not src.is_contiguous():
         raise ValueError(f"conv_ring: expected a contiguous fp16 [B,C/16,H,W,16] source, got {src.dtype} {tuple(src.shape)}")
     B, nc, H, W, _ = src.shape
-    if pc.wh is None or pc.ks != 3 or pc.Cin != nc * 16:
+    if pc.wh is None or pc.ks != 3 or (pc.Cin != nc * 16 and not (plane_wrap == nc and pc.Cin % 16 == 0 and pc.Cin > nc * 16)):
         raise ValueError("conv_ring: weight does not match the source")
     a = ConvArgs()
     a.src[0], a.ld[0], a.cs[0], a.nsrc = src.data_ptr(), 16, pc.Cin, 1
@@ -328,6 +328,7 @@ def conv_ring(src: torch.Tensor, pc: PackedConv, *, act: int = ACT_NONE, res1: O
     _, _, _, _, a.ldo = _chk_act(out, "out", odt)
     a.out, a.store_mode, a.prec = out.data_ptr(), 0, PREC_FP16 | (dbg << 8)
     a.src_f16, a.out_f16 = 1, int(out_f16)
+    a.src_plane_wrap = plane_wrap
     for nm, r in (("res1", res1), ("res2", res2)):
         if r is not None:
             rb, rh, rw, rc, rld = _chk_act(r, nm)
@@ -423,6 +424,24 @@ def qkv_dw(x: torch.Tensor, packed, dw_w: torch.Tensor, eps: float = 1e-5) -> to
     check(_lib.lib().cdfo_qkv_dw(_vp(x), ld, B, H, W, _vp(packed[0]), _vp(packed[1]), _vp(dw_w), C.c_float(eps), _vp(out),
                                  192, _stream()), "cdfo_qkv_dw")
     return out
+
+
+def layernorm64_hl(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor) -> torch.Tensor:
+    """LayerNorm64 written as fp16 hi | lo chunk-planar planes [B, 8, H, W, 16] (planes 0-3 hi, 4-7 lo)."""
+    B, H, W, Cc, ld = _chk_act(x)
+    assert Cc == 64
+    out = torch.empty((B, 8, H, W, 16), dtype=torch.float16, device=x.device)
+    check(_lib.lib().cdfo_layernorm64_cp16hl(_vp(x), ld, _vp(gamma), _vp(beta), B, C.c_longlong(H * W), _vp(out), _stream()),
+          "cdfo_layernorm64_cp16hl")
+    return out
+
+
+def pack_conv_hilo(weight: torch.Tensor, bias: Optional[torch.Tensor]) -> PackedConv:
+    """3x3 weight for the split-fp16 product on the ring kernel: K-expanded (w_hi | w_hi | w_lo) along the input channels,
+    to be used with a source of hi | lo planes and plane_wrap = 2 * Cin / 16: a_hi*w_hi + a_lo*w_hi + a_hi*w_lo."""
+    w = weight.detach().float()
+    wh = w.half().float()
+    return pack_conv(torch.cat([wh, wh, w - wh], 1).contiguous(), bias)
 
 
 def dwconv3x3(x: torch.Tensor, w: torch.Tensor) -> torch.Tensor:

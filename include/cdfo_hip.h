@@ -55,6 +55,8 @@ typedef struct {
   int out_f16;                /* cdfo_conv3x3_bf16 only: store the result as fp16 (ldo in halves); no residual inputs */
   void* out2_cp16;            /* optional, cdfo_conv3x3_ring only: second copy of the result as an fp16 chunk-planar tensor
                                  [B][Cout/16][H][W][16] (the next Block_'s body[0] source), Cout % 16 == 0 */
+  int src_plane_wrap;         /* optional, cdfo_conv3x3_ring only: chunk c reads source plane c % src_plane_wrap (0 = plane c), so
+                                 that a K-expanded product (a_hi | a_lo | a_hi) x (w_hi | w_hi | w_lo) needs no duplicated planes */
   const float* res_up2; int ldru;   /* optional, cdfo_conv3x3_ring only: a HALF-resolution residual [B][H/2][W/2][ldru] that is
                                  added after bilinear x2 up-sampling (align_corners=False), i.e. Block_'s x1/2 branch */
 } cdfo_conv_args;
@@ -130,6 +132,10 @@ int cdfo_stem_conv(const float* img, long long img_bstride, const float* w, cons
 /* per-pixel LayerNorm over 64 channels (arch.py:1169-1198). */
 int cdfo_layernorm64(const float* in, int ldi, const float* gamma, const float* beta, long long npix, float* out,
                      int ldo, void* stream);
+/* the same LayerNorm written as an fp16 hi / lo pair in chunk-planar layout [B][8][P][16]: planes 0-3 = fp16(v) of channels
+ * 0-63, planes 4-7 = fp16(v - fp16(v)): the source of a split-fp16 (fp32-grade) 3x3 convolution on cdfo_conv3x3_ring. */
+int cdfo_layernorm64_cp16hl(const float* in, int ldi, const float* gamma, const float* beta, int B, long long P, void* out,
+                            void* stream);
 /* depthwise 3x3, pad 1, no bias; raw weight [C][1][3][3] (arch.py:1552). */
 int cdfo_dwconv3x3(const float* in, int ldi, const float* w, int B, int H, int W, int C, float* out, int ldo,
                    void* stream);

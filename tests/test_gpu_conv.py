@@ -468,3 +468,21 @@ def test_upconv_last_fused_tail(B, H, W):
     torch.cuda.synchronize()
     err = (out.cpu() - ref).abs().max().item()
     assert err < 3e-5 * max(1.0, ref.abs().max().item()), err
+
+
+@pytest.mark.parametrize("B,H,W", [(2, 20, 36), (1, 48, 64)])
+def test_split_fp16_conv_on_ring_kernel(B, H, W):
+    """LayerNorm -> fp16 hi | lo planes -> K-expanded (w_hi | w_hi | w_lo) 3x3 conv on the ring kernel: fp32-grade."""
+    from cdfo_amd import kernels as K
+    g = torch.Generator().manual_seed(B + H + W)
+    x = torch.randn(B, 64, H, W, generator=g) * 3 + 0.5
+    gamma, beta = torch.rand(64, generator=g) + 0.5, torch.randn(64, generator=g) * 0.1
+    w = torch.randn(64, 64, 3, 3, generator=g) / 24.0
+    b = torch.randn(64, generator=g)
+    r1, r2 = torch.randn(B, 64, H, W, generator=g), torch.randn(B, 64, H, W, generator=g)
+    ln = F.layer_norm(x.permute(0, 2, 3, 1), (64,), gamma, beta, 1e-5).permute(0, 3, 1, 2)
+    ref = F.conv2d(ln.double(), w.double(), b.double(), padding=1).float() + r1 + r2
+    hl = K.layernorm64_hl(_nhwc(x).cuda(), gamma.cuda(), beta.cuda())
+    out = K.conv_ring(hl, K.pack_conv_hilo(w.cuda(), b.cuda()), res1=_nhwc(r1).cuda(), res2=_nhwc(r2).cuda(), plane_wrap=8)
+    torch.cuda.synchronize()
+    _cmp(out, ref, 2e-5, "split-fp16 conv on the ring kernel")

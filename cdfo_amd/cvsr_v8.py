@@ -20,6 +20,8 @@ Differences, all deliberate:
 """
 from __future__ import annotations
 
+import contextlib
+
 import math
 from typing import Dict, List, Optional, Sequence
 
@@ -131,6 +133,7 @@ class CVSR_V8(nn.Module):
         #            (2-4e-4 max-abs: inside the 1e-3 parity bound; default);
         #   "bf16"   plain bf16 MFMA with fp32 accumulation (BASELINE's bf16 configuration, ~6e-3: outside the bound).
         self.precision = "fp16x2"
+        self.neighbour_streams = 3       # HIP side streams for the independent per-neighbour pipelines (1 = single stream)
         for key, shape, fan_in, init in _param_spec():
             t = torch.empty(shape)
             if init == "default":
@@ -258,6 +261,8 @@ class CVSR_V8(nn.Module):
         raw = w["raw"]
         p = "transformer_feature_extraction.path1."
         for rnd in range(3):
+            # (the prior U-net is independent of the MDTA chain below, but issuing it on a side stream made the
+            # forward 18 % slower: both chains are made of full-GPU launches that only get in each other's way)
             x2 = self._udsa(w, x2, x1 if rnd == 0 else x2)
             if self.precision == "f32":
                 qkv = self._conv(x1, w[p + "attn.qkv"], ln=(raw[p + "norm1.body.weight"], raw[p + "norm1.body.bias"]))
@@ -418,27 +423,32 @@ class CVSR_V8(nn.Module):
         noise = gumbel_uniform if gumbel_uniform is not None else self.gumbel_uniform
         aligned: List[torch.Tensor] = []
         draw = 0
+        # The six neighbour pipelines are independent of each other: with `neighbour_streams` > 1 they are issued
+        # round-robin on side streams (HIP streams, joined before the temporal fusion), so that their many small
+        # kernels overlap.  Every tensor they produce stays referenced until forward returns.
+        nstr = int(getattr(self, "neighbour_streams", 3))
+        main = torch.cuda.current_stream(x.device)
+        side = []
+        if nstr > 1:
+            cache = self.__dict__.setdefault("_side_streams", {})
+            side = cache.get((x.device, nstr))
+            if side is None:
+                side = cache[(x.device, nstr)] = [torch.cuda.Stream(x.device) for _ in range(nstr)]
+        for st in side:
+            st.wait_stream(main)
+        keep = []
         for i in range(N):
             if i == ctr:
                 aligned.append(Lf[ctr])
                 continue
-            ufs_prior = K.stem_conv(ufs[:, 0, i], N * P, B, H, W, raw["conv_expand_ufs.weight"],
-                                    raw["conv_expand_ufs.bias"])
-            rms_prior, fea_com = K.stem_conv(rms[:, 0, i], N * P, B, H, W, raw["conv_expand_rms.weight"],
-                                             raw["conv_expand_rms.bias"], add=Lf[i])
-            if noise is None:
-                u = torch.rand((B, NF, H, W), device=x.device, dtype=torch.float32).clamp_min_(1e-30)
-            else:
-                u = noise[draw].to(device=x.device, dtype=torch.float32).contiguous()
+            ctx = torch.cuda.stream(side[draw % nstr]) if side else contextlib.nullcontext()
+            with ctx:
+                aligned.append(self._neighbour(w, raw, Lf, i, ctr, ufs, rms, mvs1, noise, draw, B, H, W, P, N, keep))
+            if side:
+                aligned[-1].record_stream(main)      # produced on a side stream, consumed on the caller's
             draw += 1
-            x_n = self._rdab(w, rms_prior, fea_com, u)
-            if self.debug_taps is not None:
-                self.debug_taps[f"rdab_{i}"] = x_n
-                self.debug_taps[f"align_{i}"] = al_ref = K.empty_act(B, H, W, NF, x.device)
-            fea_i = self._conv([Lf[i], x_n], w["conv_expand_fea_r"], pad=1)
-            al = al_ref if self.debug_taps is not None else K.empty_act(B, H, W, NF, x.device)
-            self._align(w, Lf[ctr], fea_i, ufs_prior, mvs1[:, i], N * 2 * P, al)
-            aligned.append(al)
+        for st in side:
+            main.wait_stream(st)
 
         # 3. temporal fusion, 4. reconstruction trunk, 5. upsampling + skip (arch.py:4463-4481)
         fused = self._conv(aligned, w["tsa_fusion"], act=K.ACT_LRELU)
@@ -452,6 +462,27 @@ class CVSR_V8(nn.Module):
         else:   # upconv2 writes conv_last's nine per-tap channel sums instead of the 64-channel HR map
             out = K.upconv_last(t, w["upconv2"], raw["conv_last.weight"], raw["conv_last.bias"], x[:, ctr], N * P)
         return out, L1.permute(0, 3, 1, 2)
+
+    def _neighbour(self, w, raw, Lf, i, ctr, ufs, rms, mvs1, noise, draw, B, H, W, P, N, keep):
+        """One neighbour frame: prior stems, RDAB compensation, conv_expand_fea_r, MV alignment (arch.py:4443-4460)."""
+        x_dev = Lf.device
+        ufs_prior = K.stem_conv(ufs[:, 0, i], N * P, B, H, W, raw["conv_expand_ufs.weight"],
+                                raw["conv_expand_ufs.bias"])
+        rms_prior, fea_com = K.stem_conv(rms[:, 0, i], N * P, B, H, W, raw["conv_expand_rms.weight"],
+                                         raw["conv_expand_rms.bias"], add=Lf[i])
+        if noise is None:
+            u = torch.rand((B, NF, H, W), device=x_dev, dtype=torch.float32).clamp_min_(1e-30)
+        else:
+            u = noise[draw].to(device=x_dev, dtype=torch.float32).contiguous()
+        x_n = self._rdab(w, rms_prior, fea_com, u)
+        if self.debug_taps is not None:
+            self.debug_taps[f"rdab_{i}"] = x_n
+            self.debug_taps[f"align_{i}"] = al_ref = K.empty_act(B, H, W, NF, x_dev)
+        fea_i = self._conv([Lf[i], x_n], w["conv_expand_fea_r"], pad=1)
+        al = al_ref if self.debug_taps is not None else K.empty_act(B, H, W, NF, x_dev)
+        self._align(w, Lf[ctr], fea_i, ufs_prior, mvs1[:, i], N * 2 * P, al)
+        keep.extend([ufs_prior, rms_prior, fea_com, u, x_n, fea_i])
+        return al
 
     @staticmethod
     def _as_pixel_major(t: torch.Tensor, F: int, H: int, W: int) -> torch.Tensor:

@@ -21,11 +21,12 @@ def main():
     model = CVSR_V8()
     model.load_state_dict(make_state_dict(0, perturb=False), strict=True)
     model = model.cuda().eval()
-    for use_graph in (False, True):
+    for use_graph, nstr in ((False, 1), (True, 1), (False, 3), (False, 6)):
+        model.neighbour_streams = nstr
         s = StreamingSR(model, lr, pms, rms, ufs, mv[0], mv[1], use_graph=use_graph)
         s.run()                               # warm-up (weight packing, first-touch allocations, graph capture)
         outs = s.run()
-        print(f"streaming, 1 sequence of {T} frames {H}x{W} -> {tuple(outs[0].shape)}, HIP graph {use_graph}: "
+        print(f"streaming, 1 sequence of {T} frames {H}x{W} -> {tuple(outs[0].shape)}, HIP graph {use_graph}, neighbour streams {nstr}: "
               f"{s.fps:.2f} frames/s ({1e3 * s.seconds / T:.1f} ms per frame, forward only, B=1)", flush=True)
 
 

@@ -8,10 +8,13 @@
 //     halo (20 pieces of 1 KiB) and the chunk's weight slab (18 pieces; 8 when only four taps carry weights) are
 //     copied global -> LDS by LDS-DMA (buffer_load_dwordx4 ... lds), four or five instructions per wave and chunk,
 //     issued one at a time BETWEEN the taps' MFMAs -- no staging registers, no ds_write pass;
-//   * three or four ring stages, two or three chunks (56-115 KB per CU) in flight -- the activations come from HBM, and at its ~4 us
-//     loaded latency two chunks in flight capped the chip at ~3.5 TB/s --, ONE workgroup barrier per chunk (the tiled
-//     kernel needs two and restages through VGPRs); the ring runs across tile boundaries, so the epilogue of one
-//     tile overlaps the loads of the next;
+//   * a ring of four stages (dense form) or three (four-tap form), i.e. three or two chunks in flight, ONE workgroup
+//     barrier per chunk (the tiled kernel needs two and restages through VGPRs); the ring runs across tile
+//     boundaries, so the epilogue of one tile overlaps the loads of the next;
+//   * four-tap form: the half-resolution residual of Block_'s x1/2 branch (added after bilinear x2 by the epilogue) is
+//     copied into LDS by DMA at the tile's first chunk, so its taps cost no global loads at the tile boundary;
+//   * optional source plane wrap (chunk c reads plane c % wrap): a split-fp16, fp32-grade product
+//     (a_hi | a_lo | a_hi) x (w_hi | w_hi | w_lo) runs as one K-expanded convolution without duplicated planes;
 //   * chunk-planar source [B][Cin/16][H][W][16]: a halo row is 34 x 32 contiguous bytes; out-of-image pixels get an
 //     out-of-range buffer offset = hardware zero fill = the zero padding;
 //   * the dense 32-byte pixel records are made conflict-free for ds_read_b128 by swapping the two 16-byte halves of

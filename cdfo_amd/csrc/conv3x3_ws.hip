@@ -10,7 +10,8 @@
 //     stages its own 4 x 34 pixel halo, 16 channels at a time, straight from global memory into a wave-private LDS
 //     ring by LDS-DMA (buffer_load_dwordx4 ... lds: no staging VGPRs, no ds_write pass; out-of-image lanes are given an
 //     out-of-range buffer offset, which the hardware zero-fills = the convolution's zero padding).  The eight waves
-//     drift apart freely, so one wave's DMA wait or epilogue is covered by its SIMD partner's MFMAs;
+//     drift apart freely, so one wave's DMA wait or epilogue is covered by its SIMD partner's MFMAs; tiles are handed
+//     out through an LDS counter (the two waves of a SIMD do not progress at the same rate);
 //   * reads a "chunk-planar" fp16 source [B][Cin/16][H][W][16]: a staged image row is 34 x 32 contiguous bytes, every
 //     DMA piece moves whole cache lines (the pixel-major layout would touch 32 bytes of each 128-byte line);
 //   * computes the transposed product (M = output channels, N = pixels) with the weight rows of each 32-channel block

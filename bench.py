@@ -176,7 +176,7 @@ def main():
                     # the other matrix-core convolution kernels of the step, same definitions (not the headline entry)
                     "other_mfma_kernels": [fam(k) for k in range(nk) if KID_NAMES[k] in MFMA16 and k != dom and launches[k]]}
         cpu = None
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:      # reported on rank 0 at N = 1 only
             cpu = cpu_baseline(sd, Hp, Wp)
         res = {
             "metric": "x4 SR frames/sec, 7-frame 270x480->1080p", "value": round(value, 4), "unit": "frames/s",

@@ -30,7 +30,7 @@ PEAK_TFLOPS = {"f32": 157.3, "bf16x3": 2500.0, "bf16": 2500.0, "fp16x2": 2500.0}
 MFMA_PASSES = {"f32": 1, "bf16x3": 3, "bf16": 1, "fp16x2": 2}   # tiled kernel; the Block_ kernels (ws, ring) are 1-pass fp16                    # bf16 MFMA MACs issued per algorithmic MAC
 KID_NAMES = ["conv3x3_wide", "conv3x3_narrow", "conv1x1", "conv3x3_s2", "stem", "layernorm", "dwconv", "flow_warp",
              "resample", "scale", "conv_last", "small_conv", "spatial_gate", "chan_sum", "gram", "fold", "rdab_prep",
-             "colconv9", "attn_row", "attn_col", "attn_win", "layout", "pack", "dcn", "conv3x3_ws", "conv3x3_ring", "conv3x3_ring4", "conv3x3_ws_res"]
+             "colconv9", "attn_row", "attn_col", "attn_win", "layout", "pack", "dcn", "conv3x3_ws", "conv3x3_ring", "conv3x3_ring4", "conv3x3_ws_res", "dcn_bwd"]
 # kernel families on the 16-bit matrix cores -> (kernel symbol in the rocprofv3 stats, MFMA passes per algorithmic MAC)
 # conv3x3_wide (the tiled kernel) runs the --precision mode's passes: fp16x2 = 2 (3 for the split-bf16 feature cache)
 MFMA16 = {"conv3x3_wide": ("conv3x3_mma16_kernel", None), "conv3x3_ws": ("conv3x3_c64_ws_kernel<0, false>", 1),

@@ -1,0 +1,235 @@
+// Deformable convolution BACKWARD (DCNv1 and modulated DCNv2) for gfx950 -- SURVEY section 8f n2.
+//
+// Replaces, without the `columns` [C*kh*kw, Ho*Wo] HBM buffer the reference materialises twice per image,
+//   columns = W^T x grad_output                                            (ops/dcn/src/deform_conv_cuda.cpp:617-620, 331-336)
+//   modulated_deformable_col2im_coord_gpu_kernel / deformable_col2im_coord  (cu:700-766, 373-430)  -> grad_offset, grad_mask
+//   modulated_deformable_col2im_gpu_kernel / deformable_col2im              (cu:634-698, 283-330)  -> grad_input
+//   im2col + grad_weight += grad_output x columns^T, grad_bias += rowsum    (cpp:637-664, 447-476)
+//
+// Three kernels:
+//   dcn_bwd_data_kernel    one thread = (image, deformable group, tap, output pixel).  The sample position and its
+//                          bilinear / coordinate weights depend on exactly that tuple, so they are computed once and the
+//                          thread walks the C/dg channels of its deformable group: column gradient = dot(W[:, c, tap],
+//                          grad_output[:, pixel]) (weight operand is wave-uniform -> scalar loads; grad_output reads are
+//                          coalesced along the pixel axis), grad_offset / grad_mask are reduced in registers and
+//                          ASSIGNED (deterministic, as in the reference), grad_input takes 4 hardware fp32 atomics.
+//   dcn_bwd_weight_kernel  one workgroup = one input channel x 64 output channels x a range of (image, pixel) positions,
+//                          walked in chunks of 64: sampled column values [T][64] and the grad_output tile [64][64] are
+//                          staged in LDS, each thread owns up to 16 (cout, tap) pairs; one atomic per pair per workgroup.
+//   dcn_bwd_bias_kernel    one workgroup per output channel.
+// grad_input, grad_weight and grad_bias are accumulated into (callers zero them: ops/dcn/deform_conv.py:71-72, 85, 154-158).
+#include "common.h"
+
+namespace {
+
+struct DcnBwdArgs {
+  const float* in; const float* offset; const float* mask; const float* w; const float* gout;
+  float* gin; float* goff; float* gmask; float* gw; float* gbias;
+  int B, C, H, W, Co, Ho, Wo, kh, kw, sh, sw, ph, pw, dh, dw, groups, dg;
+  float scale;
+};
+
+struct Sample {             // bilinear footprint of one sample position (cu:466-496, 498-567)
+  int o1, o2, o3, o4;       // plane offsets of the 4 corners; -1 = outside the image (contributes 0)
+  float hh, hw, lh, lw;
+  bool valid;
+};
+
+__device__ __forceinline__ Sample make_sample(float h, float w, int H, int W) {
+  Sample s;
+  s.valid = !(h <= -1.f || w <= -1.f || h >= (float)H || w >= (float)W);
+  const int hl = (int)floorf(h), wl = (int)floorf(w), hhi = hl + 1, whi = wl + 1;
+  s.lh = h - (float)hl; s.lw = w - (float)wl; s.hh = 1.f - s.lh; s.hw = 1.f - s.lw;
+  s.o1 = (s.valid && hl >= 0 && wl >= 0) ? hl * W + wl : -1;
+  s.o2 = (s.valid && hl >= 0 && whi <= W - 1) ? hl * W + whi : -1;
+  s.o3 = (s.valid && hhi <= H - 1 && wl >= 0) ? hhi * W + wl : -1;
+  s.o4 = (s.valid && hhi <= H - 1 && whi <= W - 1) ? hhi * W + whi : -1;
+  return s;
+}
+
+__global__ __launch_bounds__(256) void dcn_bwd_data_kernel(DcnBwdArgs a) {
+  const int T = a.kh * a.kw, P = a.Ho * a.Wo;
+  const int Cg = a.C / a.groups, Cog = a.Co / a.groups, Cdg = a.C / a.dg;
+  const int p = blockIdx.x * 256 + threadIdx.x;
+  const int d = blockIdx.y / T, t = blockIdx.y - d * T, b = blockIdx.z;
+  if (p >= P) return;
+  const int ho = p / a.Wo, wo = p - ho * a.Wo, ki = t / a.kw, kj = t - ki * a.kw;
+  const long long ob = ((long long)(b * a.dg + d) * T + t) * 2 * P + p;
+  const float h_im = (float)(ho * a.sh - a.ph + ki * a.dh) + a.offset[ob];
+  const float w_im = (float)(wo * a.sw - a.pw + kj * a.dw) + a.offset[ob + P];
+  const long long mb = ((long long)(b * a.dg + d) * T + t) * P + p;
+  const float m = a.mask ? a.mask[mb] : 1.f;
+  const Sample s = make_sample(h_im, w_im, a.H, a.W);
+  const float w1 = s.hh * s.hw, w2 = s.hh * s.lw, w3 = s.lh * s.hw, w4 = s.lh * s.lw;
+  float vh = 0.f, vw = 0.f, mv = 0.f;
+  if (s.valid) {
+    for (int cc = 0; cc < Cdg; ++cc) {
+      const int c = d * Cdg + cc, g = c / Cg, cl = c - g * Cg;
+      const float* wp = a.w + ((long long)(g * Cog) * Cg + cl) * T + t;          // + o * Cg * T   (wave-uniform)
+      const float* gp = a.gout + ((long long)b * a.Co + g * Cog) * P + p;        // + o * P        (coalesced)
+      float cg = 0.f;
+      for (int o = 0; o < Cog; ++o) cg = fmaf(wp[(long long)o * Cg * T], gp[(long long)o * P], cg);
+      const long long pl = ((long long)b * a.C + c) * a.H * a.W;
+      const float* im = a.in + pl;
+      const float v1 = s.o1 >= 0 ? im[s.o1] : 0.f, v2 = s.o2 >= 0 ? im[s.o2] : 0.f;
+      const float v3 = s.o3 >= 0 ? im[s.o3] : 0.f, v4 = s.o4 >= 0 ? im[s.o4] : 0.f;
+      mv = fmaf(cg, w1 * v1 + w2 * v2 + w3 * v3 + w4 * v4, mv);
+      const float tg = cg * m;
+      vh = fmaf(s.hw * (v3 - v1) + s.lw * (v4 - v2), tg, vh);                    // d sample / d h
+      vw = fmaf(s.hh * (v2 - v1) + s.lh * (v4 - v3), tg, vw);                    // d sample / d w
+      if (a.gin) {
+        float* gi = a.gin + pl;
+        if (s.o1 >= 0) unsafeAtomicAdd(gi + s.o1, w1 * tg);
+        if (s.o2 >= 0) unsafeAtomicAdd(gi + s.o2, w2 * tg);
+        if (s.o3 >= 0) unsafeAtomicAdd(gi + s.o3, w3 * tg);
+        if (s.o4 >= 0) unsafeAtomicAdd(gi + s.o4, w4 * tg);
+      }
+    }
+  }
+  if (a.goff) { a.goff[ob] = vh; a.goff[ob + P] = vw; }
+  if (a.gmask) a.gmask[mb] = mv;
+}
+
+constexpr int WPX = 64;     // positions per chunk
+constexpr int WOB = 64;     // output channels per workgroup
+constexpr int WPAIRS = 16;  // (cout, tap) pairs per thread  =>  kh*kw <= 64
+
+__global__ __launch_bounds__(256) void dcn_bwd_weight_kernel(DcnBwdArgs a, int span /* positions per workgroup */) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* gl = smem;                      // [WOB][WPX + 1]
+  float* vl = smem + WOB * (WPX + 1);    // [T][WPX]
+  const int tid = threadIdx.x;
+  const int T = a.kh * a.kw, P = a.Ho * a.Wo;
+  const int Cg = a.C / a.groups, Cog = a.Co / a.groups, Cdg = a.C / a.dg;
+  const int c = blockIdx.y, g = c / Cg, cl = c - g * Cg, d = c / Cdg;
+  const int o0 = blockIdx.z * WOB, no = (Cog - o0) < WOB ? (Cog - o0) : WOB;
+  const long long total = (long long)a.B * P;
+  const long long q0 = (long long)blockIdx.x * span;
+  const long long q1 = (q0 + span) < total ? (q0 + span) : total;
+  float acc[WPAIRS];
+#pragma unroll
+  for (int k = 0; k < WPAIRS; ++k) acc[k] = 0.f;
+
+  for (long long qc = q0; qc < q1; qc += WPX) {
+    __syncthreads();
+    for (int item = tid; item < T * WPX; item += 256) {
+      const int t = item >> 6, px = item & (WPX - 1);
+      const long long q = qc + px;
+      float val = 0.f;
+      if (q < q1) {
+        const int b = (int)(q / P), p = (int)(q - (long long)b * P);
+        const int ho = p / a.Wo, wo = p - ho * a.Wo, ki = t / a.kw, kj = t - ki * a.kw;
+        const long long ob = ((long long)(b * a.dg + d) * T + t) * 2 * P + p;
+        const float h_im = (float)(ho * a.sh - a.ph + ki * a.dh) + a.offset[ob];
+        const float w_im = (float)(wo * a.sw - a.pw + kj * a.dw) + a.offset[ob + P];
+        const Sample s = make_sample(h_im, w_im, a.H, a.W);
+        if (s.valid) {
+          const float* im = a.in + ((long long)b * a.C + c) * a.H * a.W;
+          const float v1 = s.o1 >= 0 ? im[s.o1] : 0.f, v2 = s.o2 >= 0 ? im[s.o2] : 0.f;
+          const float v3 = s.o3 >= 0 ? im[s.o3] : 0.f, v4 = s.o4 >= 0 ? im[s.o4] : 0.f;
+          val = (s.hh * s.hw) * v1 + (s.hh * s.lw) * v2 + (s.lh * s.hw) * v3 + (s.lh * s.lw) * v4;
+          if (a.mask) val *= a.mask[((long long)(b * a.dg + d) * T + t) * P + p];
+        }
+      }
+      vl[t * WPX + px] = val;
+    }
+    for (int item = tid; item < WOB * WPX; item += 256) {
+      const int o = item >> 6, px = item & (WPX - 1);
+      const long long q = qc + px;
+      float v = 0.f;
+      if (o < no && q < q1) {
+        const int b = (int)(q / P), p = (int)(q - (long long)b * P);
+        v = a.gout[((long long)b * a.Co + g * Cog + o0 + o) * P + p];
+      }
+      gl[o * (WPX + 1) + px] = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < WPAIRS; ++k) {
+      const int pair = tid + k * 256;
+      if (pair < WOB * T) {
+        const int o = pair & (WOB - 1), t = pair >> 6;
+        const float* gr = gl + o * (WPX + 1);
+        const float* vr = vl + t * WPX;
+        float s = 0.f;
+#pragma unroll 16
+        for (int px = 0; px < WPX; ++px) s = fmaf(gr[px], vr[px], s);
+        acc[k] += s;
+      }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < WPAIRS; ++k) {
+    const int pair = tid + k * 256;
+    if (pair < WOB * T) {
+      const int o = pair & (WOB - 1), t = pair >> 6;
+      if (o < no) unsafeAtomicAdd(a.gw + ((long long)(g * Cog + o0 + o) * Cg + cl) * T + t, a.scale * acc[k]);
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void dcn_bwd_bias_kernel(const float* __restrict__ gout, float* __restrict__ gbias, int B,
+                                                           int Co, int P) {
+  __shared__ float part[4];
+  const int o = blockIdx.x, tid = threadIdx.x;
+  float s = 0.f;
+  for (int b = 0; b < B; ++b) {
+    const float* gp = gout + ((long long)b * Co + o) * P;
+    for (int p = tid; p < P; p += 256) s += gp[p];
+  }
+#pragma unroll
+  for (int sh = 32; sh > 0; sh >>= 1) s += __shfl_xor(s, sh, 64);
+  if ((tid & 63) == 0) part[tid >> 6] = s;
+  __syncthreads();
+  if (tid == 0) gbias[o] += part[0] + part[1] + part[2] + part[3];
+}
+
+}  // namespace
+
+extern "C" int cdfo_dcn_backward(const float* in, const float* offset, const float* mask, const float* weight,
+                                 const float* grad_out, float* grad_in, float* grad_offset, float* grad_mask,
+                                 float* grad_weight, float* grad_bias, int B, int C, int H, int W, int Co, int kh, int kw,
+                                 int sh, int sw, int ph, int pw, int dh, int dw, int groups, int deformable_groups,
+                                 float scale, void* stream) {
+  if (B <= 0 || C <= 0 || Co <= 0 || kh <= 0 || kw <= 0 || sh <= 0 || sw <= 0 || dh <= 0 || dw <= 0 || groups <= 0 ||
+      deformable_groups <= 0)
+    return CDFO_EINVAL;
+  if (C % groups || Co % groups || C % deformable_groups) return CDFO_EINVAL;
+  if (!in || !offset || !weight || !grad_out) return CDFO_EINVAL;
+  if (grad_mask && !mask) return CDFO_EINVAL;
+  const int Ho = (H + 2 * ph - (dh * (kh - 1) + 1)) / sh + 1;
+  const int Wo = (W + 2 * pw - (dw * (kw - 1) + 1)) / sw + 1;
+  if (Ho <= 0 || Wo <= 0) return CDFO_EINVAL;
+  const int T = kh * kw, P = Ho * Wo;
+  if (T > (WPAIRS * 256) / WOB) return CDFO_EINVAL;
+  if ((long long)deformable_groups * T > 65535 || B > 65535 || C > 65535) return CDFO_EINVAL;
+  DcnBwdArgs a{in, offset, mask, weight, grad_out, grad_in, grad_offset, grad_mask, grad_weight, grad_bias,
+               B, C, H, W, Co, Ho, Wo, kh, kw, sh, sw, ph, pw, dh, dw, groups, deformable_groups, scale};
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const double px = (double)B * P;
+  if (grad_in || grad_offset || grad_mask) {
+    CdfoProfScope prof(st, KID_DCN_BWD, 2.0 * px * Co * (C / groups) * T,
+                       4.0 * (px * (Co + 6.0 * deformable_groups * T) + 2.0 * B * C * H * W + (double)Co * (C / groups) * T));
+    hipLaunchKernelGGL(dcn_bwd_data_kernel, dim3(cdiv(P, 256), deformable_groups * T, B), dim3(256), 0, st, a);
+    CDFO_LAUNCH_CHECK();
+  }
+  if (grad_weight) {
+    const long long total = (long long)B * P;
+    // enough workgroups to fill 256 CUs a few times over, each walking a whole number of 64-position chunks
+    const int zb = cdiv(Co / groups, WOB);
+    long long want = 2048 / ((long long)C * zb) + 1;
+    long long span = (total + want - 1) / want;
+    span = (span + WPX - 1) / WPX * WPX;
+    const int nx = (int)((total + span - 1) / span);
+    const size_t lds = (size_t)(WOB * (WPX + 1) + T * WPX) * sizeof(float);
+    CdfoProfScope prof(st, KID_DCN_BWD, 2.0 * px * Co * (C / groups) * T,
+                       4.0 * (px * (Co + 3.0 * deformable_groups * T) + (double)B * C * H * W + (double)Co * (C / groups) * T));
+    hipLaunchKernelGGL(dcn_bwd_weight_kernel, dim3(nx, C, zb), dim3(256), lds, st, a, (int)span);
+    CDFO_LAUNCH_CHECK();
+  }
+  if (grad_bias) {
+    hipLaunchKernelGGL(dcn_bwd_bias_kernel, dim3(Co), dim3(256), 0, st, grad_out, grad_bias, B, Co, P);
+    CDFO_LAUNCH_CHECK();
+  }
+  return 0;
+}

@@ -3,7 +3,8 @@
 ``modulated_deform_conv``, ``DeformConv``, ``DeformConvPack``, ``ModulatedDeformConv``, ``ModulatedDeformConvPack``
 with the constructor / forward signatures of deform_conv.py:190-201, 234, 264-275, 305, 311-337 and the same error
 behaviour (``NotImplementedError`` for CPU tensors, deform_conv.py:46-47, 136-137; ``ValueError`` for non-4D input,
-:26-29).  The arithmetic runs in libcdfo_hip.so (``cdfo_dcn_forward``).  Forward only: ``backward`` raises."""
+:26-29).  The arithmetic runs in libcdfo_hip.so (``cdfo_dcn_forward`` / ``cdfo_dcn_backward``); ``backward`` follows
+deform_conv.py:60-99 and :150-172 (zero-filled gradient tensors handed to the extension's backward entry points)."""
 from __future__ import annotations
 
 import math
@@ -28,7 +29,11 @@ class DeformConvFunction(Function):
         output = input.new_empty(DeformConvFunction._output_size(input, weight, padding, dilation, stride))
         cur_im2col_step = min(im2col_step, input.shape[0])
         assert (input.shape[0] % cur_im2col_step) == 0, 'im2col step must divide batchsize'
+        ctx.stride, ctx.padding, ctx.dilation = stride, padding, dilation
+        ctx.groups, ctx.deformable_groups, ctx.im2col_step = groups, deformable_groups, im2col_step
+        ctx.save_for_backward(input, offset, weight)
         bufs = [input.new_empty(0), input.new_empty(0)]
+        ctx.bufs_ = bufs
         deform_conv_cuda.deform_conv_forward_cuda(
             input.contiguous(), weight.contiguous(), offset, output, bufs[0], bufs[1], weight.size(3), weight.size(2),
             stride[1], stride[0], padding[1], padding[0], dilation[1], dilation[0], groups, deformable_groups,
@@ -37,7 +42,26 @@ class DeformConvFunction(Function):
 
     @staticmethod
     def backward(ctx, grad_output):
-        raise NotImplementedError("DeformConvFunction.backward: forward-only HIP path")
+        input, offset, weight = ctx.saved_tensors
+        grad_input = grad_offset = grad_weight = None
+        if not grad_output.is_cuda:
+            raise NotImplementedError
+        cur_im2col_step = min(ctx.im2col_step, input.shape[0])
+        assert (input.shape[0] % cur_im2col_step) == 0, 'im2col step must divide batchsize'
+        if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
+            grad_input = torch.zeros_like(input)
+            grad_offset = torch.zeros_like(offset)
+            deform_conv_cuda.deform_conv_backward_input_cuda(
+                input, offset, grad_output, grad_input, grad_offset, weight, ctx.bufs_[0], weight.size(3),
+                weight.size(2), ctx.stride[1], ctx.stride[0], ctx.padding[1], ctx.padding[0], ctx.dilation[1],
+                ctx.dilation[0], ctx.groups, ctx.deformable_groups, cur_im2col_step)
+        if ctx.needs_input_grad[2]:
+            grad_weight = torch.zeros_like(weight)
+            deform_conv_cuda.deform_conv_backward_parameters_cuda(
+                input, offset, grad_output, grad_weight, ctx.bufs_[0], ctx.bufs_[1], weight.size(3), weight.size(2),
+                ctx.stride[1], ctx.stride[0], ctx.padding[1], ctx.padding[0], ctx.dilation[1], ctx.dilation[0],
+                ctx.groups, ctx.deformable_groups, 1, cur_im2col_step)
+        return (grad_input, grad_offset, grad_weight, None, None, None, None, None, None)
 
     @staticmethod
     def _output_size(input, weight, padding, dilation, stride):
@@ -67,7 +91,12 @@ class ModulatedDeformConvFunction(Function):
         height_out = (height + 2 * padding - (dilation * (kernel_h - 1) + 1)) // stride + 1
         width_out = (width + 2 * padding - (dilation * (kernel_w - 1) + 1)) // stride + 1
         output = input.new_empty((n, channels_out, height_out, width_out))
+        ctx.stride, ctx.padding, ctx.dilation = stride, padding, dilation
+        ctx.groups, ctx.deformable_groups, ctx.with_bias = groups, deformable_groups, with_bias
+        if weight.requires_grad or mask.requires_grad or offset.requires_grad or input.requires_grad:
+            ctx.save_for_backward(input, offset, mask, weight, bias)
         bufs = [input.new_empty(0), input.new_empty(0)]
+        ctx._bufs = bufs
         deform_conv_cuda.modulated_deform_conv_cuda_forward(
             input.contiguous(), weight.contiguous(), bias, bufs[0], offset, mask, output, bufs[1], kernel_h, kernel_w,
             stride, stride, padding, padding, dilation, dilation, groups, deformable_groups, with_bias)
@@ -75,7 +104,21 @@ class ModulatedDeformConvFunction(Function):
 
     @staticmethod
     def backward(ctx, grad_output):
-        raise NotImplementedError("ModulatedDeformConvFunction.backward: forward-only HIP path")
+        if not grad_output.is_cuda:
+            raise NotImplementedError
+        input, offset, mask, weight, bias = ctx.saved_tensors
+        grad_input = torch.zeros_like(input)
+        grad_offset = torch.zeros_like(offset)
+        grad_mask = torch.zeros_like(mask)
+        grad_weight = torch.zeros_like(weight)
+        grad_bias = torch.zeros_like(bias)
+        deform_conv_cuda.modulated_deform_conv_cuda_backward(
+            input, weight, bias, ctx._bufs[0], offset, mask, ctx._bufs[1], grad_input, grad_weight, grad_bias,
+            grad_offset, grad_mask, grad_output, weight.shape[2], weight.shape[3], ctx.stride, ctx.stride, ctx.padding,
+            ctx.padding, ctx.dilation, ctx.dilation, ctx.groups, ctx.deformable_groups, ctx.with_bias)
+        if not ctx.with_bias:
+            grad_bias = None
+        return (grad_input, grad_offset, grad_mask, grad_weight, grad_bias, None, None, None, None, None)
 
 
 deform_conv = DeformConvFunction.apply

@@ -2,8 +2,9 @@
 the same five entry points with the same positional signatures, backed by libcdfo_hip.so's ``cdfo_dcn_forward``.
 
 The out-parameter convention is kept (caller pre-allocates ``output``; ``columns``/``ones`` scratch tensors are
-accepted and ignored -- the HIP kernel fuses sampling and contraction).  The three backward entry points exist and
-raise ``NotImplementedError`` (forward-only hot path)."""
+accepted and ignored -- the HIP kernels fuse sampling and contraction).  The three backward entry points share
+``cdfo_dcn_backward`` and keep the reference's conventions: gradient tensors arrive zero-filled,
+grad_input / grad_weight / grad_bias are accumulated into, grad_offset / grad_mask are assigned."""
 from __future__ import annotations
 
 import ctypes as C
@@ -68,13 +69,66 @@ def modulated_deform_conv_cuda_forward(input, weight, bias, ones, offset, mask, 
          pad_h, pad_w, dilation_h, dilation_w, group, deformable_group)
 
 
-def deform_conv_backward_input_cuda(*args, **kw):
-    raise NotImplementedError("deform_conv_backward_input_cuda: backward kernels are not part of this path yet")
+def _bwd(input, offset, mask, weight, grad_output, grad_input, grad_offset, grad_mask, grad_weight, grad_bias, kh, kw,
+         sh, sw, ph, pw, dh, dw, group, dg, scale):
+    if not input.is_contiguous():
+        raise RuntimeError("input tensor has to be contiguous")      # cpp:574
+    if not weight.is_contiguous():
+        raise RuntimeError("weight tensor has to be contiguous")     # cpp:575
+    _check_cuda_f32(input, offset, mask, weight, grad_output, grad_input, grad_offset, grad_mask, grad_weight, grad_bias)
+    B, Cc, H, W = input.shape
+    Co, Ck, kh_, kw_ = weight.shape
+    if (kh_, kw_) != (kh, kw):
+        raise RuntimeError(f"Input shape and kernel shape wont match: ({kh} x {kw} vs {kh_} x {kw_}).")
+    if Cc != Ck * group:
+        raise RuntimeError(f"Input shape and kernel channels wont match: ({Cc} vs {Ck * group}).")
+    Ho = (H + 2 * ph - (dh * (kh - 1) + 1)) // sh + 1
+    Wo = (W + 2 * pw - (dw * (kw - 1) + 1)) // sw + 1
+    if tuple(offset.shape) != (B, 2 * dg * kh * kw, Ho, Wo):
+        raise RuntimeError(f"invalid offset shape {tuple(offset.shape)}, expected {(B, 2 * dg * kh * kw, Ho, Wo)}")
+    if mask is not None and tuple(mask.shape) != (B, dg * kh * kw, Ho, Wo):
+        raise RuntimeError(f"invalid mask shape {tuple(mask.shape)}")
+    if tuple(grad_output.shape) != (B, Co, Ho, Wo):
+        raise RuntimeError(f"invalid gradOutput shape {tuple(grad_output.shape)}, expected {(B, Co, Ho, Wo)}")
+    for name, t, like in (("grad_input", grad_input, input), ("grad_offset", grad_offset, offset),
+                          ("grad_mask", grad_mask, mask), ("grad_weight", grad_weight, weight)):
+        if t is not None and (t.numel() != like.numel() or not t.is_contiguous()):
+            raise RuntimeError(f"{name} must be a contiguous tensor shaped like its forward counterpart")
+    if grad_bias is not None and (grad_bias.numel() != Co or not grad_bias.is_contiguous()):
+        raise RuntimeError("grad_bias must be a contiguous tensor of Co elements")
+    offset, grad_output = offset.contiguous(), grad_output.contiguous()
+    mask = None if mask is None else mask.contiguous()
+    p = lambda t: C.c_void_p(None if t is None else t.data_ptr())  # noqa: E731
+    _lib.check(_lib.lib().cdfo_dcn_backward(p(input), p(offset), p(mask), p(weight), p(grad_output), p(grad_input),
+                                            p(grad_offset), p(grad_mask), p(grad_weight), p(grad_bias), B, Cc, H, W, Co,
+                                            kh, kw, sh, sw, ph, pw, dh, dw, group, dg, float(scale), _stream()),
+               "cdfo_dcn_backward")
 
 
-def deform_conv_backward_parameters_cuda(*args, **kw):
-    raise NotImplementedError("deform_conv_backward_parameters_cuda: backward kernels are not part of this path yet")
+def deform_conv_backward_input_cuda(input, offset, gradOutput, gradInput, gradOffset, weight, columns, kW, kH, dW, dH,
+                                    padW, padH, dilationW, dilationH, group, deformable_group, im2col_step):
+    """ops/dcn/src/deform_conv_cuda.cpp:260-266.  Returns 1 like the reference (cpp:370)."""
+    _bwd(input, offset, None, weight, gradOutput, gradInput, gradOffset, None, None, None, kH, kW, dH, dW, padH, padW,
+         dilationH, dilationW, group, deformable_group, 1.0)
+    return 1
 
 
-def modulated_deform_conv_cuda_backward(*args, **kw):
-    raise NotImplementedError("modulated_deform_conv_cuda_backward: backward kernels are not part of this path yet")
+def deform_conv_backward_parameters_cuda(input, offset, gradOutput, gradWeight, columns, ones, kW, kH, dW, dH, padW,
+                                         padH, dilationW, dilationH, group, deformable_group, scale, im2col_step):
+    """ops/dcn/src/deform_conv_cuda.cpp:373-378.  ``gradWeight += scale * dW``; returns 1 (cpp:483)."""
+    if gradWeight.dim() != 4 or gradWeight.size(1) * group != input.size(1):
+        raise RuntimeError("gradWeight must be [Co, C/groups, kH, kW]")
+    # the forward weight is not an argument of this entry point (the product only needs its shape)
+    _bwd(input, offset, None, gradWeight, gradOutput, None, None, None, gradWeight, None, kH, kW, dH, dW, padH, padW,
+         dilationH, dilationW, group, deformable_group, scale)
+    return 1
+
+
+def modulated_deform_conv_cuda_backward(input, weight, bias, ones, offset, mask, columns, grad_input, grad_weight,
+                                        grad_bias, grad_offset, grad_mask, grad_output, kernel_h, kernel_w, stride_h,
+                                        stride_w, pad_h, pad_w, dilation_h, dilation_w, group, deformable_group,
+                                        with_bias):
+    """ops/dcn/src/deform_conv_cuda.cpp:566-573."""
+    _bwd(input, offset, mask, weight, grad_output, grad_input, grad_offset, grad_mask, grad_weight,
+         grad_bias if with_bias else None, kernel_h, kernel_w, stride_h, stride_w, pad_h, pad_w, dilation_h, dilation_w,
+         group, deformable_group, 1.0)

@@ -216,6 +216,20 @@ int cdfo_dcn_forward(const float* in, const float* offset, const float* mask, co
                      float* out, int B, int C, int H, int W, int Co, int kh, int kw, int sh, int sw, int ph, int pw,
                      int dh, int dw, int groups, int deformable_groups, void* stream);
 
+/* ---- deformable convolution backward (dcn_bwd.hip) -----------------------------------------------------------
+ * One entry point behind the module's three backward functions: deform_conv_backward_input_cuda
+ * (ops/dcn/src/deform_conv_cuda.cpp:260-266: grad_in + grad_offset; mask, grad_mask, grad_weight, grad_bias NULL),
+ * deform_conv_backward_parameters_cuda (cpp:373-378: grad_weight only, `scale` multiplies the contribution) and
+ * modulated_deform_conv_cuda_backward (cpp:566-573: all five).  Tensors as in cdfo_dcn_forward plus
+ * grad_out [B,Co,Ho,Wo].  Any gradient pointer may be NULL (skipped).  grad_in, grad_weight and grad_bias are
+ * ACCUMULATED into -- the reference's callers hand over zero-filled tensors (ops/dcn/deform_conv.py:71-72, 85,
+ * 154-158) -- grad_offset and grad_mask are assigned.  kh*kw <= 64.  grad_in / grad_weight use fp32 hardware
+ * atomics, so their summation order (not their value beyond fp32 rounding) varies between runs, as in the reference. */
+int cdfo_dcn_backward(const float* in, const float* offset, const float* mask, const float* weight,
+                      const float* grad_out, float* grad_in, float* grad_offset, float* grad_mask, float* grad_weight,
+                      float* grad_bias, int B, int C, int H, int W, int Co, int kh, int kw, int sh, int sw, int ph,
+                      int pw, int dh, int dw, int groups, int deformable_groups, float scale, void* stream);
+
 /* ---- small NCHW operators of the DCN consumer modules DSTA (ops/attentionlayer.py:86-156) and MVDualAttAlignment
  * (arch/SIDECVSR_our.py:3265-3352); contiguous NCHW fp32, one thread per output (nchw_ops.hip) ------------------ */
 int cdfo_conv2d_nchw(const float* in, const float* w, const float* bias, int B, int C, int H, int W, int Co, int kh,

@@ -29,6 +29,8 @@ def _dcn_lib():
         _lib = C.CDLL(_SO)
         _lib.dcn_forward_ref.restype = C.c_int
         _lib.dcn_forward_ref.argtypes = [C.c_void_p] * 6 + [C.c_int] * 15
+        _lib.dcn_backward_ref.restype = C.c_int
+        _lib.dcn_backward_ref.argtypes = [C.c_void_p] * 10 + [C.c_int] * 15 + [C.c_float]
     return _lib
 
 
@@ -53,6 +55,31 @@ def dcn_forward_ref(x, offset, mask, weight, bias, stride=1, pad=0, dil=1, group
     if rc != 0:
         raise ValueError("dcn_forward_ref rejected the shapes")
     return out
+
+
+def dcn_backward_ref(x, offset, mask, weight, gout, stride=1, pad=0, dil=1, groups=1, dg=1, scale=1.0, with_bias=True):
+    """numpy fp32 arrays -> dict(grad_input, grad_offset, grad_mask (DCNv2 only), grad_weight, grad_bias) computed by
+    oracle/dcn_ref.c:dcn_backward_ref from zero-initialised gradients, as the reference's autograd Functions do
+    (ops/dcn/deform_conv.py:60-99, 150-172)."""
+    f = lambda a: None if a is None else np.ascontiguousarray(a, np.float32)  # noqa: E731
+    x, offset, mask, weight, gout = f(x), f(offset), f(mask), f(weight), f(gout)
+    B, Cc, H, W = x.shape
+    Co, _, kh, kw = weight.shape
+    sh, sw = (stride, stride) if isinstance(stride, int) else stride
+    ph, pw = (pad, pad) if isinstance(pad, int) else pad
+    dh, dw = (dil, dil) if isinstance(dil, int) else dil
+    g = dict(grad_input=np.zeros_like(x), grad_offset=np.zeros_like(offset), grad_weight=np.zeros_like(weight))
+    if mask is not None:
+        g["grad_mask"] = np.zeros_like(mask)
+    if with_bias:
+        g["grad_bias"] = np.zeros((Co,), np.float32)
+    p = lambda a: None if a is None else a.ctypes.data  # noqa: E731
+    rc = _dcn_lib().dcn_backward_ref(p(x), p(offset), p(mask), p(weight), p(gout), p(g["grad_input"]), p(g["grad_offset"]),
+                                     p(g.get("grad_mask")), p(g["grad_weight"]), p(g.get("grad_bias")), B, Cc, H, W, Co,
+                                     kh, kw, sh, sw, ph, pw, dh, dw, groups, dg, float(scale))
+    if rc != 0:
+        raise ValueError("dcn_backward_ref rejected the shapes")
+    return g
 
 
 def dcn_torch(x, offset, mask, weight, bias, stride=1, pad=0, dil=1, groups=1, dg=1):

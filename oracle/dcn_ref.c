@@ -1,5 +1,5 @@
 /* ORACLE (test infrastructure, not product code): plain-C restatement of the reference's deformable-convolution
- * FORWARD operators, DCNv1 and modulated DCNv2.  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline
+ * operators, DCNv1 and modulated DCNv2, forward (below) and backward (second half).  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline
  * leg may load this; the product path (libcdfo_hip.so) never does.
  *
  * Follows, in the reference repo:
@@ -73,6 +73,134 @@ int dcn_forward_ref(const float* in, const float* offset, const float* mask, con
           orow[p] = (float)s + (bias ? bias[oc] : 0.f);
         }
       }
+  }
+  free(col);
+  return 0;
+}
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * BACKWARD restatement.  Follows, in the reference repo:
+ *   ops/dcn/src/deform_conv_cuda.cpp:566-680   modulated backward: per image  columns = W^T x grad_output,
+ *                                              col2im_coord -> grad_offset / grad_mask (assigned),
+ *                                              col2im -> grad_input (accumulated), im2col again,
+ *                                              grad_weight += grad_output x columns^T, grad_bias += rowsum
+ *   ops/dcn/src/deform_conv_cuda.cpp:260-371, 373-484  DCNv1: the same split over two entry points
+ *                                              (backward_input, backward_parameters with `scale`)
+ *   ops/dcn/src/deform_conv_cuda_kernel.cu:498-523 / 115-141   gradient weight of a corner (== its bilinear weight;
+ *                                              0 when the sample lies at or beyond -1 / H / W)
+ *   ops/dcn/src/deform_conv_cuda_kernel.cu:525-567 / 143-187   coordinate weight (d sample / d h, d sample / d w)
+ *   ops/dcn/src/deform_conv_cuda_kernel.cu:634-766             col2im and col2im_coord loops
+ * The reference holds no vector for the backward; tests/test_dcn_oracle.py pins this restatement against float64
+ * autograd through an independent gather-based statement of the forward.
+ * Any of gin / goff / gmask / gw / gbias may be NULL (skipped).  gin, gw, gbias are ACCUMULATED into (the reference's
+ * callers zero them first, deform_conv.py:71-72,85,154-158); goff, gmask are assigned. */
+int dcn_backward_ref(const float* in, const float* offset, const float* mask, const float* weight, const float* gout,
+                     float* gin, float* goff, float* gmask, float* gw, float* gbias, int B, int C, int H, int W, int Co,
+                     int kh, int kw, int sh, int sw, int ph, int pw, int dh, int dw, int groups, int dg, float scale) {
+  if (C % groups || Co % groups || C % dg) return -1;
+  const int Ho = (H + 2 * ph - (dh * (kh - 1) + 1)) / sh + 1;
+  const int Wo = (W + 2 * pw - (dw * (kw - 1) + 1)) / sw + 1;
+  if (Ho <= 0 || Wo <= 0) return -1;
+  const int T = kh * kw, P = Ho * Wo, Cg = C / groups, Cog = Co / groups, Cdg = C / dg;
+  float* col = (float*)malloc(sizeof(float) * (size_t)C * T * P);
+  if (!col) return -1;
+  for (int b = 0; b < B; ++b) {
+    /* columns[g] = weight[g]^T x grad_output[b][g]   (cpp:617-620) */
+    for (int c = 0; c < C; ++c) {
+      const int g = c / Cg, cl = c - g * Cg;
+      for (int t = 0; t < T; ++t)
+        for (int p = 0; p < P; ++p) {
+          double s = 0.0;
+          for (int o = 0; o < Cog; ++o)
+            s += (double)weight[((size_t)(g * Cog + o) * Cg + cl) * T + t] * (double)gout[((size_t)b * Co + g * Cog + o) * P + p];
+          col[((size_t)c * T + t) * P + p] = (float)s;
+        }
+    }
+    for (int d = 0; d < dg; ++d) {
+      const float* off = offset + ((size_t)b * dg + d) * 2 * T * P;
+      const float* msk = mask ? mask + ((size_t)b * dg + d) * T * P : NULL;
+      for (int i = 0; i < kh; ++i)
+        for (int j = 0; j < kw; ++j) {
+          const int t = i * kw + j;
+          for (int ho = 0; ho < Ho; ++ho)
+            for (int wo = 0; wo < Wo; ++wo) {
+              const int p = ho * Wo + wo;
+              const float h_im = (float)(ho * sh - ph + i * dh) + off[(size_t)(2 * t) * P + p];
+              const float w_im = (float)(wo * sw - pw + j * dw) + off[(size_t)(2 * t + 1) * P + p];
+              const float m = msk ? msk[(size_t)t * P + p] : 1.f;
+              const int valid = !(h_im <= -1 || w_im <= -1 || h_im >= H || w_im >= W);
+              float vh = 0.f, vw = 0.f, mv = 0.f;
+              if (valid) {
+                const int hl = (int)floorf(h_im), wl = (int)floorf(w_im), hhi = hl + 1, whi = wl + 1;
+                const float lh = h_im - hl, lw = w_im - wl, hh = 1 - lh, hw = 1 - lw;
+                const int c1 = hl >= 0 && wl >= 0, c2 = hl >= 0 && whi <= W - 1, c3 = hhi <= H - 1 && wl >= 0,
+                          c4 = hhi <= H - 1 && whi <= W - 1;
+                for (int cc = 0; cc < Cdg; ++cc) {
+                  const int c = d * Cdg + cc;
+                  const float* im = in + ((size_t)b * C + c) * H * W;
+                  const float cg = col[((size_t)c * T + t) * P + p];
+                  const float v1 = c1 ? im[hl * W + wl] : 0.f, v2 = c2 ? im[hl * W + whi] : 0.f,
+                              v3 = c3 ? im[hhi * W + wl] : 0.f, v4 = c4 ? im[hhi * W + whi] : 0.f;
+                  mv += cg * (hh * hw * v1 + hh * lw * v2 + lh * hw * v3 + lh * lw * v4);       /* cu:733-736 */
+                  vh += (-hw * v1 - lw * v2 + hw * v3 + lw * v4) * cg * m;                       /* cu:543-553 */
+                  vw += (-hh * v1 + hh * v2 - lh * v3 + lh * v4) * cg * m;                       /* cu:554-564 */
+                  if (gin) {                                                                     /* cu:667-683 */
+                    float* gi = gin + ((size_t)b * C + c) * H * W;
+                    const float tg = cg * m;
+                    if (c1) gi[hl * W + wl] += hh * hw * tg;
+                    if (c2) gi[hl * W + whi] += hh * lw * tg;
+                    if (c3) gi[hhi * W + wl] += lh * hw * tg;
+                    if (c4) gi[hhi * W + whi] += lh * lw * tg;
+                  }
+                }
+              }
+              if (goff) {
+                goff[(((size_t)b * dg + d) * 2 * T + 2 * t) * P + p] = vh;
+                goff[(((size_t)b * dg + d) * 2 * T + 2 * t + 1) * P + p] = vw;
+              }
+              if (gmask) gmask[(((size_t)b * dg + d) * T + t) * P + p] = mv;
+            }
+        }
+    }
+    if (gw || gbias) {
+      /* im2col again (cpp:637-641), then grad_weight[g] += grad_output[b][g] x columns[g]^T (cpp:650-655) */
+      for (int c = 0; c < C; ++c) {
+        const int d = c / Cdg;
+        const float* im = in + ((size_t)b * C + c) * H * W;
+        const float* off = offset + ((size_t)b * dg + d) * 2 * T * P;
+        const float* msk = mask ? mask + ((size_t)b * dg + d) * T * P : NULL;
+        for (int i = 0; i < kh; ++i)
+          for (int j = 0; j < kw; ++j) {
+            const int t = i * kw + j;
+            for (int ho = 0; ho < Ho; ++ho)
+              for (int wo = 0; wo < Wo; ++wo) {
+                const int p = ho * Wo + wo;
+                const float h_im = (float)(ho * sh - ph + i * dh) + off[(size_t)(2 * t) * P + p];
+                const float w_im = (float)(wo * sw - pw + j * dw) + off[(size_t)(2 * t + 1) * P + p];
+                float v = 0.f;
+                if (h_im > -1 && w_im > -1 && h_im < H && w_im < W) v = bilinear(im, H, W, h_im, w_im);
+                if (msk) v *= msk[(size_t)t * P + p];
+                col[((size_t)c * T + t) * P + p] = v;
+              }
+          }
+      }
+      for (int oc = 0; oc < Co; ++oc) {
+        const int g = oc / Cog;
+        const float* go = gout + ((size_t)b * Co + oc) * P;
+        if (gw)
+          for (int k = 0; k < Cg * T; ++k) {
+            double s = 0.0;
+            const float* cr = col + ((size_t)g * Cg * T + k) * P;
+            for (int p = 0; p < P; ++p) s += (double)go[p] * (double)cr[p];
+            gw[(size_t)oc * Cg * T + k] += scale * (float)s;
+          }
+        if (gbias) {
+          double s = 0.0;
+          for (int p = 0; p < P; ++p) s += go[p];
+          gbias[oc] += (float)s;
+        }
+      }
+    }
   }
   free(col);
   return 0;

@@ -63,3 +63,74 @@ def test_mask_scales_linearly_and_fractional_offsets_interpolate():
     ref = F.conv2d(torch.from_numpy(xa), torch.from_numpy(w), None).numpy()       # valid conv on the 5x5 average
     full = dcn_forward_ref(x, off, None, w, None, pad=1)
     assert np.abs(full[:, :, 1:4, 1:4] - ref).max() < 1e-5
+
+
+# ------------------------------------------------------------------------------------------------ backward restatement
+def _dcn_forward_f64(x, offset, mask, w, b, s, p, d, groups, dg):
+    """Independent, differentiable statement of the operator (float64, gather based) used only to pin the C oracle's
+    backward: out = sum_taps W * mask * bilinear(x, base + offset), corners outside the image contribute 0."""
+    B, C, H, W = x.shape
+    Co, Cg, kh, kw = w.shape
+    T = kh * kw
+    Ho = (H + 2 * p - (d * (kh - 1) + 1)) // s + 1
+    Wo = (W + 2 * p - (d * (kw - 1) + 1)) // s + 1
+    Cdg = C // dg
+    ys = (torch.arange(Ho, dtype=x.dtype) * s - p).view(1, 1, Ho, 1)
+    xs = (torch.arange(Wo, dtype=x.dtype) * s - p).view(1, 1, 1, Wo)
+    cols = []
+    for t in range(T):
+        i, j = divmod(t, kw)
+        off = offset.view(B, dg, T, 2, Ho, Wo)[:, :, t]
+        hy = ys + i * d + off[:, :, 0]                                       # [B, dg, Ho, Wo]
+        wx = xs + j * d + off[:, :, 1]
+        hl, wl = torch.floor(hy).detach(), torch.floor(wx).detach()
+        lh, lw = hy - hl, wx - wl
+        xg = x.view(B, dg, Cdg, H * W)
+        val = 0
+        for (dy, dx, wt) in ((0, 0, (1 - lh) * (1 - lw)), (0, 1, (1 - lh) * lw), (1, 0, lh * (1 - lw)), (1, 1, lh * lw)):
+            yy, xx = hl + dy, wl + dx
+            ok = ((yy >= 0) & (yy <= H - 1) & (xx >= 0) & (xx <= W - 1)).to(x.dtype)
+            idx = (yy.clamp(0, H - 1) * W + xx.clamp(0, W - 1)).long().view(B, dg, 1, Ho * Wo).expand(B, dg, Cdg, Ho * Wo)
+            val = val + torch.gather(xg, 3, idx).view(B, dg, Cdg, Ho, Wo) * (wt * ok).unsqueeze(2)
+        if mask is not None:
+            val = val * mask.view(B, dg, T, Ho, Wo)[:, :, t].unsqueeze(2)
+        cols.append(val.reshape(B, C, Ho, Wo))
+    col = torch.stack(cols, 2)                                               # [B, C, T, Ho, Wo]
+    col = col.view(B, groups, Cg * T, Ho * Wo)
+    out = torch.einsum("gok,bgkp->bgop", w.view(groups, Co // groups, Cg * T), col).reshape(B, Co, Ho, Wo)
+    return out if b is None else out + b.view(1, -1, 1, 1)
+
+
+def test_backward_restatement_matches_float64_autograd():
+    from oracle.dcn_modules_ref import dcn_backward_ref
+    for n, (C, Co, k, s, p, d, g, dg, modulated) in enumerate([(8, 6, 3, 1, 1, 1, 1, 4, True), (8, 8, 3, 2, 1, 1, 2, 2, True),
+                                                              (4, 4, 3, 1, 2, 2, 1, 1, False), (6, 3, 1, 1, 0, 1, 3, 3, True),
+                                                              (4, 2, 3, 1, 1, 1, 2, 1, False)]):
+        rs = np.random.RandomState(100 + n)
+        B, H, W = 2, 7, 9
+        Ho = (H + 2 * p - (d * (k - 1) + 1)) // s + 1
+        Wo = (W + 2 * p - (d * (k - 1) + 1)) // s + 1
+        x = rs.standard_normal((B, C, H, W)).astype(np.float32)
+        w = rs.standard_normal((Co, C // g, k, k)).astype(np.float32)
+        b = rs.standard_normal((Co,)).astype(np.float32)
+        off = (3.0 * rs.standard_normal((B, 2 * dg * k * k, Ho, Wo))).astype(np.float32)     # many samples leave the image
+        msk = rs.uniform(0, 1, (B, dg * k * k, Ho, Wo)).astype(np.float32) if modulated else None
+        go = rs.standard_normal((B, Co, Ho, Wo)).astype(np.float32)
+        got = dcn_backward_ref(x, off, msk, w, go, s, p, d, g, dg, scale=1.0, with_bias=True)
+        tx, tw, tb, toff = [torch.from_numpy(a).double().requires_grad_() for a in (x, w, b, off)]
+        tm = None if msk is None else torch.from_numpy(msk).double().requires_grad_()
+        out = _dcn_forward_f64(tx, toff, tm, tw, tb, s, p, d, g, dg)
+        fwd = dcn_forward_ref(x, off, msk, w, b, s, p, d, g, dg)
+        assert np.abs(out.detach().numpy() - fwd).max() < 1e-4                 # the two forward statements agree
+        out.backward(torch.from_numpy(go).double())
+        want = dict(grad_input=tx.grad, grad_offset=toff.grad, grad_weight=tw.grad, grad_bias=tb.grad)
+        if tm is not None:
+            want["grad_mask"] = tm.grad
+        for key, ref in want.items():
+            ref = ref.numpy()
+            err = np.abs(got[key] - ref).max() / max(1.0, np.abs(ref).max())
+            assert err < 2e-5, (n, key, err)
+        # `scale` multiplies the weight gradient only (cpp:373-378, deform_conv.py:92)
+        half = dcn_backward_ref(x, off, msk, w, go, s, p, d, g, dg, scale=0.5, with_bias=True)
+        assert np.allclose(half["grad_weight"], 0.5 * got["grad_weight"], atol=1e-5)
+        assert np.array_equal(half["grad_input"], got["grad_input"])

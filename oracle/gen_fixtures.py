@@ -282,6 +282,73 @@ def gen_metrics_psnr():
     print(f"metrics psnr -> {path}: {out.tolist()}")
 
 
+V7_CASES = {   # name: (B, H, W, weight seed, input seed, layout, cached)
+    "b1_16x16": (1, 16, 16, 21, 201, "b1n", False),
+    "b2_16x24_bn1": (2, 16, 24, 22, 202, "bn1", False),
+    "b1_24x32_cached": (1, 24, 32, 23, 203, "b1n", True),
+}
+
+
+def run_case_v7(ref, name, B, H, W, wseed, iseed, layout, cached):
+    """The REAL ``CVSR_V7`` (arch.py:4215-4367) on seeded weights / inputs; its RDAB noise is fed from the seeded list
+    by intercepting ``torch.rand_like`` and its ``torchvision.ops.deform_conv2d`` is the C oracle (load_reference)."""
+    from oracle.cvsr_v7_ref import make_inputs_v7, make_state_dict_v7
+    sd = make_state_dict_v7(wseed)
+    model = ref.CVSR_V7()
+    model.load_state_dict(sd, strict=True)
+    model.eval()
+    inp = make_inputs_v7(B, H, W, iseed, layout)
+    queue = list(inp["gumbel_u"])
+    real_rand_like = torch.rand_like
+
+    def fake_rand_like(t, *a, **k):
+        u = queue.pop(0)
+        assert u.shape == t.shape, (u.shape, t.shape)
+        return u
+
+    taps = {}
+    hooks = []
+    for nm in ("transformer_feature_extraction", "RDAB", "MV_deform_align", "fb_fusion", "tsa_fusion"):
+        lst = taps.setdefault(nm, [])
+        hooks.append(getattr(model, nm).register_forward_hook(lambda m, i, o, lst=lst: lst.append(o.detach().clone())))
+    trunk = []
+    hooks.append(model.recon_trunk.register_forward_hook(lambda m, i, o: trunk.extend(t.detach().clone() for t in o)))
+    pre = None
+    if cached:
+        prev = make_inputs_v7(B, H, W, iseed + 1000, layout)
+        with torch.no_grad():
+            torch.rand_like = lambda t, *a, **k: real_rand_like(t)
+            try:
+                _, pre = model(prev["x"], prev["mvs0"], prev["mvs1"], prev["pms"], prev["rms"], prev["ufs"])
+            finally:
+                torch.rand_like = real_rand_like
+        for lst in taps.values():
+            lst.clear()
+        trunk.clear()
+    torch.rand_like = fake_rand_like
+    try:
+        with torch.no_grad():
+            out, L1 = model(inp["x"], inp["mvs0"], inp["mvs1"], inp["pms"], inp["rms"], inp["ufs"], pre)
+    finally:
+        torch.rand_like = real_rand_like
+    for h in hooks:
+        h.remove()
+    assert not queue, "reference drew fewer noise tensors than expected"
+    rec = dict(B=B, H=H, W=W, wseed=wseed, iseed=iseed, layout=layout, cached=int(cached), out=out.numpy(),
+               L1_moments=moments(L1), L1_fea=L1.numpy())
+    if cached:
+        rec["pre_L1_fea"] = pre.numpy()
+    for j, t in enumerate(trunk):
+        rec[f"trunk_L{j + 1}"] = t.numpy()
+    for nm, lst in taps.items():
+        for j, t in enumerate(lst):
+            rec[f"tap_{nm}_{j}_moments"] = moments(t)
+            rec[f"tap_{nm}_{j}_sample"] = t.flatten()[::61].numpy().copy()
+    path = os.path.join(REPO, "tests", "golden", f"cvsr_v7_{name}.npz")
+    np.savez_compressed(path, **rec)
+    print(f"v7 {name}: out {tuple(out.shape)} mean {out.mean():.6f} -> {path} ({os.path.getsize(path)/1024:.0f} KiB)")
+
+
 def main():
     if sys.argv[1:] == ["streaming"]:
         return gen_streaming_helpers()
@@ -293,6 +360,10 @@ def main():
         if only and name not in only:
             continue
         run_case(ref, name, *cfg)
+    for name, cfg in V7_CASES.items():
+        if only and "v7_" + name not in only:
+            continue
+        run_case_v7(ref, name, *cfg)
     ref_att = load_reference_dsta()
     for name, cfg in MODULE_CASES.items():
         if only and name not in only:

@@ -543,6 +543,60 @@ def spatial_gate16(x: torch.Tensor, w: torch.Tensor, bias: torch.Tensor) -> torc
     return out
 
 
+# ----------------------------------------------------------------------------------------------- CVSR_V7 operators
+def chan_pool(x: torch.Tensor) -> torch.Tensor:
+    """[B,H,W,64] -> [B,H,W,2] = (max over channels, mean over channels)."""
+    B, H, W, Cc, ld = _chk_act(x)
+    out = torch.empty((B, H, W, 2), dtype=torch.float32, device=x.device)
+    check(_lib.lib().cdfo_chan_pool(_vp(x), ld, C.c_longlong(B * H * W), Cc, _vp(out), _stream()), "cdfo_chan_pool")
+    return out
+
+
+def spatial_gate(x: torch.Tensor, w: torch.Tensor, bias: torch.Tensor) -> torch.Tensor:
+    """SpatialAttention: x * sigmoid(conv(pool(x))); w: the [1,2,ks,ks] weight."""
+    B, H, W, Cc, ld = _chk_act(x)
+    out = empty_act(B, H, W, Cc, x.device)
+    check(_lib.lib().cdfo_spatial_gate(_vp(x), ld, _vp(chan_pool(x)), _vp(w), _vp(bias), B, H, W, Cc, int(w.shape[-1]),
+                                       _vp(out), Cc, _stream()), "cdfo_spatial_gate")
+    return out
+
+
+def rdab_mix(xf: torch.Tensor, xc: torch.Tensor, w3: torch.Tensor, b3: torch.Tensor, vmax: torch.Tensor,
+             noise: torch.Tensor) -> torch.Tensor:
+    B, H, W, Cc, ld = _chk_act(xf)
+    if tuple(noise.shape) != (B, 64, H, W) or not noise.is_contiguous() or noise.dtype != torch.float32:
+        raise ValueError(f"rdab_mix: noise must be a contiguous fp32 [B,64,H,W] tensor, got {tuple(noise.shape)}")
+    if tuple(vmax.shape) != (B, 64) or tuple(w3.shape) != (1, 2, 3, 3):
+        raise ValueError("rdab_mix: vmax must be [B,64] and the spatial weight [1,2,3,3]")
+    out = empty_act(B, H, W, 64, xf.device)
+    check(_lib.lib().cdfo_rdab_mix(_vp(xf), ld, _vp(chan_pool(xc)), _vp(w3), _vp(b3), _vp(vmax), _vp(noise), B, H, W,
+                                   _vp(out), 64, _stream()), "cdfo_rdab_mix")
+    return out
+
+
+def shrink_planes(t: torch.Tensor, level: int) -> torch.Tensor:
+    """t: fp32 [B,C,H,W] whose images are dense (any batch stride) -> contiguous [B,C,H>>level,W>>level]."""
+    B, Cc, H, W = t.shape
+    if t.stride(3) != 1 or t.stride(2) != W or t.stride(1) != H * W:
+        t = t.contiguous()
+    out = torch.empty((B, Cc, H >> level, W >> level), dtype=torch.float32, device=t.device)
+    check(_lib.lib().cdfo_shrink_planes(_vp(t), C.c_longlong(t.stride(0)), Cc, B, H, W, level, _vp(out), _stream()),
+          "cdfo_shrink_planes")
+    return out
+
+
+def lincomb(a: torch.Tensor, ca: float, b: Optional[torch.Tensor] = None, cb: float = 0.0,
+            c: Optional[torch.Tensor] = None, cc: float = 0.0, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    for t in (a, b, c, out):
+        if t is not None and (not t.is_contiguous() or t.dtype != torch.float32 or t.shape != a.shape):
+            raise ValueError("lincomb: contiguous fp32 tensors of one shape expected")
+    if out is None:
+        out = torch.empty_like(a)
+    check(_lib.lib().cdfo_lincomb(_vp(out), _vp(a), float(ca), _vp(b), float(cb), _vp(c), float(cc),
+                                  C.c_longlong(a.numel()), _stream()), "cdfo_lincomb")
+    return out
+
+
 # ----------------------------------------------------------------------------------------------- reductions / folds
 def nchunks_for(P: int) -> int:
     return max(1, min(128, P // 1024))

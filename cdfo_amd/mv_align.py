@@ -60,14 +60,17 @@ class MVDualAttAlignment(ModulatedDeformConvPack):
             raise NotImplementedError("MVDualAttAlignment (HIP): forward only -- wrap the call in torch.no_grad()")
         if self.in_channels != 64 or self.out_channels != 64:
             raise NotImplementedError("MVDualAttAlignment (HIP): specialised for 64 channels (arch.py:4242)")
+        x = x.contiguous().float()
+        return self.forward_pm(x, K.nchw_to_nhwc(x), K.nchw_to_nhwc(extra_feat.float()), K.nchw_to_nhwc(pred_feat.float()),
+                               flow_1.contiguous().float())
+
+    def forward_pm(self, x, xq, extra, pred, flow):
+        """The same computation for callers that already hold pixel-major tensors (``CVSR_V7``): ``x`` NCHW (the DCN's
+        input), ``xq`` = the same features pixel-major [B,H,W,64], ``extra`` / ``pred`` pixel-major, ``flow`` NCHW
+        [B,2,H,W] contiguous.  Returns the aligned features NCHW."""
         w = self._weights()
         B, _, H, W = x.shape
         P = H * W
-        x = x.contiguous().float()
-        flow = flow_1.contiguous().float()
-        xq = K.nchw_to_nhwc(x)
-        extra = K.nchw_to_nhwc(extra_feat.float())
-        pred = K.nchw_to_nhwc(pred_feat.float())
         d = lambda t: t.detach().contiguous()  # noqa: E731
         warped = K.flow_warp(extra, flow, 2 * P)
         fused = K.conv([warped, pred], w["fusion"])                      # no activation here (arch.py:3305)

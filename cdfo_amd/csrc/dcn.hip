@@ -19,9 +19,11 @@ namespace {
 constexpr int CC = 4;      // input channels per K chunk
 constexpr int PIXT = 64;   // output pixels per workgroup
 constexpr int MAXJ = 4;    // up to 4 x 64 output channels per workgroup
+constexpr int WSTR = 257;  // LDS row pitch of the staged weights: odd, so that the transposing store (lanes = consecutive k) is conflict-free
 
 struct DcnArgs {
   const float* in; const float* offset; const float* mask; const float* w; const float* bias; float* out;
+  const float* gp;   // optional group-planar copy of `in`: [B][dg][H][W][C/dg] (see dcn_to_gp_kernel)
   int B, C, H, W, Co, Ho, Wo, kh, kw, sh, sw, ph, pw, dh, dw, groups, dg;
 };
 
@@ -39,10 +41,30 @@ __device__ __forceinline__ float bilinear_zero(const float* __restrict__ plane, 
   return (hh * hw) * v1 + (hh * lw) * v2 + (lh * hw) * v3 + (lh * lw) * v4;
 }
 
+// in NCHW -> group-planar [B][dg][H][W][C/dg]: the C/dg channels that share one sample position become contiguous, so
+// a bilinear corner of a 4-channel chunk is ONE 16-byte gather instead of four 4-byte ones
+__global__ __launch_bounds__(256) void dcn_to_gp_kernel(const float* __restrict__ in, float* __restrict__ gp, int B, int C,
+                                                        int dg, long long HW) {
+  const int Cdg = C / dg;
+  const long long n = (long long)B * dg * HW;
+  const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (gid >= n) return;
+  const long long p = gid % HW, bd = gid / HW;                  // bd = b*dg + d
+  const float* src = in + bd * Cdg * HW + p;
+  float* dst = gp + gid * Cdg;
+  for (int c = 0; c < Cdg; c += 4) {
+    f32x4 v;
+    v[0] = src[(long long)c * HW]; v[1] = src[(long long)(c + 1) * HW];
+    v[2] = src[(long long)(c + 2) * HW]; v[3] = src[(long long)(c + 3) * HW];
+    *reinterpret_cast<f32x4*>(dst + c) = v;
+  }
+}
+
+template <bool GP>
 __global__ __launch_bounds__(256) void dcn_fwd_kernel(DcnArgs a, int KCH /* = CC*kh*kw rounded up to even */) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* col = smem;               // [KCH][64]
-  float* wt = smem + KCH * PIXT;   // [KCH][256]
+  float* wt = smem + KCH * PIXT;   // [KCH][WSTR]
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, h = lane >> 5, r = lane & 31;
   const int T = a.kh * a.kw;
   const int Cg = a.C / a.groups, Cog = a.Co / a.groups, Cdg = a.C / a.dg;
@@ -65,34 +87,75 @@ __global__ __launch_bounds__(256) void dcn_fwd_kernel(DcnArgs a, int KCH /* = CC
 
   for (int c0 = 0; c0 < Cg; c0 += CC) {
     __syncthreads();
-    // ---- sample: item = (k = cc*T + t, pixel i)
-    for (int item = tid; item < KCH * PIXT; item += 256) {
-      const int i = item & (PIXT - 1), k = item >> 6;
-      const int cc = k / T, t = k - cc * T;
-      const int p = p0 + i;
-      float val = 0.f;
-      if (cc < CC && c0 + cc < Cg && p < P) {
-        const int c = g * Cg + c0 + cc;                         // absolute input channel
-        const int d = c / Cdg;                                   // deformable group
-        const int ho = p / a.Wo, wo = p - ho * a.Wo;
-        const int ki = t / a.kw, kj = t - ki * a.kw;
-        const float oh = off_b[((long long)(d * T + t) * 2) * P + p];
-        const float ow = off_b[((long long)(d * T + t) * 2 + 1) * P + p];
-        const float h_im = (float)(ho * a.sh - a.ph + ki * a.dh) + oh;
-        const float w_im = (float)(wo * a.sw - a.pw + kj * a.dw) + ow;
-        if (h_im > -1.f && w_im > -1.f && h_im < (float)a.H && w_im < (float)a.W) {
-          val = bilinear_zero(in_b + (long long)c * a.H * a.W, a.H, a.W, h_im, w_im);
-          if (msk_b) val *= msk_b[(long long)(d * T + t) * P + p];
+    if constexpr (GP) {
+      // ---- sample: item = (tap t, pixel i); the chunk's 4 channels share the position (same deformable group)
+      const int c = g * Cg + c0, d = c / Cdg, cin = c - d * Cdg;
+      const float* gp_b = a.gp + ((long long)(b * a.dg + d) * a.H * a.W) * Cdg + cin;
+      for (int item = tid; item < T * PIXT; item += 256) {
+        const int i = item & (PIXT - 1), t = item >> 6;
+        const int p = p0 + i;
+        f32x4 val = {0.f, 0.f, 0.f, 0.f};
+        if (p < P) {
+          const int ho = p / a.Wo, wo = p - ho * a.Wo;
+          const int ki = t / a.kw, kj = t - ki * a.kw;
+          const float oh = off_b[((long long)(d * T + t) * 2) * P + p];
+          const float ow = off_b[((long long)(d * T + t) * 2 + 1) * P + p];
+          const float h_im = (float)(ho * a.sh - a.ph + ki * a.dh) + oh;
+          const float w_im = (float)(wo * a.sw - a.pw + kj * a.dw) + ow;
+          if (h_im > -1.f && w_im > -1.f && h_im < (float)a.H && w_im < (float)a.W) {
+            const int hl = (int)floorf(h_im), wl = (int)floorf(w_im), hh_ = hl + 1, wh_ = wl + 1;
+            const float lh = h_im - (float)hl, lw = w_im - (float)wl, hh = 1.f - lh, hw = 1.f - lw;
+            const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+            const f32x4 v1 = (hl >= 0 && wl >= 0) ? *reinterpret_cast<const f32x4*>(gp_b + ((long long)hl * a.W + wl) * Cdg) : z;
+            const f32x4 v2 = (hl >= 0 && wh_ <= a.W - 1) ? *reinterpret_cast<const f32x4*>(gp_b + ((long long)hl * a.W + wh_) * Cdg) : z;
+            const f32x4 v3 = (hh_ <= a.H - 1 && wl >= 0) ? *reinterpret_cast<const f32x4*>(gp_b + ((long long)hh_ * a.W + wl) * Cdg) : z;
+            const f32x4 v4 = (hh_ <= a.H - 1 && wh_ <= a.W - 1) ? *reinterpret_cast<const f32x4*>(gp_b + ((long long)hh_ * a.W + wh_) * Cdg) : z;
+            const float m = msk_b ? msk_b[(long long)(d * T + t) * P + p] : 1.f;
+            const float w1 = hh * hw, w2 = hh * lw, w3 = lh * hw, w4 = lh * lw;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              // same expression order as bilinear_zero(), then the mask
+              const float sv = w1 * v1[e] + w2 * v2[e] + w3 * v3[e] + w4 * v4[e];
+              val[e] = msk_b ? sv * m : sv;
+            }
+          }
         }
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (c0 + e < Cg) col[(e * T + t) * PIXT + i] = val[e];
       }
-      col[k * PIXT + i] = val;
+      if (KCH > CC * T)                                           // the odd padding row of the K = 2 MFMA step
+        for (int i = tid; i < PIXT; i += 256) col[CC * T * PIXT + i] = 0.f;
+    } else {
+      // ---- sample: item = (k = cc*T + t, pixel i)
+      for (int item = tid; item < KCH * PIXT; item += 256) {
+        const int i = item & (PIXT - 1), k = item >> 6;
+        const int cc = k / T, t = k - cc * T;
+        const int p = p0 + i;
+        float val = 0.f;
+        if (cc < CC && c0 + cc < Cg && p < P) {
+          const int c = g * Cg + c0 + cc;                         // absolute input channel
+          const int d = c / Cdg;                                   // deformable group
+          const int ho = p / a.Wo, wo = p - ho * a.Wo;
+          const int ki = t / a.kw, kj = t - ki * a.kw;
+          const float oh = off_b[((long long)(d * T + t) * 2) * P + p];
+          const float ow = off_b[((long long)(d * T + t) * 2 + 1) * P + p];
+          const float h_im = (float)(ho * a.sh - a.ph + ki * a.dh) + oh;
+          const float w_im = (float)(wo * a.sw - a.pw + kj * a.dw) + ow;
+          if (h_im > -1.f && w_im > -1.f && h_im < (float)a.H && w_im < (float)a.W) {
+            val = bilinear_zero(in_b + (long long)c * a.H * a.W, a.H, a.W, h_im, w_im);
+            if (msk_b) val *= msk_b[(long long)(d * T + t) * P + p];
+          }
+        }
+        col[k * PIXT + i] = val;
+      }
     }
     // ---- weights of this chunk, transposed: wt[k][o] = W[g*Cog + co0 + o][c0*T + k]
-    for (int item = tid; item < KCH * 256; item += 256) {
+    for (int item = tid; item < KCH * ((nco + 63) & ~63); item += 256) {   // only the 64-channel groups the MFMAs read
       const int k = item % KCH, o = item / KCH;
       float v = 0.f;
       if (o < nco && k < CC * T && c0 * T + k < Cg * T) v = a.w[((long long)(g * Cog + co0 + o) * Cg + c0) * T + k];
-      wt[k * 256 + o] = v;
+      wt[k * WSTR + o] = v;
     }
     __syncthreads();
     for (int k = 0; k < KCH; k += 2) {
@@ -100,7 +163,7 @@ __global__ __launch_bounds__(256) void dcn_fwd_kernel(DcnArgs a, int KCH /* = CC
 #pragma unroll
       for (int j = 0; j < MAXJ; ++j) {
         if (j * 64 < nco) {
-          const float av = wt[(k + h) * 256 + j * 64 + mt * 32 + r];
+          const float av = wt[(k + h) * WSTR + j * 64 + mt * 32 + r];
           acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[j], 0, 0, 0);
         }
       }
@@ -128,7 +191,8 @@ __global__ __launch_bounds__(256) void dcn_fwd_kernel(DcnArgs a, int KCH /* = CC
 
 extern "C" int cdfo_dcn_forward(const float* in, const float* offset, const float* mask, const float* weight,
                                 const float* bias, float* out, int B, int C, int H, int W, int Co, int kh, int kw, int sh,
-                                int sw, int ph, int pw, int dh, int dw, int groups, int deformable_groups, void* stream) {
+                                int sw, int ph, int pw, int dh, int dw, int groups, int deformable_groups, void* workspace,
+                                long long workspace_bytes, void* stream) {
   if (B <= 0 || C <= 0 || Co <= 0 || kh <= 0 || kw <= 0 || sh <= 0 || sw <= 0 || dh <= 0 || dw <= 0 || groups <= 0 ||
       deformable_groups <= 0)
     return CDFO_EINVAL;
@@ -136,16 +200,22 @@ extern "C" int cdfo_dcn_forward(const float* in, const float* offset, const floa
   const int Ho = (H + 2 * ph - (dh * (kh - 1) + 1)) / sh + 1;
   const int Wo = (W + 2 * pw - (dw * (kw - 1) + 1)) / sw + 1;
   if (Ho <= 0 || Wo <= 0) return CDFO_EINVAL;
-  DcnArgs a{in, offset, mask, weight, bias, out, B, C, H, W, Co, Ho, Wo, kh, kw, sh, sw, ph, pw, dh, dw, groups,
+  DcnArgs a{in, offset, mask, weight, bias, out, nullptr, B, C, H, W, Co, Ho, Wo, kh, kw, sh, sw, ph, pw, dh, dw, groups,
             deformable_groups};
+  // group-planar gathers need: a caller-provided scratch copy of `in`, 4-channel chunks that never straddle a
+  // deformable group or a conv group, 16-byte aligned rows
+  const bool gp = workspace && workspace_bytes >= (long long)B * C * H * W * 4 && aligned16(workspace) &&
+                  (C / deformable_groups) % 4 == 0 && (C / groups) % 4 == 0;
   const int T = kh * kw;
   const int KCH = (CC * T + 1) / 2 * 2;
-  const size_t lds = (size_t)KCH * (PIXT + 256) * sizeof(float);
+  const size_t lds = (size_t)KCH * (PIXT + WSTR) * sizeof(float);
   if (lds > 160 * 1024) return CDFO_EINVAL;
   static size_t attr = 0;
   if (lds > attr) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dcn_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              (int)lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dcn_fwd_kernel<false>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dcn_fwd_kernel<true>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr = lds;
   }
   const int Cog = Co / groups;
@@ -154,7 +224,15 @@ extern "C" int cdfo_dcn_forward(const float* in, const float* offset, const floa
   const double px = (double)B * Ho * Wo;
   CdfoProfScope prof(st, KID_DCN, 2.0 * px * Co * (C / groups) * T,
                      4.0 * (px * (Co + 3.0 * deformable_groups * T) + (double)B * C * H * W + (double)Co * (C / groups) * T));
-  hipLaunchKernelGGL(dcn_fwd_kernel, grid, dim3(256), lds, st, a, KCH);
+  if (gp) {
+    a.gp = static_cast<const float*>(workspace);
+    const long long n = (long long)B * deformable_groups * H * W;
+    hipLaunchKernelGGL(dcn_to_gp_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, in,
+                       static_cast<float*>(workspace), B, C, deformable_groups, (long long)H * W);
+    hipLaunchKernelGGL(dcn_fwd_kernel<true>, grid, dim3(256), lds, st, a, KCH);
+  } else {
+    hipLaunchKernelGGL(dcn_fwd_kernel<false>, grid, dim3(256), lds, st, a, KCH);
+  }
   CDFO_LAUNCH_CHECK();
   return 0;
 }

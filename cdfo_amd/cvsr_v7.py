@@ -265,11 +265,11 @@ class CVSR_V7(nn.Module):
         if noise is not None and len(noise) != N_DRAWS:
             raise ValueError(f"gumbel_uniform must hold the {N_DRAWS} draws of one forward, got {len(noise)}")
         align = self.MV_deform_align
+        align.precision = self.precision
         dev = x.device
         draw = 0
         prev = None
         fused_pyr: List[torch.Tensor] = []
-        keep = []
         # 3. per level, coarse to fine (arch.py:4275-4347)
         for lv in (2, 1, 0):
             h, wd = H >> lv, W >> lv
@@ -299,7 +299,6 @@ class CVSR_V7(nn.Module):
                 x_n = self._rdab(w, rms_prior, fea_com, u)
                 fea_i = self._conv([Lf[i], x_n], w["conv_expand_fea_r"], pad=1)
                 out = K.nchw_to_nhwc(align.forward_pm(centre_nchw, Lf[ctr], fea_i, ufs_prior, mv))
-                keep.extend([mv, u_img, r_img, ufs_prior, rms_prior, fea_com, u, x_n, fea_i])
                 return out
 
             back = {i: neighbour(i, mvs[0]) for i in range(N - 1, -1, -1) if i != ctr}

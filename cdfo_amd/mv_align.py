@@ -39,6 +39,9 @@ class MVDualAttAlignment(ModulatedDeformConvPack):
         self.sigmoid = nn.Sigmoid()
         nn.init.constant_(self.conv_offset[-1].weight, 0)
         nn.init.constant_(self.conv_offset[-1].bias, 0)
+        # arithmetic of the 64->64->432 offset/mask head (the module's FLOPs): "bf16x3" = split-bf16 matrix cores,
+        # fp32-grade (~1e-6 relative; the head's output is scaled by 10 px, so nothing coarser), or "f32" = exact
+        self.precision = "bf16x3"
         self._packed = None
         self._sig = None
 
@@ -72,6 +75,7 @@ class MVDualAttAlignment(ModulatedDeformConvPack):
         B, _, H, W = x.shape
         P = H * W
         d = lambda t: t.detach().contiguous()  # noqa: E731
+        prec = K.PREC_BF16X3 if self.precision == "bf16x3" else K.PREC_F32
         warped = K.flow_warp(extra, flow, 2 * P)
         fused = K.conv([warped, pred], w["fusion"])                      # no activation here (arch.py:3305)
         gp, ng = K.gram_partial(xq, fused, 8)
@@ -82,8 +86,8 @@ class MVDualAttAlignment(ModulatedDeformConvPack):
             gate = K.vec_mlp(part, n, P, d(self.conv_du[0].weight), d(self.conv_du[0].bias), self.out_channels // 16,
                              K.ACT_RELU, d(self.conv_du[2].weight), d(self.conv_du[2].bias), 64, K.ACT_SIGMOID)
             o = K.conv(K.scale_channels(v, gate), fold)                   # project_out(attn @ (v * gate))
-            o = K.conv(o, w["off0"], pad=1, act=K.ACT_LRELU)            # exact fp32: offsets are scaled by 10
-            outs.append(K.conv(o, w["off2"], pad=1))                      # [B,H,W,27*dg]
+            o = K.conv(o, w["off0"], pad=1, act=K.ACT_LRELU, prec=prec)
+            outs.append(K.conv(o, w["off2"], pad=1, prec=prec))           # [B,H,W,27*dg]
         third = 9 * self.deformable_groups
         offset = torch.empty((B, 2 * third, H, W), dtype=torch.float32, device=x.device)
         mask = torch.empty((B, third, H, W), dtype=torch.float32, device=x.device)

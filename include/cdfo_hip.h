@@ -210,11 +210,15 @@ int cdfo_seq_attn(const float* q, int ldq, const float* v, int ldv, float* out, 
  * modulated_deform_conv_cuda_forward (ops/dcn/src/deform_conv_cuda.cpp:486-492) of the pybind module
  * `deform_conv_cuda` (cpp:681-695).  NCHW fp32 contiguous tensors exactly as the reference passes them:
  * in [B,C,H,W], offset [B,2*dg*kh*kw,Ho,Wo], mask [B,dg*kh*kw,Ho,Wo] or NULL, weight [Co,C/groups,kh,kw],
- * bias [Co] or NULL, out [B,Co,Ho,Wo] (written, not accumulated).  The reference's `columns`/`ones` scratch tensors
- * have no counterpart: sampling and contraction are fused.  */
+ * bias [Co] or NULL, out [B,Co,Ho,Wo] (written, not accumulated).  The reference's `columns` scratch tensor
+ * [C*kh*kw, Ho*Wo] has no counterpart (sampling and contraction are fused); `workspace` is an optional device scratch
+ * of at least B*C*H*W*4 bytes (16-byte aligned) in which the kernel keeps a group-planar copy of `in` so that the
+ * bilinear corners of a deformable group's channels are single 16-byte gathers; NULL selects the direct NCHW gathers
+ * (same results, slower).  */
 int cdfo_dcn_forward(const float* in, const float* offset, const float* mask, const float* weight, const float* bias,
                      float* out, int B, int C, int H, int W, int Co, int kh, int kw, int sh, int sw, int ph, int pw,
-                     int dh, int dw, int groups, int deformable_groups, void* stream);
+                     int dh, int dw, int groups, int deformable_groups, void* workspace, long long workspace_bytes,
+                     void* stream);
 
 /* ---- deformable convolution backward (dcn_bwd.hip) -----------------------------------------------------------
  * One entry point behind the module's three backward functions: deform_conv_backward_input_cuda

@@ -27,7 +27,7 @@ def test_argument_validation_needs_no_gpu():
     a = _lib.ConvArgs()
     a.nsrc = 0
     assert lib.cdfo_conv_igemm(C.byref(a), None) == -1                       # CDFO_EINVAL before any HIP call
-    assert lib.cdfo_dcn_forward(None, None, None, None, None, None, 1, 6, 8, 8, 4, 3, 3, 1, 1, 1, 1, 1, 1, 4, 1, None) == -1
+    assert lib.cdfo_dcn_forward(None, None, None, None, None, None, 1, 6, 8, 8, 4, 3, 3, 1, 1, 1, 1, 1, 1, 4, 1, None, 0, None) == -1
     assert lib.cdfo_layernorm64(None, 63, None, None, 10, None, 64, None) == -1
     assert lib.cdfo_seq_attn(C.c_void_p(8), 64, C.c_void_p(16), 64, C.c_void_p(16), 64, 1, 8, 8, 0, None) == -2  # EALIGN
 

@@ -170,3 +170,31 @@ def test_dcn_backward_full_size_properties():
         outs.append((off3.grad.clone(), msk3.grad.clone()))
     assert (outs[1][0] + 2.0 * outs[0][0]).abs().max().item() <= 1e-4 * outs[0][0].abs().max().item()
     assert (outs[1][1] + 2.0 * outs[0][1]).abs().max().item() <= 1e-4 * outs[0][1].abs().max().item()
+
+
+def test_dcn_forward_group_planar_and_direct_gathers_agree():
+    """cdfo_dcn_forward with a workspace (group-planar 16-byte gathers) and without (direct NCHW gathers) through the
+    C-ABI, on a shape where the fast path applies (C/dg = 4) and one where it silently does not (C/dg = 2)."""
+    import ctypes as C
+    from cdfo_amd import _lib
+    for (B, Cc, Co, H, W, dg, g) in ((2, 64, 64, 20, 24, 16, 1), (1, 8, 12, 9, 11, 4, 2), (1, 32, 16, 10, 12, 2, 1)):
+        gen = torch.Generator(device="cuda").manual_seed(Cc + dg)
+        x = torch.randn(B, Cc, H, W, device="cuda", generator=gen)
+        w = torch.randn(Co, Cc // g, 3, 3, device="cuda", generator=gen) / 10
+        b = torch.randn(Co, device="cuda", generator=gen)
+        off = 3 * torch.randn(B, 2 * dg * 9, H, W, device="cuda", generator=gen)
+        msk = torch.rand(B, dg * 9, H, W, device="cuda", generator=gen)
+        outs = []
+        for ws in (None, torch.empty_like(x)):
+            out = torch.full((B, Co, H, W), float("nan"), device="cuda")
+            p = lambda t: C.c_void_p(None if t is None else t.data_ptr())  # noqa: E731
+            _lib.check(_lib.lib().cdfo_dcn_forward(p(x), p(off), p(msk), p(w), p(b), p(out), B, Cc, H, W, Co, 3, 3, 1, 1, 1, 1,
+                                                   1, 1, g, dg, p(ws), C.c_longlong(0 if ws is None else ws.numel() * 4),
+                                                   None), "cdfo_dcn_forward")
+            outs.append(out)
+        torch.cuda.synchronize()
+        ref = dcn_forward_ref(x.cpu().numpy(), off.cpu().numpy(), msk.cpu().numpy(), w.cpu().numpy(), b.cpu().numpy(),
+                              1, 1, 1, g, dg)
+        for out in outs:
+            assert np.abs(out.cpu().numpy() - ref).max() <= 2e-5 * max(1.0, np.abs(ref).max())
+        assert (outs[0] - outs[1]).abs().max().item() <= 1e-5

@@ -1,0 +1,44 @@
+"""Developer tool (GPU box only): the fused DCNv2 forward (cdfo_dcn_forward) at the alignment module's c3 shape
+(C = Co = 64, dg = 16, 3x3, 272x480) against its HBM roofline: algorithmic bytes = (C + 3*dg*k*k + Co) * P * 4 per image
++ the weights, HIP-event timed on the launch stream.
+    python tools/bench_dcn.py [--batch 8] [--iters 20]"""
+import argparse, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from cdfo_amd.dcn import modulated_deform_conv
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--batch", type=int, default=8)
+    ap.add_argument("--iters", type=int, default=20)
+    ap.add_argument("--height", type=int, default=272)
+    ap.add_argument("--width", type=int, default=480)
+    ap.add_argument("--offset-scale", type=float, default=3.0)
+    a = ap.parse_args()
+    B, C, Co, H, W, dg = a.batch, 64, 64, a.height, a.width, 16
+    g = torch.Generator(device="cuda").manual_seed(0)
+    x = torch.randn(B, C, H, W, device="cuda", generator=g)
+    w = torch.randn(Co, C, 3, 3, device="cuda", generator=g) / 24
+    b = torch.randn(Co, device="cuda", generator=g)
+    off = a.offset_scale * torch.randn(B, 2 * dg * 9, H, W, device="cuda", generator=g)
+    msk = torch.rand(B, dg * 9, H, W, device="cuda", generator=g)
+    with torch.no_grad():
+        for _ in range(3):
+            modulated_deform_conv(x, off, msk, w, b, 1, 1, 1, 1, dg)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(a.iters):
+            modulated_deform_conv(x, off, msk, w, b, 1, 1, 1, 1, dg)
+        e1.record()
+        torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / a.iters
+    P = H * W
+    bytes_ = (C + 3 * dg * 9 + Co) * P * 4 * B + w.numel() * 4
+    flops = 2.0 * C * Co * 9 * P * B
+    print(f"dcn_fwd B={B} {H}x{W} C=Co=64 dg=16: {ms:.3f} ms/launch  {bytes_ / ms / 1e6:.0f} GB/s algorithmic "
+          f"({bytes_ / ms / 1e6 / 8000 * 100:.1f} % of 8 TB/s)  {flops / ms / 1e9:.1f} TFLOP/s fp32")
+
+
+if __name__ == "__main__":
+    main()

@@ -68,7 +68,7 @@ def header_prototypes(path: str = HEADER_PATH):
     text = open(path).read()
     text = re.sub(r"/\*.*?\*/", " ", text, flags=re.S)
     protos = {}
-    for m in re.finditer(r"(const char\*|int)\s+(cdfo_[a-z0-9_]+)\s*\(([^)]*)\)\s*;", text):
+    for m in re.finditer(r"(const char\*|long long|int)\s+(cdfo_[a-z0-9_]+)\s*\(([^)]*)\)\s*;", text):
         ret, name, args = m.group(1), m.group(2), m.group(3).strip()
         at = []
         if args and args != "void":
@@ -84,7 +84,7 @@ def header_prototypes(path: str = HEADER_PATH):
                     at.append(C.c_int)
                 else:
                     raise CdfoError(f"cannot map C type in prototype of {name}: {a!r}")
-        protos[name] = (C.c_char_p if ret.startswith("const char") else C.c_int, at)
+        protos[name] = (C.c_char_p if ret.startswith("const char") else C.c_longlong if ret == "long long" else C.c_int, at)
     return protos
 
 

@@ -187,7 +187,18 @@ __global__ __launch_bounds__(256) void dcn_fwd_kernel(DcnArgs a, int KCH /* = CC
   }
 }
 
+void launch_to_gp(const float* in, float* gp, int B, int C, int dg, long long HW, hipStream_t st) {
+  const long long n = (long long)B * dg * HW;
+  hipLaunchKernelGGL(dcn_to_gp_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, in, gp, B, C, dg, HW);
+}
+
 }  // namespace
+
+// dcn_fast.hip
+int cdfo_dcn_forward_fast(const float* in, const float* offset, const float* mask, const float* weight, const float* bias,
+                          float* out, int B, int C, int H, int W, int Co, int Ho, int Wo, int kh, int kw, int sh, int sw, int ph,
+                          int pw, int dh, int dw, int groups, int dg, void* workspace, long long workspace_bytes,
+                          hipStream_t st, void (*to_gp)(const float*, float*, int, int, int, long long, hipStream_t));
 
 extern "C" int cdfo_dcn_forward(const float* in, const float* offset, const float* mask, const float* weight,
                                 const float* bias, float* out, int B, int C, int H, int W, int Co, int kh, int kw, int sh,
@@ -224,11 +235,13 @@ extern "C" int cdfo_dcn_forward(const float* in, const float* offset, const floa
   const double px = (double)B * Ho * Wo;
   CdfoProfScope prof(st, KID_DCN, 2.0 * px * Co * (C / groups) * T,
                      4.0 * (px * (Co + 3.0 * deformable_groups * T) + (double)B * C * H * W + (double)Co * (C / groups) * T));
+  const int fast = cdfo_dcn_forward_fast(in, offset, mask, weight, bias, out, B, C, H, W, Co, Ho, Wo, kh, kw, sh, sw, ph, pw, dh,
+                                         dw, groups, deformable_groups, workspace, workspace_bytes, st, &launch_to_gp);
+  if (fast == 1) return 0;
+  if (fast > 1) return fast - 2;
   if (gp) {
     a.gp = static_cast<const float*>(workspace);
-    const long long n = (long long)B * deformable_groups * H * W;
-    hipLaunchKernelGGL(dcn_to_gp_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, in,
-                       static_cast<float*>(workspace), B, C, deformable_groups, (long long)H * W);
+    launch_to_gp(in, static_cast<float*>(workspace), B, C, deformable_groups, (long long)H * W, st);
     hipLaunchKernelGGL(dcn_fwd_kernel<true>, grid, dim3(256), lds, st, a, KCH);
   } else {
     hipLaunchKernelGGL(dcn_fwd_kernel<false>, grid, dim3(256), lds, st, a, KCH);

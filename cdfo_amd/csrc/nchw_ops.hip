@@ -108,22 +108,43 @@ __global__ __launch_bounds__(256) void ew_nchw_kernel(const float* __restrict__ 
 // MVDualAttAlignment offset / mask assembly (arch.py:3336-3350) from the two pixel-major conv_offset outputs
 // o1, o2 [B,H,W,27*dg] (ch: o1 | o2 | mask thirds):  offset[b][k] = mag*tanh(oa[k]) + mag*tanh(ob[k]) + flow[b][1 - (k&1)],
 // mask[b][k] = sigmoid(ma[k] + mb[k]); outputs NCHW for the DCN operator.
+// One workgroup = 64 consecutive pixels of one image; the 27*dg channels are walked in slabs of 48: read along the
+// channel axis of the pixel-major inputs (coalesced), transposed through LDS, written along the pixel axis of the NCHW
+// outputs (coalesced).
 __global__ __launch_bounds__(256) void mv_offset_mask_kernel(const float* __restrict__ o1, const float* __restrict__ o2,
                                                              int ld, const float* __restrict__ flow, long long flow_bstride,
                                                              int B, long long P, int third, float mag,
                                                              float* __restrict__ offset, float* __restrict__ mask) {
-  const long long total = (long long)B * 3 * third * P;
-  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
-       i += (long long)gridDim.x * blockDim.x) {
-    const long long p = i % P;
-    const int k = (i / P) % (3 * third);
-    const long long b = i / (P * 3 * third);
-    const float va = o1[(b * P + p) * ld + k], vb = o2[(b * P + p) * ld + k];
-    if (k < 2 * third) {
-      const float fl = flow[b * flow_bstride + (long long)(1 - (k & 1)) * P + p];   // flip(1): (y, x) pairs
-      offset[(b * 2 * third + k) * P + p] = mag * tanhf(va) + mag * tanhf(vb) + fl;
-    } else {
-      mask[(b * third + (k - 2 * third)) * P + p] = 1.f / (1.f + expf(-(va + vb)));
+  constexpr int SL = 48;
+  __shared__ float t[SL][65];
+  const int tid = threadIdx.x;
+  const long long tiles = (P + 63) / 64;
+  const long long b = blockIdx.x / tiles, p0 = (blockIdx.x - b * tiles) * 64;
+  const int nch = 3 * third;
+  for (int k0 = 0; k0 < nch; k0 += SL) {
+    const int ns = (nch - k0) < SL ? (nch - k0) : SL;
+    __syncthreads();
+    for (int idx = tid; idx < 64 * SL; idx += 256) {
+      const int px = idx / SL, kl = idx - px * SL;
+      const long long p = p0 + px;
+      if (kl < ns && p < P) {
+        const int k = k0 + kl;
+        const float va = o1[(b * P + p) * ld + k], vb = o2[(b * P + p) * ld + k];
+        float r;
+        if (k < 2 * third) r = mag * tanhf(va) + mag * tanhf(vb) + flow[b * flow_bstride + (long long)(1 - (k & 1)) * P + p];   // flip(1): (y, x) pairs
+        else r = 1.f / (1.f + expf(-(va + vb)));
+        t[kl][px] = r;
+      }
+    }
+    __syncthreads();
+    for (int idx = tid; idx < 64 * ns; idx += 256) {
+      const int kl = idx >> 6, px = idx & 63;
+      const long long p = p0 + px;
+      if (p < P) {
+        const int k = k0 + kl;
+        if (k < 2 * third) offset[(b * 2 * third + k) * P + p] = t[kl][px];
+        else mask[(b * third + (k - 2 * third)) * P + p] = t[kl][px];
+      }
     }
   }
 }
@@ -178,8 +199,10 @@ extern "C" int cdfo_ew_nchw(const float* a, const float* b, const float* x, cons
 extern "C" int cdfo_mv_offset_mask(const float* o1, const float* o2, int ld, const float* flow, long long flow_bstride,
                                    int B, long long P, int third, float mag, float* offset, float* mask, void* stream) {
   if (B <= 0 || P <= 0 || third <= 0 || ld < 3 * third) return CDFO_EINVAL;
-  hipLaunchKernelGGL(mv_offset_mask_kernel, dim3(grid_for((long long)B * 3 * third * P)), dim3(256), 0,
-                     static_cast<hipStream_t>(stream), o1, o2, ld, flow, flow_bstride, B, P, third, mag, offset, mask);
+  const long long blocks = (long long)B * ((P + 63) / 64);
+  if (blocks > 0x7fffffffLL) return CDFO_EINVAL;
+  hipLaunchKernelGGL(mv_offset_mask_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), o1, o2, ld,
+                     flow, flow_bstride, B, P, third, mag, offset, mask);
   CDFO_LAUNCH_CHECK();
   return 0;
 }

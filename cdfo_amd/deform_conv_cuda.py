@@ -48,10 +48,12 @@ def _fwd(input, weight, bias, offset, mask, output, kh, kw, sh, sw, ph, pw, dh, 
     offset = offset.contiguous()
     mask = None if mask is None else mask.contiguous()
     p = lambda t: C.c_void_p(None if t is None else t.data_ptr())  # noqa: E731
-    ws = torch.empty_like(input)       # device scratch for the kernel's group-planar copy of `input` (plumbing, no arithmetic)
+    # device scratch (plumbing, no arithmetic): what the fast kernel asks for, else room for a group-planar copy of `input`
+    nbytes = max(int(_lib.lib().cdfo_dcn_workspace_bytes(B, Cc, H, W, Co, kh, kw, group, dg)), input.numel() * 4)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=input.device)
     _lib.check(_lib.lib().cdfo_dcn_forward(p(input), p(offset), p(mask), p(weight), p(bias), p(output), B, Cc, H, W,
                                            Co, kh, kw, sh, sw, ph, pw, dh, dw, group, dg, p(ws),
-                                           C.c_longlong(ws.numel() * 4), _stream()),
+                                           C.c_longlong(nbytes), _stream()),
                "cdfo_dcn_forward")
 
 

@@ -214,7 +214,10 @@ int cdfo_seq_attn(const float* q, int ldq, const float* v, int ldv, float* out, 
  * [C*kh*kw, Ho*Wo] has no counterpart (sampling and contraction are fused); `workspace` is an optional device scratch
  * of at least B*C*H*W*4 bytes (16-byte aligned) in which the kernel keeps a group-planar copy of `in` so that the
  * bilinear corners of a deformable group's channels are single 16-byte gathers; NULL selects the direct NCHW gathers
- * (same results, slower).  */
+ * (same results, slower).  With cdfo_dcn_workspace_bytes(...) bytes (non-zero for groups == 1, (C/dg) % 4 == 0,
+ * Co % 32 == 0, Co <= 128, kh*kw <= 64 -- the alignment module's shape) the fast kernel of dcn_fast.hip runs: whole-K
+ * LDS staging and split-fp16 matrix products (fp32-grade, ~2^-22 relative; |in * mask| < 65504).  */
+long long cdfo_dcn_workspace_bytes(int B, int C, int H, int W, int Co, int kh, int kw, int groups, int deformable_groups);
 int cdfo_dcn_forward(const float* in, const float* offset, const float* mask, const float* weight, const float* bias,
                      float* out, int B, int C, int H, int W, int Co, int kh, int kw, int sh, int sw, int ph, int pw,
                      int dh, int dw, int groups, int deformable_groups, void* workspace, long long workspace_bytes,

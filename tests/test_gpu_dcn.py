@@ -172,29 +172,49 @@ def test_dcn_backward_full_size_properties():
     assert (outs[1][1] + 2.0 * outs[0][1]).abs().max().item() <= 1e-4 * outs[0][1].abs().max().item()
 
 
-def test_dcn_forward_group_planar_and_direct_gathers_agree():
-    """cdfo_dcn_forward with a workspace (group-planar 16-byte gathers) and without (direct NCHW gathers) through the
-    C-ABI, on a shape where the fast path applies (C/dg = 4) and one where it silently does not (C/dg = 2)."""
+def test_dcn_forward_workspace_paths_agree_with_the_oracle():
+    """cdfo_dcn_forward through the C-ABI with no workspace (direct NCHW gathers, exact fp32), a workspace just large
+    enough for the group-planar copy (16-byte gathers, exact fp32) and the full cdfo_dcn_workspace_bytes (the fast
+    split-fp16 kernel where it applies: the first five shapes) -- all against the C oracle."""
     import ctypes as C
     from cdfo_amd import _lib
-    for (B, Cc, Co, H, W, dg, g) in ((2, 64, 64, 20, 24, 16, 1), (1, 8, 12, 9, 11, 4, 2), (1, 32, 16, 10, 12, 2, 1)):
+    lib = _lib.lib()
+    shapes = [  # B, C, Co, H, W, k, stride, pad, dil, groups, dg
+        (2, 64, 64, 20, 24, 3, 1, 1, 1, 1, 16),     # the alignment module's shape
+        (1, 128, 128, 11, 13, 3, 1, 1, 1, 1, 16),   # two K chunks, two output tiles per wave, C/dg = 8
+        (1, 16, 32, 9, 70, 1, 1, 0, 1, 1, 4),       # 1x1 kernel: K = 16 (one step), ragged last pixel tile
+        (2, 32, 96, 12, 10, 3, 2, 1, 1, 1, 2),      # stride 2, odd number of output tiles
+        (1, 8, 32, 10, 12, 5, 1, 4, 2, 1, 1),       # 5x5 dilated: K = 200, padded last step
+        (1, 8, 12, 9, 11, 3, 1, 1, 1, 2, 4),        # conv groups: general kernel, group-planar gathers
+        (1, 32, 16, 10, 12, 3, 1, 1, 1, 1, 16),     # C/dg = 2: general kernel, direct gathers
+    ]
+    for n, (B, Cc, Co, H, W, k, st, pd, dl, g, dg) in enumerate(shapes):
         gen = torch.Generator(device="cuda").manual_seed(Cc + dg)
+        Ho = (H + 2 * pd - (dl * (k - 1) + 1)) // st + 1
+        Wo = (W + 2 * pd - (dl * (k - 1) + 1)) // st + 1
         x = torch.randn(B, Cc, H, W, device="cuda", generator=gen)
-        w = torch.randn(Co, Cc // g, 3, 3, device="cuda", generator=gen) / 10
+        w = torch.randn(Co, Cc // g, k, k, device="cuda", generator=gen) / 10
         b = torch.randn(Co, device="cuda", generator=gen)
-        off = 3 * torch.randn(B, 2 * dg * 9, H, W, device="cuda", generator=gen)
-        msk = torch.rand(B, dg * 9, H, W, device="cuda", generator=gen)
-        outs = []
-        for ws in (None, torch.empty_like(x)):
-            out = torch.full((B, Co, H, W), float("nan"), device="cuda")
-            p = lambda t: C.c_void_p(None if t is None else t.data_ptr())  # noqa: E731
-            _lib.check(_lib.lib().cdfo_dcn_forward(p(x), p(off), p(msk), p(w), p(b), p(out), B, Cc, H, W, Co, 3, 3, 1, 1, 1, 1,
-                                                   1, 1, g, dg, p(ws), C.c_longlong(0 if ws is None else ws.numel() * 4),
-                                                   None), "cdfo_dcn_forward")
-            outs.append(out)
-        torch.cuda.synchronize()
+        off = 3 * torch.randn(B, 2 * dg * k * k, Ho, Wo, device="cuda", generator=gen)
+        msk = torch.rand(B, dg * k * k, Ho, Wo, device="cuda", generator=gen)
+        need = int(lib.cdfo_dcn_workspace_bytes(B, Cc, H, W, Co, k, k, g, dg))
+        assert (need > 0) == (n < 5), (n, need)
         ref = dcn_forward_ref(x.cpu().numpy(), off.cpu().numpy(), msk.cpu().numpy(), w.cpu().numpy(), b.cpu().numpy(),
-                              1, 1, 1, g, dg)
-        for out in outs:
-            assert np.abs(out.cpu().numpy() - ref).max() <= 2e-5 * max(1.0, np.abs(ref).max())
-        assert (outs[0] - outs[1]).abs().max().item() <= 1e-5
+                              st, pd, dl, g, dg)
+        for nbytes in (0, x.numel() * 4, max(need, x.numel() * 4)):
+            ws = torch.empty(nbytes, dtype=torch.uint8, device="cuda") if nbytes else None
+            out = torch.full((B, Co, Ho, Wo), float("nan"), device="cuda")
+            p = lambda t: C.c_void_p(None if t is None else t.data_ptr())  # noqa: E731
+            _lib.check(lib.cdfo_dcn_forward(p(x), p(off), p(msk), p(w), p(b), p(out), B, Cc, H, W, Co, k, k, st, st, pd, pd,
+                                            dl, dl, g, dg, p(ws), C.c_longlong(nbytes), None), "cdfo_dcn_forward")
+            torch.cuda.synchronize()
+            err = np.abs(out.cpu().numpy() - ref).max()
+            assert err <= 2e-5 * max(1.0, np.abs(ref).max()), (n, nbytes, err)
+        # DCNv1 through the same entry point (mask = bias = NULL) on the fast path
+        if need:
+            ws = torch.empty(need, dtype=torch.uint8, device="cuda")
+            out = torch.full((B, Co, Ho, Wo), float("nan"), device="cuda")
+            _lib.check(lib.cdfo_dcn_forward(p(x), p(off), None, p(w), None, p(out), B, Cc, H, W, Co, k, k, st, st, pd, pd, dl,
+                                            dl, g, dg, p(ws), C.c_longlong(need), None), "cdfo_dcn_forward")
+            ref1 = dcn_forward_ref(x.cpu().numpy(), off.cpu().numpy(), None, w.cpu().numpy(), None, st, pd, dl, g, dg)
+            assert np.abs(out.cpu().numpy() - ref1).max() <= 2e-5 * max(1.0, np.abs(ref1).max()), n

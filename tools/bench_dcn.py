@@ -14,14 +14,22 @@ def main():
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--height", type=int, default=272)
     ap.add_argument("--width", type=int, default=480)
-    ap.add_argument("--offset-scale", type=float, default=3.0)
+    ap.add_argument("--offsets", default="mv", choices=["mv", "random"],
+                    help="mv: the alignment module's kind of field (arch.py:3345-3347) -- a motion vector constant on 8x8 "
+                         "blocks, |mv| <= 3 px, shared by all taps, plus a 0.5 px per-tap residual; random: independent "
+                         "N(0, 3 px) per tap and pixel (worst case for the gathers)")
     a = ap.parse_args()
     B, C, Co, H, W, dg = a.batch, 64, 64, a.height, a.width, 16
     g = torch.Generator(device="cuda").manual_seed(0)
     x = torch.randn(B, C, H, W, device="cuda", generator=g)
     w = torch.randn(Co, C, 3, 3, device="cuda", generator=g) / 24
     b = torch.randn(Co, device="cuda", generator=g)
-    off = a.offset_scale * torch.randn(B, 2 * dg * 9, H, W, device="cuda", generator=g)
+    if a.offsets == "random":
+        off = 3.0 * torch.randn(B, 2 * dg * 9, H, W, device="cuda", generator=g)
+    else:
+        mv = (torch.rand(B, 2, (H + 7) // 8, (W + 7) // 8, device="cuda", generator=g) * 6 - 3)
+        mv = mv.repeat_interleave(8, 2).repeat_interleave(8, 3)[:, :, :H, :W]
+        off = mv.repeat(1, dg * 9, 1, 1) + 0.5 * torch.randn(B, 2 * dg * 9, H, W, device="cuda", generator=g)
     msk = torch.rand(B, dg * 9, H, W, device="cuda", generator=g)
     with torch.no_grad():
         for _ in range(3):
@@ -36,7 +44,7 @@ def main():
     P = H * W
     bytes_ = (C + 3 * dg * 9 + Co) * P * 4 * B + w.numel() * 4
     flops = 2.0 * C * Co * 9 * P * B
-    print(f"dcn_fwd B={B} {H}x{W} C=Co=64 dg=16: {ms:.3f} ms/launch  {bytes_ / ms / 1e6:.0f} GB/s algorithmic "
+    print(f"dcn_fwd offsets={a.offsets} B={B} {H}x{W} C=Co=64 dg=16: {ms:.3f} ms/launch  {bytes_ / ms / 1e6:.0f} GB/s algorithmic "
           f"({bytes_ / ms / 1e6 / 8000 * 100:.1f} % of 8 TB/s)  {flops / ms / 1e9:.1f} TFLOP/s fp32")
 
 

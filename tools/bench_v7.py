@@ -61,12 +61,16 @@ def main():
         run()
         torch.cuda.synchronize()
         t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        import time
         t0.record()
+        h0 = time.perf_counter()
         for _ in range(a.steps):
             run()
+        host_ms = (time.perf_counter() - h0) * 1e3 / a.steps
         t1.record()
         torch.cuda.synchronize()
         ms = t0.elapsed_time(t1) / a.steps
+        print(f"# host issue time {host_ms:.1f} ms/forward")
         print(f"# CVSR_V7 {a.precision} B={B} {H}x{W}: {ms:.1f} ms/forward = {B / ms * 1e3:.2f} frames/s; "
               f"peak memory {torch.cuda.max_memory_allocated() / 2**30:.1f} GiB")
         for mod in (K, D):

@@ -193,6 +193,10 @@ def main():
                        "per_rank_max_abs": [float(v) for v in allm[:, 2]]},
             "roofline": roofline, "cpu_baseline": cpu,
         }
+        if world == 1 and not args.no_parity:
+            # the path's other operator row, outside the timed region: the fused DCNv2 forward at the
+            # alignment module's shape against its HBM roofline (same definitions as tools/bench_dcn.py)
+            res["dcn_forward"] = dcn_forward_line(dev, Hp, Wp, B)
         print(json.dumps(res))
         if args.breakdown:
             with open(args.breakdown, "w") as f:
@@ -206,6 +210,34 @@ def main():
                             f"{fl[k]/ms[k]/1e9:.2f} {by[k]/ms[k]/1e6:.1f}\n")
     if world > 1:
         dist.destroy_process_group()
+
+
+def dcn_forward_line(device, H, W, B, iters=10):
+    from cdfo_amd.dcn import modulated_deform_conv
+    C, Co, dg = 64, 64, 16
+    g = torch.Generator(device=device).manual_seed(0)
+    x = torch.randn(B, C, H, W, device=device, generator=g)
+    w = torch.randn(Co, C, 3, 3, device=device, generator=g) / 24
+    b = torch.randn(Co, device=device, generator=g)
+    mv = torch.rand(B, 2, (H + 7) // 8, (W + 7) // 8, device=device, generator=g) * 6 - 3    # block-constant motion field
+    mv = mv.repeat_interleave(8, 2).repeat_interleave(8, 3)[:, :, :H, :W]
+    off = mv.repeat(1, dg * 9, 1, 1) + 0.5 * torch.randn(B, 2 * dg * 9, H, W, device=device, generator=g)
+    msk = torch.rand(B, dg * 9, H, W, device=device, generator=g)
+    with torch.no_grad():
+        for _ in range(2):
+            modulated_deform_conv(x, off, msk, w, b, 1, 1, 1, 1, dg)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            modulated_deform_conv(x, off, msk, w, b, 1, 1, 1, 1, dg)
+        e1.record()
+        torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / iters
+    nbytes = (C + 3 * dg * 9 + Co) * H * W * 4 * B + w.numel() * 4
+    ach = nbytes / ms / 1e6
+    return {"workload": f"DCNv2 forward C=Co=64 dg=16 3x3, {B}x{H}x{W}, MV-like offsets", "ms_per_launch": round(ms, 4),
+            "roofline": {"bound": "hbm", "achieved": round(ach, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(ach / 8000.0, 4),
+                         "algorithmic_bytes_per_launch": nbytes, "traffic": None}}
 
 
 def cpu_baseline(sd, Hp, Wp):

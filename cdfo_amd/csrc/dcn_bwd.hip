@@ -9,14 +9,15 @@
 // Three kernels:
 //   dcn_bwd_data_kernel    one thread = (image, deformable group, tap, output pixel).  The sample position and its
 //                          bilinear / coordinate weights depend on exactly that tuple, so they are computed once and the
-//                          thread walks the C/dg channels of its deformable group: column gradient = dot(W[:, c, tap],
-//                          grad_output[:, pixel]) (weight operand is wave-uniform -> scalar loads; grad_output reads are
-//                          coalesced along the pixel axis), grad_offset / grad_mask are reduced in registers and
+//                          thread walks the C/dg channels of its deformable group four at a time: column gradient =
+//                          dot(W[:, c, tap], grad_output[:, pixel]) (weight operand is wave-uniform -> scalar loads;
+//                          grad_output reads are coalesced along the pixel axis and shared by the four channels),
+//                          grad_offset / grad_mask are reduced in registers and
 //                          ASSIGNED (deterministic, as in the reference), grad_input takes 4 hardware fp32 atomics.
 //   dcn_bwd_weight_kernel  one workgroup = one input channel x 64 output channels x a range of (image, pixel) positions,
 //                          walked in chunks of 64: sampled column values [T][64] and the grad_output tile [64][64] are
 //                          staged in LDS, each thread owns up to 16 (cout, tap) pairs; one atomic per pair per workgroup.
-//   dcn_bwd_bias_kernel    one workgroup per output channel.
+//   dcn_bwd_bias_kernel    (output channel, slice of positions) workgroups, one atomic each.
 // grad_input, grad_weight and grad_bias are accumulated into (callers zero them: ops/dcn/deform_conv.py:71-72, 85, 154-158).
 #include "common.h"
 
@@ -63,26 +64,52 @@ __global__ __launch_bounds__(256) void dcn_bwd_data_kernel(DcnBwdArgs a) {
   const float w1 = s.hh * s.hw, w2 = s.hh * s.lw, w3 = s.lh * s.hw, w4 = s.lh * s.lw;
   float vh = 0.f, vw = 0.f, mv = 0.f;
   if (s.valid) {
-    for (int cc = 0; cc < Cdg; ++cc) {
-      const int c = d * Cdg + cc, g = c / Cg, cl = c - g * Cg;
-      const float* wp = a.w + ((long long)(g * Cog) * Cg + cl) * T + t;          // + o * Cg * T   (wave-uniform)
-      const float* gp = a.gout + ((long long)b * a.Co + g * Cog) * P + p;        // + o * P        (coalesced)
-      float cg = 0.f;
-      for (int o = 0; o < Cog; ++o) cg = fmaf(wp[(long long)o * Cg * T], gp[(long long)o * P], cg);
-      const long long pl = ((long long)b * a.C + c) * a.H * a.W;
-      const float* im = a.in + pl;
-      const float v1 = s.o1 >= 0 ? im[s.o1] : 0.f, v2 = s.o2 >= 0 ? im[s.o2] : 0.f;
-      const float v3 = s.o3 >= 0 ? im[s.o3] : 0.f, v4 = s.o4 >= 0 ? im[s.o4] : 0.f;
-      mv = fmaf(cg, w1 * v1 + w2 * v2 + w3 * v3 + w4 * v4, mv);
-      const float tg = cg * m;
-      vh = fmaf(s.hw * (v3 - v1) + s.lw * (v4 - v2), tg, vh);                    // d sample / d h
-      vw = fmaf(s.hh * (v2 - v1) + s.lh * (v4 - v3), tg, vw);                    // d sample / d w
-      if (a.gin) {
-        float* gi = a.gin + pl;
-        if (s.o1 >= 0) unsafeAtomicAdd(gi + s.o1, w1 * tg);
-        if (s.o2 >= 0) unsafeAtomicAdd(gi + s.o2, w2 * tg);
-        if (s.o3 >= 0) unsafeAtomicAdd(gi + s.o3, w3 * tg);
-        if (s.o4 >= 0) unsafeAtomicAdd(gi + s.o4, w4 * tg);
+    for (int cc0 = 0; cc0 < Cdg; cc0 += 4) {
+      // column gradients of up to 4 channels at once: each grad_output value is loaded once per chunk, the weights are
+      // wave-uniform (scalar loads)
+      float cg4[4] = {0.f, 0.f, 0.f, 0.f};
+      const int c_first = d * Cdg + cc0, g = c_first / Cg;
+      const int nc = (Cdg - cc0) < 4 ? (Cdg - cc0) : 4;
+      const bool one_group = (c_first + nc - 1) / Cg == g;          // the chunk lies inside one conv group (the usual case)
+      if (one_group) {
+        const int cl = c_first - g * Cg;
+        const float* wp = a.w + ((long long)(g * Cog) * Cg + cl) * T + t;        // + o * Cg * T + e * T   (wave-uniform)
+        const float* gp = a.gout + ((long long)b * a.Co + g * Cog) * P + p;      // + o * P                (coalesced)
+        for (int o = 0; o < Cog; ++o) {
+          const float gv = gp[(long long)o * P];
+          const float* wo = wp + (long long)o * Cg * T;
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (e < nc) cg4[e] = fmaf(wo[e * T], gv, cg4[e]);
+        }
+      } else {
+        for (int e = 0; e < nc; ++e) {
+          const int c = c_first + e, ge = c / Cg, cl = c - ge * Cg;
+          const float* wp = a.w + ((long long)(ge * Cog) * Cg + cl) * T + t;
+          const float* gp = a.gout + ((long long)b * a.Co + ge * Cog) * P + p;
+          for (int o = 0; o < Cog; ++o) cg4[e] = fmaf(wp[(long long)o * Cg * T], gp[(long long)o * P], cg4[e]);
+        }
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        if (e >= nc) continue;
+        const int c = c_first + e;
+        const float cg = cg4[e];
+        const long long pl = ((long long)b * a.C + c) * a.H * a.W;
+        const float* im = a.in + pl;
+        const float v1 = s.o1 >= 0 ? im[s.o1] : 0.f, v2 = s.o2 >= 0 ? im[s.o2] : 0.f;
+        const float v3 = s.o3 >= 0 ? im[s.o3] : 0.f, v4 = s.o4 >= 0 ? im[s.o4] : 0.f;
+        mv = fmaf(cg, w1 * v1 + w2 * v2 + w3 * v3 + w4 * v4, mv);
+        const float tg = cg * m;
+        vh = fmaf(s.hw * (v3 - v1) + s.lw * (v4 - v2), tg, vh);                    // d sample / d h
+        vw = fmaf(s.hh * (v2 - v1) + s.lh * (v4 - v3), tg, vw);                    // d sample / d w
+        if (a.gin) {
+          float* gi = a.gin + pl;
+          if (s.o1 >= 0) unsafeAtomicAdd(gi + s.o1, w1 * tg);
+          if (s.o2 >= 0) unsafeAtomicAdd(gi + s.o2, w2 * tg);
+          if (s.o3 >= 0) unsafeAtomicAdd(gi + s.o3, w3 * tg);
+          if (s.o4 >= 0) unsafeAtomicAdd(gi + s.o4, w4 * tg);
+        }
       }
     }
   }
@@ -168,20 +195,22 @@ __global__ __launch_bounds__(256) void dcn_bwd_weight_kernel(DcnBwdArgs a, int s
   }
 }
 
+// grid = (Co, slices): every workgroup sums one slice of one output channel's B*P values; one atomic per workgroup
 __global__ __launch_bounds__(256) void dcn_bwd_bias_kernel(const float* __restrict__ gout, float* __restrict__ gbias, int B,
                                                            int Co, int P) {
   __shared__ float part[4];
   const int o = blockIdx.x, tid = threadIdx.x;
+  const long long total = (long long)B * P;
   float s = 0.f;
-  for (int b = 0; b < B; ++b) {
-    const float* gp = gout + ((long long)b * Co + o) * P;
-    for (int p = tid; p < P; p += 256) s += gp[p];
+  for (long long q = (long long)blockIdx.y * 256 + tid; q < total; q += (long long)gridDim.y * 256) {
+    const int b = (int)(q / P), p = (int)(q - (long long)b * P);
+    s += gout[((long long)b * Co + o) * P + p];
   }
 #pragma unroll
   for (int sh = 32; sh > 0; sh >>= 1) s += __shfl_xor(s, sh, 64);
   if ((tid & 63) == 0) part[tid >> 6] = s;
   __syncthreads();
-  if (tid == 0) gbias[o] += part[0] + part[1] + part[2] + part[3];
+  if (tid == 0) unsafeAtomicAdd(gbias + o, part[0] + part[1] + part[2] + part[3]);
 }
 
 }  // namespace
@@ -228,7 +257,9 @@ extern "C" int cdfo_dcn_backward(const float* in, const float* offset, const flo
     CDFO_LAUNCH_CHECK();
   }
   if (grad_bias) {
-    hipLaunchKernelGGL(dcn_bwd_bias_kernel, dim3(Co), dim3(256), 0, st, grad_out, grad_bias, B, Co, P);
+    const long long slices = ((long long)B * P + 16383) / 16384;
+    hipLaunchKernelGGL(dcn_bwd_bias_kernel, dim3(Co, (unsigned)(slices < 64 ? slices : 64)), dim3(256), 0, st, grad_out, grad_bias,
+                       B, Co, P);
     CDFO_LAUNCH_CHECK();
   }
   return 0;

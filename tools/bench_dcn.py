@@ -18,6 +18,7 @@ def main():
                     help="mv: the alignment module's kind of field (arch.py:3345-3347) -- a motion vector constant on 8x8 "
                          "blocks, |mv| <= 3 px, shared by all taps, plus a 0.5 px per-tap residual; random: independent "
                          "N(0, 3 px) per tap and pixel (worst case for the gathers)")
+    ap.add_argument("--backward", action="store_true", help="time cdfo_dcn_backward (all five gradients) instead")
     a = ap.parse_args()
     B, C, Co, H, W, dg = a.batch, 64, 64, a.height, a.width, 16
     g = torch.Generator(device="cuda").manual_seed(0)
@@ -31,6 +32,28 @@ def main():
         mv = mv.repeat_interleave(8, 2).repeat_interleave(8, 3)[:, :, :H, :W]
         off = mv.repeat(1, dg * 9, 1, 1) + 0.5 * torch.randn(B, 2 * dg * 9, H, W, device="cuda", generator=g)
     msk = torch.rand(B, dg * 9, H, W, device="cuda", generator=g)
+    if a.backward:
+        from cdfo_amd import deform_conv_cuda as ext
+        go = torch.randn(B, Co, H, W, device="cuda", generator=g)
+        e = torch.empty(0, device="cuda")
+        gi, gw, gb = torch.zeros_like(x), torch.zeros_like(w), torch.zeros_like(b)
+        goff, gm = torch.zeros_like(off), torch.zeros_like(msk)
+        run = lambda: ext.modulated_deform_conv_cuda_backward(x, w, b, e, off, msk, e, gi, gw, gb, goff, gm, go, 3, 3, 1, 1, 1, 1,  # noqa: E731
+                                                              1, 1, 1, dg, True)
+        run()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(a.iters):
+            run()
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / a.iters
+        P = H * W
+        # each operand read once, each gradient written once (grad_input also read: it is accumulated into)
+        bytes_ = ((C + 3 * dg * 9 + Co) + (2 * C + 3 * dg * 9)) * P * 4 * B + 2 * w.numel() * 4
+        print(f"dcn_bwd offsets={a.offsets} B={B} {H}x{W} C=Co=64 dg=16: {ms:.3f} ms/launch  {bytes_ / ms / 1e6:.0f} GB/s algorithmic "
+              f"({bytes_ / ms / 1e6 / 8000 * 100:.1f} % of 8 TB/s)  {3 * 2.0 * C * Co * 9 * P * B / ms / 1e9:.1f} TFLOP/s fp32")
+        return
     with torch.no_grad():
         for _ in range(3):
             modulated_deform_conv(x, off, msk, w, b, 1, 1, 1, 1, dg)

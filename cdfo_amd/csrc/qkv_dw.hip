@@ -13,7 +13,15 @@
 //   * 64 output channels at a time: accumulators -> LDS y tile (zero outside the image = the depthwise conv's padding)
 //     -> barrier -> each thread slides a 3x3 window down one (column, 4-channel) strip (24 LDS reads for 6 outputs)
 //     -> 16-byte stores;
-//   * the next tile's input rows are fetched into registers while the current tile is in its depthwise phase.
+//   * the next tile's input rows are fetched into registers while the current tile is in its depthwise phase;
+//   * optional fused Gram pass (a.gram != NULL): the attention only needs q and k through sum_p q[c] k[c'] (same head),
+//     sum q^2 and sum k^2 (arch.py:1561-1566), so blocks 0 and 1 hold [32 q | 32 k] channels of the same four heads, the
+//     depthwise threads exchange their k values inside the wave (ds_bpermute), accumulate the per-head 8x8 products in
+//     registers over the tile's 6 rows, fold the 4 columns of a wave with shuffles, and the 8 waves' contributions are
+//     summed in a fixed order into a 640-float LDS image (the layout of cdfo_gram_partial) that is stored to the
+//     workgroup's own slot of gram[b] when the workgroup moves to another image -- no atomics anywhere, so the sums
+//     (and the forward) are bit-reproducible: q and k never reach HBM (3.7 GB written + 3.7 GB re-read per round at 56
+//     frames of 272x480).
 #include "common.h"
 
 namespace {
@@ -24,7 +32,9 @@ constexpr int QD_W_BYTES = 2 * 4 * 2 * 192 * 16;          // [hi|lo][k-step][k-h
 constexpr int QD_YP = 68;                                 // floats per staged pixel (64 + 4: conflict-free b128 reads)
 constexpr int QD_Y_BYTES = 8 * 32 * QD_YP * 4;            // 69,632
 constexpr int QD_DW_OFF = QD_W_BYTES + QD_Y_BYTES;        // depthwise taps [9][192] floats, then bias [192]
-constexpr int QD_LDS = QD_DW_OFF + 9 * 192 * 4 + 192 * 4; // 126,464 bytes
+constexpr int QD_G_OFF = QD_DW_OFF + 9 * 192 * 4 + 192 * 4; // Gram image: 640 floats
+constexpr int QD_GW_OFF = QD_G_OFF + 640 * 4;              // per-wave Gram contributions of one block: [8][320] floats
+constexpr int QD_LDS = QD_GW_OFF + 8 * 320 * 4;            // 139,264 bytes
 
 typedef __bf16 qd_bf16x8 __attribute__((ext_vector_type(8)));
 
@@ -36,6 +46,7 @@ struct qd_args {
   const float* dw;              // [192][9] depthwise taps
   float eps;
   float* out; int ldo;
+  float* gram; int nslot;       // optional [B][nslot][640]: fused Gram pass; `out` then receives v only (64 channels)
 };
 
 __global__ __launch_bounds__(QD_THREADS) void qkv_dw_kernel(qd_args a) {
@@ -43,6 +54,8 @@ __global__ __launch_bounds__(QD_THREADS) void qkv_dw_kernel(qd_args a) {
   float* sY = reinterpret_cast<float*>(smem + QD_W_BYTES);
   float* sDw = reinterpret_cast<float*>(smem + QD_DW_OFF);
   float* sBias = sDw + 9 * 192;
+  float* sG = reinterpret_cast<float*>(smem + QD_G_OFF);
+  float* sGW = reinterpret_cast<float*>(smem + QD_GW_OFF);
   const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, r = lane & 31;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int H = a.H, W = a.W;
@@ -51,6 +64,7 @@ __global__ __launch_bounds__(QD_THREADS) void qkv_dw_kernel(qd_args a) {
     reinterpret_cast<f32x4*>(smem)[i] = reinterpret_cast<const f32x4*>(a.w)[i];
   for (int i = tid; i < 9 * 192; i += QD_THREADS) sDw[i] = a.dw[(i % 192) * 9 + i / 192];     // -> [tap][channel]
   for (int i = tid; i < 192; i += QD_THREADS) sBias[i] = a.bias ? a.bias[i] : 0.f;
+  for (int i = tid; i < 640; i += QD_THREADS) sG[i] = 0.f;
   __syncthreads();
 
   const int tiles_x = (W + QD_TC - 1) / QD_TC, tiles_y = (H + QD_TR - 1) / QD_TR;
@@ -72,9 +86,12 @@ __global__ __launch_bounds__(QD_THREADS) void qkv_dw_kernel(qd_args a) {
     }
   };
 
-  int t = blockIdx.x;
-  if (t < ntiles) load_x(t);
-  for (; t < ntiles; t += gridDim.x) {
+  // contiguous tile range per workgroup (a workgroup then sees at most a few images: few Gram flushes)
+  const int per = (ntiles + gridDim.x - 1) / gridDim.x;
+  int t = blockIdx.x * per;
+  const int t_end = (t + per) < ntiles ? (t + per) : ntiles;
+  if (t < t_end) load_x(t);
+  for (; t < t_end; ++t) {
     const int tx = t % tiles_x, t2 = t / tiles_x;
     const int ty = t2 % tiles_y, b = t2 / tiles_y;
     const int oy0 = ty * QD_TR, ox0 = tx * QD_TC;
@@ -102,8 +119,8 @@ __global__ __launch_bounds__(QD_THREADS) void qkv_dw_kernel(qd_args a) {
         al[s][j] = (__bf16)(v - (float)ah[s][j]);
       }
     const bool pin = xin;                                   // this tile's pixel; xr / xin move on to the next tile
-    const int tn = t + gridDim.x;
-    if (tn < ntiles) load_x(tn);
+    const int tn = t + 1;
+    if (tn < t_end) load_x(tn);
 
     // the 16 pixels of this lane's accumulator registers: halo column (e&3) + 8 (e>>2) + 4 h of halo row `wave`
     const int gyw = oy0 - 1 + wave;
@@ -117,7 +134,7 @@ __global__ __launch_bounds__(QD_THREADS) void qkv_dw_kernel(qd_args a) {
         f32x16 acc;
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[e] = 0.f;
-        const int n = nb * 64 + nt * 32 + r;
+        const int n = nb < 2 ? nt * 64 + nb * 32 + r : 128 + nt * 32 + r;   // blocks 0, 1: [32 q | 32 k] of the same heads
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
           const qd_bf16x8 wh = *reinterpret_cast<const qd_bf16x8*>(smem + ((s * 2 + h) * 192 + n) * 16);
@@ -136,9 +153,19 @@ __global__ __launch_bounds__(QD_THREADS) void qkv_dw_kernel(qd_args a) {
       }
       __syncthreads();
       // ---- depthwise 3x3: thread = (column x, 4 channels q*4..), sliding down the 6 output rows
+      const bool gram_blk = a.gram != nullptr && nb < 2;
+      // Gram products of a head (8 q x 8 k channels) are shared by its four lanes: the q lanes L0 / L1 (channels 0-3 /
+      // 4-7) take q x k against the k lanes M0 / M1 with the same index, M0 / M1 take k x q against L1 / L0
+      float g[4][4], s2[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        s2[i] = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) g[i][j] = 0.f;
+      }
+      const int q = tid & 15, x = tid >> 4;
+      const int cb = nb < 2 ? ((q & 8) ? 64 : 0) + nb * 32 + (q & 7) * 4 : 128 + q * 4;
       if (tid < QD_TC * 16) {
-        const int q = tid & 15, x = tid >> 4;
-        const int cb = nb * 64 + q * 4;
         f32x4 wt[9];
 #pragma unroll
         for (int k = 0; k < 9; ++k) wt[k] = *reinterpret_cast<const f32x4*>(sDw + k * 192 + cb);
@@ -149,6 +176,7 @@ __global__ __launch_bounds__(QD_THREADS) void qkv_dw_kernel(qd_args a) {
           for (int dx = 0; dx < 3; ++dx)
             win[ry][dx] = *reinterpret_cast<const f32x4*>(sY + (ry * 32 + x + dx) * QD_YP + q * 4);
         const bool xok = ox0 + x < W;
+        const int src0 = (lane & 48) | (q < 8 ? 8 + q : (q & 7) ^ 1);   // partner lane, same column
 #pragma unroll
         for (int y = 0; y < QD_TR; ++y) {
 #pragma unroll
@@ -159,21 +187,96 @@ __global__ __launch_bounds__(QD_THREADS) void qkv_dw_kernel(qd_args a) {
           for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
             for (int dx = 0; dx < 3; ++dx) o += wt[dy * 3 + dx] * win[(y + dy) % 3][dx];
-          if (xok && oy0 + y < H)
-            *reinterpret_cast<f32x4*>(a.out + ((long long)(b * H + oy0 + y) * W + ox0 + x) * a.ldo + cb) = o;
+          const bool ok = xok && oy0 + y < H;
+          if (gram_blk) {
+            if (!ok) o = f32x4{0.f, 0.f, 0.f, 0.f};
+            float pv[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) pv[e] = __shfl(o[e], src0, 64);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              s2[i] = fmaf(o[i], o[i], s2[i]);
+#pragma unroll
+              for (int j = 0; j < 4; ++j) g[i][j] = fmaf(o[i], pv[j], g[i][j]);
+            }
+          } else if (ok) {
+            const int co = a.gram ? q * 4 : cb;                      // Gram mode: the output tensor holds v only
+            *reinterpret_cast<f32x4*>(a.out + ((long long)(b * H + oy0 + y) * W + ox0 + x) * a.ldo + co) = o;
+          }
+        }
+      }
+      if (gram_blk) {                                                // all 512 threads: idle ones carry zeros
+        // fold the wave's 4 columns, then one LDS add per (channel, partner) from the 16 lanes of column 0
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          s2[i] += __shfl_xor(s2[i], 16, 64);
+          s2[i] += __shfl_xor(s2[i], 32, 64);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            g[i][j] += __shfl_xor(g[i][j], 16, 64);
+            g[i][j] += __shfl_xor(g[i][j], 32, 64);
+          }
+        }
+        if (lane < 16) {
+          float* slot = sGW + wave * 320;
+          const int m = q & 7;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            if (q < 8) {                                             // own q channel m*4+i  x  k channels 4*(m&1) .. +3
+#pragma unroll
+              for (int j = 0; j < 4; ++j) slot[(m * 4 + i) * 9 + 4 * (m & 1) + j] = g[i][j];
+              slot[(m * 4 + i) * 9 + 8] = s2[i];
+            } else {                                                 // partner's q channel (m^1)*4+j  x  own k channel 4*(m&1)+i
+#pragma unroll
+              for (int j = 0; j < 4; ++j) slot[((m ^ 1) * 4 + j) * 9 + 4 * (m & 1) + i] = g[i][j];
+              slot[288 + m * 4 + i] = s2[i];
+            }
+          }
         }
       }
       __syncthreads();
+      if (gram_blk && tid < 320) {                                   // fixed summation order over the 8 waves
+        float sum = 0.f;
+#pragma unroll
+        for (int wv = 0; wv < 8; ++wv) sum += sGW[wv * 320 + tid];
+        const int idx = tid < 288 ? (nb * 32 + tid / 9) * 10 + tid % 9 : (nb * 32 + tid - 288) * 10 + 9;
+        sG[idx] += sum;
+      }
     }
     (void)pin;
+    if (a.gram) {
+      const int tn2 = t + 1;
+      const int bn = tn2 < t_end ? (tn2 / tiles_x) / tiles_y : -1;
+      if (bn != b) {                                                  // leaving image b: store its Gram sums to this
+        const int first = (b * tiles_y * tiles_x) / per;              // workgroup's slot (workgroups cover contiguous ranges)
+        float* dst = a.gram + ((long long)b * a.nslot + (blockIdx.x - first)) * 640;
+        for (int i = tid; i < 640; i += QD_THREADS) {
+          dst[i] = sG[i];
+          sG[i] = 0.f;
+        }
+        __syncthreads();
+      }
+    }
   }
 }
 
 }  // namespace
 
+// Number of per-image slots the fused Gram pass needs for these shapes on this device (>= 1).
+extern "C" int cdfo_qkv_dw_gram_slots(int B, int H, int W) {
+  if (B <= 0 || H <= 0 || W <= 0) return CDFO_EINVAL;
+  int dev = 0;
+  hipDeviceProp_t prop;
+  if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return CDFO_EINVAL;
+  const long long tpi = (long long)cdiv(H, QD_TR) * cdiv(W, QD_TC), ntiles = tpi * B;
+  const long long grid = ntiles < prop.multiProcessorCount ? ntiles : prop.multiProcessorCount;
+  const long long per = (ntiles + grid - 1) / grid;
+  return (int)((tpi + per - 1) / per + 1);
+}
+
 extern "C" int cdfo_qkv_dw(const float* x, int ldx, int B, int H, int W, const void* w_bf16, const float* bias,
-                           const float* dw_w, float eps, float* out, int ldo, void* stream) {
-  if (B <= 0 || H <= 0 || W <= 0 || ldx % 4 || ldx < 64 || ldo % 4 || ldo < 192) return CDFO_EINVAL;
+                           const float* dw_w, float eps, float* out, int ldo, float* gram, int gram_slots, void* stream) {
+  if (B <= 0 || H <= 0 || W <= 0 || ldx % 4 || ldx < 64 || ldo % 4 || ldo < (gram ? 64 : 192)) return CDFO_EINVAL;
   if ((long long)B * H * W >= (1ll << 31)) return CDFO_EINVAL;
   if (!aligned16(x) || !aligned16(w_bf16) || !aligned16(out) || !dw_w) return CDFO_EALIGN;
   hipStream_t st = static_cast<hipStream_t>(stream);
@@ -193,9 +296,13 @@ extern "C" int cdfo_qkv_dw(const float* x, int ldx, int B, int H, int W, const v
   const int grid = (int)(ntiles < cus ? ntiles : cus);
   qd_args a;
   a.x = x; a.ldx = ldx; a.B = B; a.H = H; a.W = W;
-  a.w = static_cast<const unsigned short*>(w_bf16); a.bias = bias; a.dw = dw_w; a.eps = eps; a.out = out; a.ldo = ldo;
+  a.w = static_cast<const unsigned short*>(w_bf16); a.bias = bias; a.dw = dw_w; a.eps = eps; a.out = out; a.ldo = ldo; a.gram = gram; a.nslot = gram_slots;
+  if (gram) {
+    const long long per = (ntiles + grid - 1) / grid, tpi = ntiles / B;
+    if (gram_slots < (int)((tpi + per - 1) / per + 1)) return CDFO_EINVAL;
+  }
   const double px = (double)B * H * W;
-  CdfoProfScope prof(st, KID_DWCONV, 2.0 * px * 192 * (64 + 9), 4.0 * px * (64 + 192));
+  CdfoProfScope prof(st, KID_DWCONV, 2.0 * px * 192 * (64 + 9) + (gram ? 2.0 * px * 640 : 0.0), 4.0 * px * (64 + (gram ? 64 : 192)));
   hipLaunchKernelGGL(qkv_dw_kernel, dim3(grid), dim3(QD_THREADS), QD_LDS, st, a);
   CDFO_LAUNCH_CHECK();
   return 0;

@@ -171,10 +171,9 @@ class CVSR_V7(nn.Module):
         p = "transformer_feature_extraction.path1."
         for _ in range(4):
             x2 = K.spatial_gate(x2, raw[p + "SA.spatial.weight"], raw[p + "SA.spatial.bias"])
-            qkv = K.qkv_dw(x1, w[p + "qkv_dw"], raw[p + "attn.qkv_dwconv.weight"])
-            part, n = K.gram_partial(qkv[..., 0:64], qkv[..., 64:128], 8)
+            v, part, n = K.qkv_dw(x1, w[p + "qkv_dw"], raw[p + "attn.qkv_dwconv.weight"], gram=True)
             fold = K.mdta_fold(part, n, raw[p + "attn.temperature"], raw[p + "attn.project_out.weight"])
-            x1 = self._conv(qkv[..., 128:192], fold, res1=x1, res2=x2)
+            x1 = self._conv(v, fold, res1=x1, res2=x2)
             ln = K.layernorm64(x1, raw[p + "norm2.body.weight"], raw[p + "norm2.body.bias"])
             x1 = self._conv(ln, w[p + "conv"], pad=1, res1=x1)
         return x1

@@ -267,11 +267,15 @@ class CVSR_V8(nn.Module):
             if self.precision == "f32":
                 qkv = self._conv(x1, w[p + "attn.qkv"], ln=(raw[p + "norm1.body.weight"], raw[p + "norm1.body.bias"]))
                 qkv = K.dwconv3x3(qkv, raw[p + "attn.qkv_dwconv.weight"])
-            else:   # LayerNorm + qkv + depthwise 3x3 in one pass (split-bf16 MFMA, fp32-grade)
-                qkv = K.qkv_dw(x1, w[p + "qkv_dw"], raw[p + "attn.qkv_dwconv.weight"])
-            part, n = K.gram_partial(qkv[..., 0:64], qkv[..., 64:128], 8)
-            fold = K.mdta_fold(part, n, raw[p + "attn.temperature"], raw[p + "attn.project_out.weight"])
-            x1 = self._conv(qkv[..., 128:192], fold, res1=x1)
+            else:   # LayerNorm + qkv + depthwise 3x3 + the attention's Gram sums in one pass (split-bf16 MFMA, fp32-grade):
+                # q and k never reach HBM, only v and 640 sums per frame
+                v, part, n = K.qkv_dw(x1, w[p + "qkv_dw"], raw[p + "attn.qkv_dwconv.weight"], gram=True)
+                fold = K.mdta_fold(part, n, raw[p + "attn.temperature"], raw[p + "attn.project_out.weight"])
+                x1 = self._conv(v, fold, res1=x1)
+            if self.precision == "f32":
+                part, n = K.gram_partial(qkv[..., 0:64], qkv[..., 64:128], 8)
+                fold = K.mdta_fold(part, n, raw[p + "attn.temperature"], raw[p + "attn.project_out.weight"])
+                x1 = self._conv(qkv[..., 128:192], fold, res1=x1)
             if self.precision == "fp16x2":
                 # LayerNorm written as fp16 hi | lo planes; the 3x3 conv as a split-fp16 product (a_hi*w_hi + a_lo*w_hi +
                 # a_hi*w_lo, 22-bit operands: fp32-grade like the split-bf16 path it replaces) on the ring kernel

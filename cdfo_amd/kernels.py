@@ -12,7 +12,7 @@ from typing import Optional, Sequence
 import torch
 
 from . import _lib
-from ._lib import ConvArgs, check
+from ._lib import CdfoError, ConvArgs, check
 
 ACT_NONE, ACT_LRELU, ACT_RELU, ACT_SIGMOID = 0, 1, 2, 3
 PREC_F32, PREC_BF16X3, PREC_BF16, PREC_FP16X2, PREC_FP16, PREC_FP16X1 = 0, 1, 2, 3, 4, 5
@@ -416,13 +416,24 @@ def pack_qkv_dw(w_qkv: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor):
     return torch.cat([pack(hi), pack(lo)]).contiguous(), (w @ beta.detach().float()).contiguous()
 
 
-def qkv_dw(x: torch.Tensor, packed, dw_w: torch.Tensor, eps: float = 1e-5) -> torch.Tensor:
-    """depthwise3x3(conv1x1_64->192(LayerNorm64(x))) in one kernel; packed = pack_qkv_dw(...)."""
+def qkv_dw(x: torch.Tensor, packed, dw_w: torch.Tensor, eps: float = 1e-5, gram: bool = False):
+    """depthwise3x3(conv1x1_64->192(LayerNorm64(x))) in one kernel; packed = pack_qkv_dw(...).
+    gram=True: the attention's Gram pass is fused -- returns (v [B,H,W,64], partial [B,n,640], n) for mdta_fold(partial, n, ..)
+    and q / k never reach HBM."""
     B, H, W, Cc, ld = _chk_act(x)
     assert Cc == 64
+    if gram:
+        out = empty_act(B, H, W, 64, x.device)
+        n = int(_lib.lib().cdfo_qkv_dw_gram_slots(B, H, W))
+        if n < 1:
+            raise CdfoError("cdfo_qkv_dw_gram_slots failed")
+        part = torch.zeros((B, n, 640), dtype=torch.float32, device=x.device)
+        check(_lib.lib().cdfo_qkv_dw(_vp(x), ld, B, H, W, _vp(packed[0]), _vp(packed[1]), _vp(dw_w), C.c_float(eps), _vp(out),
+                                     64, _vp(part), n, _stream()), "cdfo_qkv_dw")
+        return out, part, n
     out = empty_act(B, H, W, 192, x.device)
     check(_lib.lib().cdfo_qkv_dw(_vp(x), ld, B, H, W, _vp(packed[0]), _vp(packed[1]), _vp(dw_w), C.c_float(eps), _vp(out),
-                                 192, _stream()), "cdfo_qkv_dw")
+                                 192, None, 0, _stream()), "cdfo_qkv_dw")
     return out
 
 

@@ -196,9 +196,16 @@ int cdfo_block_prologue(const float* x, int ldx, int B, int H, int W, const void
                         void* d16, void* stream);
 /* MDTA front end in one pass (arch.py:1169-1198 LayerNorm, :1551-1552 qkv + qkv_dwconv): out[B][H][W][192] =
  * depthwise3x3(conv1x1(LayerNorm64(x))).  w_bf16: split-bf16 weights [hi|lo][4][2][192][8], element (s,h,n,j) =
- * W[n][16s+8h+j] * gamma[16s+8h+j]; bias[192] = W @ beta (may be NULL); dw_w: raw [192][1][3][3] taps.  */
+ * W[n][16s+8h+j] * gamma[16s+8h+j]; bias[192] = W @ beta (may be NULL); dw_w: raw [192][1][3][3] taps.
+ * gram != NULL fuses the attention's Gram pass (arch.py:1561-1566): q and k are not written, `out` receives v only
+ * (64 channels, ldo >= 64) and gram[B][gram_slots][640] -- zero-filled by the caller, gram_slots >=
+ * cdfo_qkv_dw_gram_slots(B, H, W); per slot the layout of cdfo_gram_partial with 8 channels per head: [c*10 + j] =
+ * sum_p q[c] k[head(c)*8 + j], [c*10 + 8] = sum q[c]^2, [c*10 + 9] = sum k[c]^2 -- receives each workgroup's partial
+ * sums in its own slot (plain stores, fixed summation order: bit-reproducible); cdfo_mdta_fold(gram, gram_slots, ...)
+ * reduces the slots.  */
+int cdfo_qkv_dw_gram_slots(int B, int H, int W);
 int cdfo_qkv_dw(const float* x, int ldx, int B, int H, int W, const void* w_bf16, const float* bias, const float* dw_w,
-                float eps, float* out, int ldo, void* stream);
+                float eps, float* out, int ldo, float* gram, int gram_slots, void* stream);
 /* out = softmax(Q Q^T) V per row (mode 0), column (1) or 8x8 window (2) (arch.py:2179-2249), flash style on the matrix
  * cores: both products with fp16 hi + fp16 lo operands, three passes, fp32 accumulate (scores exact to ~1e-6 relative).
  * Modes 10 / 11 / 12: the plain-VALU forms of 0 / 1 / 2 (kept as A/B references for the tests). */

@@ -65,3 +65,16 @@ def test_qkv_dw_fused(B, H, W):
     torch.cuda.synchronize()
     err = (out.cpu().permute(0, 3, 1, 2) - ref).abs().max().item()
     assert err < 2e-5 * max(1.0, ref.abs().max().item()), err
+    # fused Gram mode: v only + the per-head sums sum_p q k^T, sum q^2, sum k^2 in cdfo_gram_partial's layout
+    v, part, n = K.qkv_dw(x.permute(0, 2, 3, 1).contiguous().cuda(), packed, wd.cuda().contiguous(), gram=True)
+    v2, part2, _ = K.qkv_dw(x.permute(0, 2, 3, 1).contiguous().cuda(), packed, wd.cuda().contiguous(), gram=True)
+    assert torch.equal(part, part2) and torch.equal(v, v2)          # no atomics: bit-reproducible
+    torch.cuda.synchronize()
+    assert (v.cpu().permute(0, 3, 1, 2) - ref[:, 128:]).abs().max().item() < 2e-5 * max(1.0, ref.abs().max().item())
+    q, k = ref[:, :64].double().reshape(B, 8, 8, H * W), ref[:, 64:128].double().reshape(B, 8, 8, H * W)
+    want = torch.zeros(B, 64, 10, dtype=torch.float64)
+    want[:, :, :8] = (q @ k.transpose(-1, -2)).reshape(B, 64, 8)
+    want[:, :, 8] = (q * q).sum(-1).reshape(B, 64)
+    want[:, :, 9] = (k * k).sum(-1).reshape(B, 64)
+    got = part.cpu().double().sum(1).view(B, 64, 10)
+    assert (got - want).abs().max().item() < 1e-4 * max(1.0, want.abs().max().item()), (got - want).abs().max().item()

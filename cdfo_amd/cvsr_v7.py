@@ -13,7 +13,9 @@ Same deliberate differences as ``CVSR_V8``: CUDA (ROCm) tensors and ``torch.no_g
 fallback), injectable Gumbel noise (``gumbel_uniform=`` : the 36 uniform draws of ``RDAB.gumbel_softmax`` in call order,
 each ``[B,64,H>>lv,W>>lv]``), ``L1_fea`` returned channels-last, no ``featuremap_visual`` side effects.  H and W must be
 multiples of 4 (two pyramid halvings; the reference's shapes only line up under the same condition).  Arithmetic:
-``precision`` = "bf16x3" (split-bf16 matrix cores, fp32-grade; default) or "f32"."""
+``precision`` = "bf16x3" (split-bf16 matrix cores, fp32-grade; default), "f32" (exact), or "fp16x2" (fp16 weights,
+fp16 hi+lo activations, two MFMA passes, in the 3x3 convolutions of the alignment head, ``conv_expand_fea_r`` and the
+trunk; the feature extractor stays split-bf16)."""
 from __future__ import annotations
 
 import math
@@ -83,7 +85,7 @@ def _param_spec():
 
 
 class CVSR_V7(nn.Module):
-    PRECISIONS = {"f32": K.PREC_F32, "bf16x3": K.PREC_BF16X3}
+    PRECISIONS = {"f32": K.PREC_F32, "bf16x3": K.PREC_BF16X3, "fp16x2": K.PREC_FP16X2}
 
     def __init__(self, nf=64, nframes=7, fea_ext_RBs=7, SCGs=4, istraining=False):
         super().__init__()
@@ -161,8 +163,12 @@ class CVSR_V7(nn.Module):
         self._packed, self._packed_sig = w, sig
         return w
 
-    def _conv(self, *args, **kw):
-        return K.conv(*args, prec=self.PRECISIONS[self.precision], **kw)
+    def _conv(self, *args, exact=False, **kw):
+        """``exact``: convolutions whose result is returned to the caller (the L1_fea feature cache) stay split-bf16."""
+        prec = self.PRECISIONS[self.precision]
+        if exact and prec == K.PREC_FP16X2:
+            prec = K.PREC_BF16X3
+        return K.conv(*args, prec=prec, **kw)
 
     # -- building blocks ------------------------------------------------------------------------------------------
     def _feature_extraction(self, w, x1, x2):
@@ -175,7 +181,7 @@ class CVSR_V7(nn.Module):
             fold = K.mdta_fold(part, n, raw[p + "attn.temperature"], raw[p + "attn.project_out.weight"])
             x1 = self._conv(v, fold, res1=x1, res2=x2)
             ln = K.layernorm64(x1, raw[p + "norm2.body.weight"], raw[p + "norm2.body.bias"])
-            x1 = self._conv(ln, w[p + "conv"], pad=1, res1=x1)
+            x1 = self._conv(ln, w[p + "conv"], pad=1, res1=x1, exact=True)
         return x1
 
     def _rdab(self, w, res, xc, noise):

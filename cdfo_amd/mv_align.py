@@ -75,7 +75,7 @@ class MVDualAttAlignment(ModulatedDeformConvPack):
         B, _, H, W = x.shape
         P = H * W
         d = lambda t: t.detach().contiguous()  # noqa: E731
-        prec = K.PREC_BF16X3 if self.precision == "bf16x3" else K.PREC_F32
+        prec = {"bf16x3": K.PREC_BF16X3, "fp16x2": K.PREC_FP16X2}.get(self.precision, K.PREC_F32)
         warped = K.flow_warp(extra, flow, 2 * P)
         fused = K.conv([warped, pred], w["fusion"])                      # no activation here (arch.py:3305)
         gp, ng = K.gram_partial(xq, fused, 8)

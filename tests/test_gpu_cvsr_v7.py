@@ -27,7 +27,7 @@ def _nchw(t):
     return t.permute(0, 3, 1, 2).cpu()
 
 
-@pytest.mark.parametrize("precision", ["f32", "bf16x3"])
+@pytest.mark.parametrize("precision", ["f32", "bf16x3", "fp16x2"])
 @pytest.mark.parametrize("path", GOLD, ids=lambda p: os.path.basename(p)[8:-4])
 def test_v7_hip_forward_matches_reference_golden(path, precision):
     from oracle.cvsr_v7_ref import cvsr_v7_forward, make_inputs_v7

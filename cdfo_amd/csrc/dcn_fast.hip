@@ -122,28 +122,38 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     // ---- phase 1: sample.  item q = (4-channel block cb, tap t) -> K rows q*4 .. q*4+3.  Items are taken NB at a time and
     // every stage (offset / mask loads, the 4 x NB corner gathers, combine + store) is unrolled over the batch, so that a
     // stage's loads are all in flight together: the dependent chain offset -> gather costs two memory latencies per
-    // BATCH, not per item (with two waves per SIMD there is little else to hide it)
+    // BATCH, not per item; the next batch's offsets are requested right behind the current batch's gathers
     {
       constexpr int NB = 3;
       int cb0 = slice / T, t0 = slice - cb0 * T;
+      float noh[NB], now_[NB], nmm[NB];                          // the NEXT batch's offsets / mask, loaded one batch ahead
+      int ntt[NB], ncb[NB];
+      bool nlive[NB];
+      auto load_batch = [&](int q0) {
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+          ntt[i] = t0; ncb[i] = cb0;
+          nlive[i] = pvalid && (q0 + 8 * i) < NI;
+          noh[i] = now_[i] = 0.f; nmm[i] = 1.f;
+          if (nlive[i]) {
+            const int d = (c0 + cb0 * 4) / Cdg;
+            const int ot = d * T + t0;                      // per-image indices fit 32 bits (checked by the launcher)
+            noh[i] = off_b[ot * 2 * P];
+            now_[i] = off_b[(ot * 2 + 1) * P];
+            if (msk_b) nmm[i] = msk_b[ot * P];
+          }
+          t0 += 8;
+          while (t0 >= T) { t0 -= T; ++cb0; }
+        }
+      };
+      load_batch(slice);
       for (int q0 = slice; q0 < NI; q0 += 8 * NB) {
         float oh[NB], ow[NB], mm[NB];
         int tt[NB], cbb[NB];
         bool live[NB];
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
-          tt[i] = t0; cbb[i] = cb0;
-          live[i] = pvalid && (q0 + 8 * i) < NI;
-          oh[i] = ow[i] = 0.f; mm[i] = 1.f;
-          if (live[i]) {
-            const int d = (c0 + cb0 * 4) / Cdg;
-            const int ot = d * T + t0;                      // per-image indices fit 32 bits (checked by the launcher)
-            oh[i] = off_b[ot * 2 * P];
-            ow[i] = off_b[(ot * 2 + 1) * P];
-            if (msk_b) mm[i] = msk_b[ot * P];
-          }
-          t0 += 8;
-          while (t0 >= T) { t0 -= T; ++cb0; }
+          oh[i] = noh[i]; ow[i] = now_[i]; mm[i] = nmm[i]; tt[i] = ntt[i]; cbb[i] = ncb[i]; live[i] = nlive[i];
         }
         f32x4 v[NB][4];
         float wgt[NB][4];
@@ -166,6 +176,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
             wgt[i][0] = hh * hw; wgt[i][1] = hh * lw; wgt[i][2] = lh * hw; wgt[i][3] = lh * lw;
           }
         }
+        if (q0 + 8 * NB < NI) load_batch(q0 + 8 * NB);             // in flight behind this batch's gathers
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
           const int q = q0 + 8 * i;

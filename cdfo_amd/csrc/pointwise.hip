@@ -182,6 +182,13 @@ __global__ __launch_bounds__(256) void flow_warp_kernel(const float* __restrict_
     const float ny = 2.0f * ((float)y + fy) / hm - 1.0f;
     const float sx = ((nx + 1.f) / 2.f) * (float)(W - 1);
     const float sy = ((ny + 1.f) / 2.f) * (float)(H - 1);
+    // a sample at or beyond one pixel outside the image has no corner inside it: the result is 0 (grid_sample, zeros
+    // padding).  Decided in floating point BEFORE any conversion to int -- the reference's mv2mvs leaves x / 0 = inf in the
+    // motion field (test_LD_22_FPS.py:106-110) and float -> int of inf / NaN is undefined
+    if (!(sx > -1.f && sx < (float)W && sy > -1.f && sy < (float)H)) {
+      *reinterpret_cast<f32x4*>(out + p * ldo + cg * 4) = f32x4{0.f, 0.f, 0.f, 0.f};
+      continue;
+    }
     const float x0f = floorf(sx), y0f = floorf(sy);
     const int x0 = (int)x0f, y0 = (int)y0f;
     const float tx = sx - x0f, ty = sy - y0f;

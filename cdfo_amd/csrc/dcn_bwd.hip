@@ -38,7 +38,8 @@ struct Sample {             // bilinear footprint of one sample position (cu:466
 
 __device__ __forceinline__ Sample make_sample(float h, float w, int H, int W) {
   Sample s;
-  s.valid = !(h <= -1.f || w <= -1.f || h >= (float)H || w >= (float)W);
+  s.valid = h > -1.f && w > -1.f && h < (float)H && w < (float)W;     // false for NaN / inf offsets as well
+  if (!s.valid) h = w = 0.f;                                           // no float -> int conversion of a non-finite value
   const int hl = (int)floorf(h), wl = (int)floorf(w), hhi = hl + 1, whi = wl + 1;
   s.lh = h - (float)hl; s.lw = w - (float)wl; s.hh = 1.f - s.lh; s.hw = 1.f - s.lw;
   s.o1 = (s.valid && hl >= 0 && wl >= 0) ? hl * W + wl : -1;

@@ -218,3 +218,40 @@ def test_dcn_forward_workspace_paths_agree_with_the_oracle():
                                             dl, g, dg, p(ws), C.c_longlong(need), None), "cdfo_dcn_forward")
             ref1 = dcn_forward_ref(x.cpu().numpy(), off.cpu().numpy(), None, w.cpu().numpy(), None, st, pd, dl, g, dg)
             assert np.abs(out.cpu().numpy() - ref1).max() <= 2e-5 * max(1.0, np.abs(ref1).max()), n
+
+
+def test_dcn_non_finite_offsets_sample_nothing():
+    """Offsets that are inf / NaN fail the validity test (cu:617) like any out-of-range position: the tap contributes 0,
+    forward and backward, on every kernel variant -- and nothing converts a non-finite float to an index."""
+    import ctypes as C
+    from cdfo_amd import _lib
+    from cdfo_amd.dcn import modulated_deform_conv
+    from oracle.dcn_modules_ref import dcn_backward_ref
+    lib = _lib.lib()
+    B, Cc, Co, H, W, dg = 1, 64, 64, 10, 14, 16
+    x, w, b, off, msk, go = _bwd_inputs(B, Cc, Co, H, W, 3, 1, 1, 1, 1, dg, 4242)
+    off[0, 0::7, 2, 3] = np.inf
+    off[0, 1::11, 4, 5] = -np.inf
+    off[0, 2::13, 6, 7] = np.nan
+    ref = dcn_forward_ref(x, off, msk, w, b, 1, 1, 1, 1, dg)
+    assert np.isfinite(ref).all()
+    t = lambda a: torch.from_numpy(a).cuda()  # noqa: E731
+    p = lambda v: C.c_void_p(None if v is None else v.data_ptr())  # noqa: E731
+    need = int(lib.cdfo_dcn_workspace_bytes(B, Cc, H, W, Co, 3, 3, 1, dg))
+    tx, toff, tm, tw, tb = t(x), t(off), t(msk), t(w), t(b)
+    for nbytes in (0, x.size * 4, need):
+        ws = torch.empty(nbytes, dtype=torch.uint8, device="cuda") if nbytes else None
+        out = torch.full((B, Co, H, W), float("nan"), device="cuda")
+        _lib.check(lib.cdfo_dcn_forward(p(tx), p(toff), p(tm), p(tw), p(tb), p(out), B, Cc, H, W, Co, 3, 3, 1, 1, 1, 1, 1, 1, 1,
+                                        dg, p(ws), C.c_longlong(nbytes), None), "cdfo_dcn_forward")
+        torch.cuda.synchronize()
+        assert np.abs(out.cpu().numpy() - ref).max() <= 2e-5 * max(1.0, np.abs(ref).max()), nbytes
+    gx, gw_ = tx.clone().requires_grad_(), tw.clone().requires_grad_()
+    goff, gm = toff.clone().requires_grad_(), tm.clone().requires_grad_()
+    modulated_deform_conv(gx, goff, gm, gw_, tb, 1, 1, 1, 1, dg).backward(t(go))
+    torch.cuda.synchronize()
+    want = dcn_backward_ref(x, np.nan_to_num(off, nan=1e6, posinf=1e6, neginf=-1e6), msk, w, go, 1, 1, 1, 1, dg)
+    _close(gx.grad.cpu().numpy(), want["grad_input"])
+    _close(gw_.grad.cpu().numpy(), want["grad_weight"])
+    _close(gm.grad.cpu().numpy(), want["grad_mask"])
+    _close(goff.grad.cpu().numpy(), want["grad_offset"])

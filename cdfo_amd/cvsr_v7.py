@@ -14,8 +14,8 @@ fallback), injectable Gumbel noise (``gumbel_uniform=`` : the 36 uniform draws o
 each ``[B,64,H>>lv,W>>lv]``), ``L1_fea`` returned channels-last, no ``featuremap_visual`` side effects.  H and W must be
 multiples of 4 (two pyramid halvings; the reference's shapes only line up under the same condition).  Arithmetic:
 ``precision`` = "bf16x3" (split-bf16 matrix cores, fp32-grade; default), "f32" (exact), or "fp16x2" (fp16 weights,
-fp16 hi+lo activations, two MFMA passes, in the 3x3 convolutions of the alignment head, ``conv_expand_fea_r`` and the
-trunk; the feature extractor stays split-bf16)."""
+fp16 hi+lo activations, two MFMA passes, in the 3x3 convolutions of the alignment head and ``conv_expand_fea_r``; the
+trunk's body convolutions on CVSR_V8's single-pass fp16 ``Block_`` kernels; the feature extractor stays split-bf16)."""
 from __future__ import annotations
 
 import math
@@ -199,7 +199,13 @@ class CVSR_V7(nn.Module):
     def _block(self, w, p, xs):
         """``Block.forward`` over the level list (arch.py:367-375): x + body(x) + down-exchange + up-exchange, where the
         finest level takes its own body output in place of a down-exchange and the coarsest in place of an up-exchange."""
-        res = [self._conv(self._conv(z, w[p + "body.0"], pad=1, act=K.ACT_LRELU), w[p + "body.2"], pad=1) for z in xs]
+        b0, b2 = w[p + "body.0"], w[p + "body.2"]
+        if self.precision == "fp16x2" and b0.wh is not None and all(z.shape[1] % 4 == 0 for z in xs):
+            # the body on CVSR_V8's Block_ kernels: 64->256 weights-stationary, 256->64 on the LDS-DMA ring kernel, fp16
+            # chunk-planar tensors in between, single-pass fp16 MFMA with fp32 accumulation
+            res = [K.conv_ring(K.conv3x3_ws(K.to_cp16(z), b0, act=K.ACT_LRELU), b2) for z in xs]
+        else:
+            res = [self._conv(self._conv(z, b0, pad=1, act=K.ACT_LRELU), b2, pad=1) for z in xs]
         outs = []
         last = len(xs) - 1
         for l, (x, r) in enumerate(zip(xs, res)):

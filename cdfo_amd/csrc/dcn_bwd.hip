@@ -118,6 +118,116 @@ __global__ __launch_bounds__(256) void dcn_bwd_data_kernel(DcnBwdArgs a) {
   if (a.gmask) a.gmask[mb] = mv;
 }
 
+// ---- data gradients, tiled form (groups == 1, C/dg == 4, kh*kw <= 9: the alignment module's shape) ----------------------
+// One workgroup = an 8 x 32 tile of output pixels x one deformable group; one thread = one pixel.
+//   * the thread's 64 grad_output values are read once (coalesced along x) and turned into all 4 x kh*kw column gradients
+//     of its deformable group with wave-uniform (scalar-loaded) weights: Co * 4 * kh*kw FMAs per pixel, no re-reads;
+//   * with 4 channels per group the thread is the only contributor to grad_offset / grad_mask of (group, tap, pixel):
+//     plain coalesced stores, deterministic;
+//   * grad_input is scattered into an LDS window covering the tile's sampling footprint + a 5-pixel margin (LDS float
+//     atomics -- they are what bounds the kernel: 2.9 ms without the scatter, 13.5 ms with it at the alignment shape);
+//     only samples that leave the window go to global memory one by one.  The window is flushed once, skipping
+//     zeros: ~3.7 k global atomics per workgroup instead of 256 * kh*kw * 16 (a 16 x 32 tile was no faster).
+constexpr int DT_Y = 8, DT_X = 32, DT_MARGIN = 5, DT_MAXT = 9, DT_THREADS = DT_Y * DT_X;
+
+template <bool T9>
+__global__ __launch_bounds__(DT_THREADS) void dcn_bwd_data_tile_kernel(DcnBwdArgs a, int WH, int WW, int tiles_x) {
+  extern __shared__ __attribute__((aligned(16))) float win[];          // [4][WH][WW]
+  const int tid = threadIdx.x;
+  const int T = T9 ? 9 : a.kh * a.kw, P = a.Ho * a.Wo;
+  const int d = blockIdx.y, b = blockIdx.z;
+  const int ty0 = (blockIdx.x / tiles_x) * DT_Y, tx0 = (blockIdx.x % tiles_x) * DT_X;
+  const int ho = ty0 + (tid >> 5), wo = tx0 + (tid & 31);
+  const bool pvalid = ho < a.Ho && wo < a.Wo;
+  const int p = pvalid ? ho * a.Wo + wo : 0;
+  const int wy0 = ty0 * a.sh - a.ph - DT_MARGIN, wx0 = tx0 * a.sw - a.pw - DT_MARGIN;
+  const int wsize = 4 * WH * WW;
+  if (a.gin) {
+    for (int i = tid; i < wsize; i += DT_THREADS) win[i] = 0.f;
+    __syncthreads();
+  }
+  float cg[4][DT_MAXT];
+#pragma unroll
+  for (int e = 0; e < 4; ++e)
+#pragma unroll
+    for (int t = 0; t < DT_MAXT; ++t) cg[e][t] = 0.f;
+  if (pvalid) {
+    const float* gp = a.gout + (long long)b * a.Co * P + p;
+    const float* wd = a.w + (long long)(4 * d) * T;                    // + o * C * T + e * T + t   (wave-uniform: scalar loads;
+    for (int o = 0; o < a.Co; ++o) {                                   //  staging them in LDS instead was 9 % slower)
+      const float gv = gp[(long long)o * P];
+      const float* wo_ = wd + (long long)o * a.C * T;
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int t = 0; t < DT_MAXT; ++t)
+          if (T9 || t < T) cg[e][t] = fmaf(wo_[e * T + t], gv, cg[e][t]);
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < DT_MAXT; ++t) {
+    if (!T9 && t >= T) break;
+    if (!pvalid) continue;
+    const int ki = t / a.kw, kj = t - ki * a.kw;
+    const long long ob = ((long long)(b * a.dg + d) * T + t) * 2 * P + p;
+    const long long mb = ((long long)(b * a.dg + d) * T + t) * P + p;
+    const float h_im = (float)(ho * a.sh - a.ph + ki * a.dh) + a.offset[ob];
+    const float w_im = (float)(wo * a.sw - a.pw + kj * a.dw) + a.offset[ob + P];
+    const float m = a.mask ? a.mask[mb] : 1.f;
+    float vh = 0.f, vw = 0.f, mv = 0.f;
+    if (h_im > -1.f && w_im > -1.f && h_im < (float)a.H && w_im < (float)a.W) {
+      const int hl = (int)floorf(h_im), wl = (int)floorf(w_im);
+      const float lh = h_im - (float)hl, lw = w_im - (float)wl, hh = 1.f - lh, hw = 1.f - lw;
+      const bool r0 = hl >= 0, r1 = hl + 1 <= a.H - 1, c0 = wl >= 0, c1 = wl + 1 <= a.W - 1;
+      const float w1 = hh * hw, w2 = hh * lw, w3 = lh * hw, w4 = lh * lw;
+      const int o00 = hl * a.W + wl;
+      const int ly = hl - wy0, lx = wl - wx0;                          // window coordinates of the top-left corner
+      const bool inwin = ly >= 0 && ly + 1 < WH && lx >= 0 && lx + 1 < WW;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const long long pl = ((long long)b * a.C + 4 * d + e) * a.H * a.W;
+        const float* im = a.in + pl;
+        const float v1 = (r0 && c0) ? im[o00] : 0.f, v2 = (r0 && c1) ? im[o00 + 1] : 0.f;
+        const float v3 = (r1 && c0) ? im[o00 + a.W] : 0.f, v4 = (r1 && c1) ? im[o00 + a.W + 1] : 0.f;
+        const float cgv = cg[e][t];
+        mv = fmaf(cgv, w1 * v1 + w2 * v2 + w3 * v3 + w4 * v4, mv);
+        const float tg = cgv * m;
+        vh = fmaf(hw * (v3 - v1) + lw * (v4 - v2), tg, vh);
+        vw = fmaf(hh * (v2 - v1) + lh * (v4 - v3), tg, vw);
+        if (a.gin) {
+          if (inwin) {
+            float* wp = win + (e * WH + ly) * WW + lx;
+            if (r0 && c0) atomicAdd(wp, w1 * tg);
+            if (r0 && c1) atomicAdd(wp + 1, w2 * tg);
+            if (r1 && c0) atomicAdd(wp + WW, w3 * tg);
+            if (r1 && c1) atomicAdd(wp + WW + 1, w4 * tg);
+          } else {
+            float* gi = a.gin + pl + o00;
+            if (r0 && c0) unsafeAtomicAdd(gi, w1 * tg);
+            if (r0 && c1) unsafeAtomicAdd(gi + 1, w2 * tg);
+            if (r1 && c0) unsafeAtomicAdd(gi + a.W, w3 * tg);
+            if (r1 && c1) unsafeAtomicAdd(gi + a.W + 1, w4 * tg);
+          }
+        }
+      }
+    }
+    if (a.goff) { a.goff[ob] = vh; a.goff[ob + P] = vw; }
+    if (a.gmask) a.gmask[mb] = mv;
+  }
+  if (a.gin) {
+    __syncthreads();
+    const int plane = WH * WW;
+    for (int i = tid; i < wsize; i += DT_THREADS) {
+      const float v = win[i];
+      if (v == 0.f) continue;
+      const int e = i / plane, r = i - e * plane, ly = r / WW, lx = r - ly * WW;
+      const int yy = wy0 + ly, xx = wx0 + lx;
+      if (yy >= 0 && yy < a.H && xx >= 0 && xx < a.W)
+        unsafeAtomicAdd(a.gin + (((long long)b * a.C + 4 * d + e) * a.H + yy) * a.W + xx, v);
+    }
+  }
+}
+
 constexpr int WPX = 64;     // positions per chunk
 constexpr int WOB = 64;     // output channels per workgroup
 constexpr int WPAIRS = 16;  // (cout, tap) pairs per thread  =>  kh*kw <= 64
@@ -196,6 +306,89 @@ __global__ __launch_bounds__(256) void dcn_bwd_weight_kernel(DcnBwdArgs a, int s
   }
 }
 
+// The same contraction for four input channels of one deformable group at a time (groups == 1, (C/dg) % 4 == 0,
+// kh*kw <= 9): the sample position, its bilinear weights and the offset / mask reads are shared by the four channels and
+// the grad_output tile is staged once for all of them -- a quarter of the latency-bound sampling work per channel.
+constexpr int W4PAIRS = 9;   // (cout, channel, tap) triples per thread: 64 * 4 * T / 256  =>  T <= 9
+
+__global__ __launch_bounds__(256) void dcn_bwd_weight4_kernel(DcnBwdArgs a, int span /* positions per workgroup */) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* gl = smem;                      // [WOB][WPX + 1]
+  float* vl = smem + WOB * (WPX + 1);    // [4][T][WPX]
+  const int tid = threadIdx.x;
+  const int T = a.kh * a.kw, P = a.Ho * a.Wo, Cdg = a.C / a.dg;
+  const int c0 = blockIdx.y * 4, d = c0 / Cdg;
+  const int o0 = blockIdx.z * WOB, no = (a.Co - o0) < WOB ? (a.Co - o0) : WOB;
+  const long long total = (long long)a.B * P;
+  const long long q0 = (long long)blockIdx.x * span;
+  const long long q1 = (q0 + span) < total ? (q0 + span) : total;
+  float acc[W4PAIRS];
+#pragma unroll
+  for (int k = 0; k < W4PAIRS; ++k) acc[k] = 0.f;
+
+  for (long long qc = q0; qc < q1; qc += WPX) {
+    __syncthreads();
+    for (int item = tid; item < T * WPX; item += 256) {
+      const int t = item >> 6, px = item & (WPX - 1);
+      const long long q = qc + px;
+      float val[4] = {0.f, 0.f, 0.f, 0.f};
+      if (q < q1) {
+        const int b = (int)(q / P), p = (int)(q - (long long)b * P);
+        const int ho = p / a.Wo, wo = p - ho * a.Wo, ki = t / a.kw, kj = t - ki * a.kw;
+        const long long ob = ((long long)(b * a.dg + d) * T + t) * 2 * P + p;
+        const float h_im = (float)(ho * a.sh - a.ph + ki * a.dh) + a.offset[ob];
+        const float w_im = (float)(wo * a.sw - a.pw + kj * a.dw) + a.offset[ob + P];
+        const Sample s = make_sample(h_im, w_im, a.H, a.W);
+        if (s.valid) {
+          const float m = a.mask ? a.mask[((long long)(b * a.dg + d) * T + t) * P + p] : 1.f;
+          const float w1 = s.hh * s.hw, w2 = s.hh * s.lw, w3 = s.lh * s.hw, w4 = s.lh * s.lw;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float* im = a.in + ((long long)b * a.C + c0 + e) * a.H * a.W;
+            const float v1 = s.o1 >= 0 ? im[s.o1] : 0.f, v2 = s.o2 >= 0 ? im[s.o2] : 0.f;
+            const float v3 = s.o3 >= 0 ? im[s.o3] : 0.f, v4 = s.o4 >= 0 ? im[s.o4] : 0.f;
+            val[e] = (w1 * v1 + w2 * v2 + w3 * v3 + w4 * v4) * m;
+          }
+        }
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) vl[(e * T + t) * WPX + px] = val[e];
+    }
+    for (int item = tid; item < WOB * WPX; item += 256) {
+      const int o = item >> 6, px = item & (WPX - 1);
+      const long long q = qc + px;
+      float v = 0.f;
+      if (o < no && q < q1) {
+        const int b = (int)(q / P), p = (int)(q - (long long)b * P);
+        v = a.gout[((long long)b * a.Co + o0 + o) * P + p];
+      }
+      gl[o * (WPX + 1) + px] = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < W4PAIRS; ++k) {
+      const int pair = tid + k * 256;
+      if (pair < WOB * 4 * T) {
+        const int o = pair & (WOB - 1), et = pair >> 6;          // et = e * T + t
+        const float* gr = gl + o * (WPX + 1);
+        const float* vr = vl + et * WPX;
+        float s = 0.f;
+#pragma unroll 16
+        for (int px = 0; px < WPX; ++px) s = fmaf(gr[px], vr[px], s);
+        acc[k] += s;
+      }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < W4PAIRS; ++k) {
+    const int pair = tid + k * 256;
+    if (pair < WOB * 4 * T) {
+      const int o = pair & (WOB - 1), et = pair >> 6;
+      if (o < no) unsafeAtomicAdd(a.gw + ((long long)(o0 + o) * a.C + c0) * T + et, a.scale * acc[k]);   // [o][c0 + e][t]
+    }
+  }
+}
+
 // grid = (Co, slices): every workgroup sums one slice of one output channel's B*P values; one atomic per workgroup
 __global__ __launch_bounds__(256) void dcn_bwd_bias_kernel(const float* __restrict__ gout, float* __restrict__ gbias, int B,
                                                            int Co, int P) {
@@ -240,7 +433,17 @@ extern "C" int cdfo_dcn_backward(const float* in, const float* offset, const flo
   if (grad_in || grad_offset || grad_mask) {
     CdfoProfScope prof(st, KID_DCN_BWD, 2.0 * px * Co * (C / groups) * T,
                        4.0 * (px * (Co + 6.0 * deformable_groups * T) + 2.0 * B * C * H * W + (double)Co * (C / groups) * T));
-    hipLaunchKernelGGL(dcn_bwd_data_kernel, dim3(cdiv(P, 256), deformable_groups * T, B), dim3(256), 0, st, a);
+    const int WH = (DT_Y - 1) * sh + (kh - 1) * dh + 2 + 2 * DT_MARGIN, WW = (DT_X - 1) * sw + (kw - 1) * dw + 2 + 2 * DT_MARGIN;
+    const size_t wlds = (size_t)4 * WH * WW * sizeof(float);
+    const int tiles_x = cdiv(Wo, DT_X), tiles_y = cdiv(Ho, DT_Y);
+    if (groups == 1 && C / deformable_groups == 4 && T <= DT_MAXT && wlds <= 48 * 1024 &&
+        (long long)tiles_x * tiles_y < (1ll << 31)) {
+      dim3 grid(tiles_x * tiles_y, deformable_groups, B);
+      if (T == 9) hipLaunchKernelGGL(dcn_bwd_data_tile_kernel<true>, grid, dim3(DT_THREADS), wlds, st, a, WH, WW, tiles_x);
+      else hipLaunchKernelGGL(dcn_bwd_data_tile_kernel<false>, grid, dim3(DT_THREADS), wlds, st, a, WH, WW, tiles_x);
+    } else {
+      hipLaunchKernelGGL(dcn_bwd_data_kernel, dim3(cdiv(P, 256), deformable_groups * T, B), dim3(256), 0, st, a);
+    }
     CDFO_LAUNCH_CHECK();
   }
   if (grad_weight) {
@@ -251,10 +454,19 @@ extern "C" int cdfo_dcn_backward(const float* in, const float* offset, const flo
     long long span = (total + want - 1) / want;
     span = (span + WPX - 1) / WPX * WPX;
     const int nx = (int)((total + span - 1) / span);
-    const size_t lds = (size_t)(WOB * (WPX + 1) + T * WPX) * sizeof(float);
     CdfoProfScope prof(st, KID_DCN_BWD, 2.0 * px * Co * (C / groups) * T,
                        4.0 * (px * (Co + 3.0 * deformable_groups * T) + (double)B * C * H * W + (double)Co * (C / groups) * T));
-    hipLaunchKernelGGL(dcn_bwd_weight_kernel, dim3(nx, C, zb), dim3(256), lds, st, a, (int)span);
+    if (groups == 1 && (C / deformable_groups) % 4 == 0 && T <= W4PAIRS) {
+      const size_t lds4 = (size_t)(WOB * (WPX + 1) + 4 * T * WPX) * sizeof(float);
+      long long want4 = 2048 / ((long long)(C / 4) * zb) + 1;
+      long long span4 = (total + want4 - 1) / want4;
+      span4 = (span4 + WPX - 1) / WPX * WPX;
+      const int nx4 = (int)((total + span4 - 1) / span4);
+      hipLaunchKernelGGL(dcn_bwd_weight4_kernel, dim3(nx4, C / 4, zb), dim3(256), lds4, st, a, (int)span4);
+    } else {
+      const size_t lds = (size_t)(WOB * (WPX + 1) + T * WPX) * sizeof(float);
+      hipLaunchKernelGGL(dcn_bwd_weight_kernel, dim3(nx, C, zb), dim3(256), lds, st, a, (int)span);
+    }
     CDFO_LAUNCH_CHECK();
   }
   if (grad_bias) {

@@ -30,6 +30,8 @@ CASES = [
     (1, 8, 8, 10, 10, 3, 1, 2, 2, 1, 2, False),
     (1, 6, 300, 7, 9, 1, 1, 0, 1, 1, 3, True),         # > 256 output channels, 1x1 kernel
     (1, 4, 4, 40, 70, 3, 1, 1, 1, 1, 1, False),
+    (1, 8, 16, 11, 13, 1, 1, 0, 1, 1, 2, True),        # 1x1 kernel with 4 channels per deformable group (tiled backward, T < 9)
+    (2, 16, 8, 19, 37, 3, 2, 1, 1, 1, 4, True),        # stride 2, ragged 8x32 tiles (tiled backward)
 ]
 
 

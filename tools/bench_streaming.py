@@ -6,7 +6,6 @@ import numpy as np
 import torch
 from arch.SIDECVSR_our import CVSR_V8
 from cdfo_amd.streaming import StreamingSR
-from oracle.cvsr_v8_ref import make_state_dict
 
 
 def main():
@@ -19,7 +18,6 @@ def main():
     mv[..., 2] = rs.choice([-2.0, -1.0, 1.0], size=mv.shape[:-1])
     mv = np.repeat(np.repeat(mv, 8, axis=2), 8, axis=3)[:, :, :H, :W]
     model = CVSR_V8()
-    model.load_state_dict(make_state_dict(0, perturb=False), strict=True)
     model = model.cuda().eval()
     for use_graph, nstr in ((False, 1), (True, 1), (False, 3), (False, 6)):
         model.neighbour_streams = nstr

@@ -7,7 +7,7 @@ import torch
 from cdfo_amd import kernels as K
 from cdfo_amd import deform_conv_cuda as D
 from arch.SIDECVSR_our import CVSR_V7
-from oracle.cvsr_v7_ref import make_inputs_v7, make_state_dict_v7
+from _inputs import random_inputs
 
 rec, depth = [], [0]
 
@@ -49,13 +49,13 @@ def main():
     ap.add_argument("--precision", default="bf16x3")
     a = ap.parse_args()
     B, H, W = a.batch, a.height, a.width
-    m = CVSR_V7()
-    m.load_state_dict(make_state_dict_v7(0), strict=True)
+    torch.manual_seed(0)
+    m = CVSR_V7()                                   # random init of the reference architecture
     m = m.cuda().eval()
     m.precision = a.precision
-    inp = make_inputs_v7(B, H, W, 1002)
-    d = {k: v.cuda() for k, v in inp.items() if k != "gumbel_u"}
-    noise = [u.cuda() for u in inp["gumbel_u"]]
+    inp = random_inputs(B, H, W, 1002, levels=(2, 1, 0))
+    d = {k: v for k, v in inp.items() if k != "gumbel_u"}
+    noise = inp["gumbel_u"]
     run = lambda: m(d["x"], d["mvs0"], d["mvs1"], d["pms"], d["rms"], d["ufs"], None, gumbel_uniform=noise)
     with torch.no_grad():
         run()

@@ -4,7 +4,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from cdfo_amd import kernels as K
 from arch.SIDECVSR_our import CVSR_V8
-from oracle.cvsr_v8_ref import make_inputs, make_state_dict
+from _inputs import random_inputs
 
 rec = []
 
@@ -38,11 +38,9 @@ def ws_sig(src, pc, **kw):
 
 def main():
     B, H, W = 8, 272, 480
-    sd = make_state_dict(0, perturb=False)
     m = CVSR_V8()
-    m.load_state_dict(sd, strict=True)
     m = m.cuda().eval()
-    inp = make_inputs(B, H, W, 1002, pad_rows=2)
+    inp = random_inputs(B, H, W, 1002)
     d = {k: v.cuda() for k, v in inp.items() if k != "gumbel_u"}
     noise = [u.cuda() for u in inp["gumbel_u"]]
     run = lambda: m(d["x"], d["mvs0"], d["mvs1"], d["pms"], d["rms"], d["ufs"], None, gumbel_uniform=noise)

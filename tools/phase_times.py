@@ -3,17 +3,16 @@ import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from arch.SIDECVSR_our import CVSR_V8
-from oracle.cvsr_v8_ref import make_inputs, make_state_dict
+from _inputs import random_inputs
 
 
 def main():
     B, H, W = 8, 272, 480
     m = CVSR_V8()
-    m.load_state_dict(make_state_dict(0, perturb=False), strict=True)
     m = m.cuda().eval()
     if len(sys.argv) > 1:
         m.neighbour_streams = int(sys.argv[1])
-    inp = make_inputs(B, H, W, 1002, pad_rows=2)
+    inp = random_inputs(B, H, W, 1002)
     d = {k: v.cuda() for k, v in inp.items() if k != "gumbel_u"}
     noise = [u.cuda() for u in inp["gumbel_u"]]
     marks = []

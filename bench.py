@@ -54,7 +54,7 @@ def main():
     ap.add_argument("--no-parity", action="store_true", help="skip the c1 parity spot-check (profiling runs: keeps every launch at the workload's size)")
     ap.add_argument("--precision", default="fp16x2", choices=["f32", "bf16x3", "bf16", "fp16x2"])
     ap.add_argument("--streaming", action="store_true", help="time the cached-feature path (pre_L1_fea given: one new frame per clip, test_LD_22_FPS.py:183-189) instead of the fresh path")
-    ap.add_argument("--neighbour-streams", type=int, default=3, help="issue the six neighbour-frame pipelines on this many HIP streams")
+    ap.add_argument("--neighbour-streams", type=int, default=0, help="issue the six neighbour-frame pipelines on this many HIP streams (0 = the model's choice: 3 at 8 clips)")
     ap.add_argument("--breakdown", type=str, default="", help="write the per-kernel-family event timings to this file")
     args = ap.parse_args()
 

@@ -262,14 +262,24 @@ __global__ __launch_bounds__(QD_THREADS) void qkv_dw_kernel(qd_args a) {
 
 }  // namespace
 
+static int qd_cu_count() {                      // one process drives one GPU: queried once
+  static int cus = 0;
+  if (cus == 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 0;
+    cus = prop.multiProcessorCount;
+  }
+  return cus;
+}
+
 // Number of per-image slots the fused Gram pass needs for these shapes on this device (>= 1).
 extern "C" int cdfo_qkv_dw_gram_slots(int B, int H, int W) {
   if (B <= 0 || H <= 0 || W <= 0) return CDFO_EINVAL;
-  int dev = 0;
-  hipDeviceProp_t prop;
-  if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return CDFO_EINVAL;
+  const int cus = qd_cu_count();
+  if (cus <= 0) return CDFO_EINVAL;
   const long long tpi = (long long)cdiv(H, QD_TR) * cdiv(W, QD_TC), ntiles = tpi * B;
-  const long long grid = ntiles < prop.multiProcessorCount ? ntiles : prop.multiProcessorCount;
+  const long long grid = ntiles < cus ? ntiles : cus;
   const long long per = (ntiles + grid - 1) / grid;
   return (int)((tpi + per - 1) / per + 1);
 }
@@ -281,17 +291,14 @@ extern "C" int cdfo_qkv_dw(const float* x, int ldx, int B, int H, int W, const v
   if (!aligned16(x) || !aligned16(w_bf16) || !aligned16(out) || !dw_w) return CDFO_EALIGN;
   hipStream_t st = static_cast<hipStream_t>(stream);
   static bool attr_set = false;
-  static int cus = 0;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(qkv_dw_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, QD_LDS);
     if (e != hipSuccess) return (int)e;
-    int dev = 0;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return CDFO_EINVAL;
-    cus = prop.multiProcessorCount;
     attr_set = true;
   }
+  const int cus = qd_cu_count();
+  if (cus <= 0) return CDFO_EINVAL;
   const long long ntiles = (long long)B * cdiv(H, QD_TR) * cdiv(W, QD_TC);
   const int grid = (int)(ntiles < cus ? ntiles : cus);
   qd_args a;

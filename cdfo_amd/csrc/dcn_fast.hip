@@ -165,15 +165,19 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
           const float h_im = hb + tabh[tt[i]] + oh[i], w_im = wb + tabw[tt[i]] + ow[i];
           if (live[i] && h_im > -1.f && w_im > -1.f && h_im < (float)a.H && w_im < (float)a.W) {
             const int c = c0 + cbb[i] * 4, d = c / Cdg, cin = c - d * Cdg;
-            const int hl = (int)floorf(h_im), wl = (int)floorf(w_im), hh_ = hl + 1, wh_ = wl + 1;
+            const int hl = (int)floorf(h_im), wl = (int)floorf(w_im);
             const float lh = h_im - (float)hl, lw = w_im - (float)wl, hh = 1.f - lh, hw = 1.f - lw;
             const float* g0 = gp_b + d * (a.H * a.W * Cdg) + cin;
-            const int o00 = (hl * a.W + wl) * Cdg, oy = a.W * Cdg;
-            if (hl >= 0 && wl >= 0) v[i][0] = *reinterpret_cast<const f32x4*>(g0 + o00);
-            if (hl >= 0 && wh_ <= a.W - 1) v[i][1] = *reinterpret_cast<const f32x4*>(g0 + o00 + Cdg);
-            if (hh_ <= a.H - 1 && wl >= 0) v[i][2] = *reinterpret_cast<const f32x4*>(g0 + o00 + oy);
-            if (hh_ <= a.H - 1 && wh_ <= a.W - 1) v[i][3] = *reinterpret_cast<const f32x4*>(g0 + o00 + oy + Cdg);
-            wgt[i][0] = hh * hw; wgt[i][1] = hh * lw; wgt[i][2] = lh * hw; wgt[i][3] = lh * lw;
+            // corners outside the image: the load is redirected to a clamped (valid) address and its weight set to 0 --
+            // four selects instead of four predicated 16-byte loads with zero-filled destinations
+            const bool r0 = hl >= 0, r1 = hl + 1 <= a.H - 1, q0c = wl >= 0, q1c = wl + 1 <= a.W - 1;
+            const int ya = r0 ? hl : 0, yb = r1 ? hl + 1 : a.H - 1, xa = q0c ? wl : 0, xb = q1c ? wl + 1 : a.W - 1;
+            v[i][0] = *reinterpret_cast<const f32x4*>(g0 + (ya * a.W + xa) * Cdg);
+            v[i][1] = *reinterpret_cast<const f32x4*>(g0 + (ya * a.W + xb) * Cdg);
+            v[i][2] = *reinterpret_cast<const f32x4*>(g0 + (yb * a.W + xa) * Cdg);
+            v[i][3] = *reinterpret_cast<const f32x4*>(g0 + (yb * a.W + xb) * Cdg);
+            wgt[i][0] = (r0 && q0c) ? hh * hw : 0.f; wgt[i][1] = (r0 && q1c) ? hh * lw : 0.f;
+            wgt[i][2] = (r1 && q0c) ? lh * hw : 0.f; wgt[i][3] = (r1 && q1c) ? lh * lw : 0.f;
           }
         }
         if (q0 + 8 * NB < NI) load_batch(q0 + 8 * NB);             // in flight behind this batch's gathers
@@ -181,16 +185,20 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         for (int i = 0; i < NB; ++i) {
           const int q = q0 + 8 * i;
           if (q < NI) {
-            h4 vh, vl;
+            float val[4];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              const float val = (wgt[i][0] * v[i][0][e] + wgt[i][1] * v[i][1][e] + wgt[i][2] * v[i][2][e] +
-                                 wgt[i][3] * v[i][3][e]) * mm[i];
-              vh[e] = (_Float16)val;
-              vl[e] = (_Float16)(val - (float)vh[e]);
-            }
-            *reinterpret_cast<h4*>(col_hi + px * ROWB + q * 8) = vh;
-            *reinterpret_cast<h4*>(col_lo + px * ROWB + q * 8) = vl;
+            for (int e = 0; e < 4; ++e)
+              val[e] = (wgt[i][0] * v[i][0][e] + wgt[i][1] * v[i][1][e] + wgt[i][2] * v[i][2][e] + wgt[i][3] * v[i][3][e]) * mm[i];
+            // fp16 hi + lo with the packed round-toward-zero conversion (hi truncated, lo = the exact remainder truncated:
+            // hi + lo still carries 22 bits)
+            typedef __fp16 hp2 __attribute__((ext_vector_type(2)));
+            union { hp2 h[2]; h4 v4; } uh, ul;
+            uh.h[0] = __builtin_amdgcn_cvt_pkrtz(val[0], val[1]);
+            uh.h[1] = __builtin_amdgcn_cvt_pkrtz(val[2], val[3]);
+            ul.h[0] = __builtin_amdgcn_cvt_pkrtz(val[0] - (float)uh.h[0][0], val[1] - (float)uh.h[0][1]);
+            ul.h[1] = __builtin_amdgcn_cvt_pkrtz(val[2] - (float)uh.h[1][0], val[3] - (float)uh.h[1][1]);
+            *reinterpret_cast<h4*>(col_hi + px * ROWB + q * 8) = uh.v4;
+            *reinterpret_cast<h4*>(col_lo + px * ROWB + q * 8) = ul.v4;
           }
         }
       }

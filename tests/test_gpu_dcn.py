@@ -257,3 +257,68 @@ def test_dcn_non_finite_offsets_sample_nothing():
     _close(gw_.grad.cpu().numpy(), want["grad_weight"])
     _close(gm.grad.cpu().numpy(), want["grad_mask"])
     _close(goff.grad.cpu().numpy(), want["grad_offset"])
+
+
+def test_dcn_random_shapes_forward_and_backward_through_the_cabi():
+    """Forty seeded random operator configurations (rectangular kernels, anisotropic stride / padding / dilation, conv groups,
+    1-64 channels per deformable group, ragged tiles) through the C-ABI -- every forward variant (no workspace, group-planar
+    workspace, full workspace) and the backward -- against the C oracle."""
+    import ctypes as C
+    from cdfo_amd import _lib
+    from oracle.dcn_modules_ref import dcn_backward_ref
+    lib = _lib.lib()
+    rs = np.random.RandomState(20260)
+    p = lambda v: C.c_void_p(None if v is None else v.data_ptr())  # noqa: E731
+    t = lambda a: None if a is None else torch.from_numpy(np.ascontiguousarray(a)).cuda()  # noqa: E731
+    done = fast = 0
+    while done < 40:
+        g = int(rs.choice([1, 1, 1, 2, 4]))
+        dg = int(rs.choice([1, 2, 4, 8, 16]))
+        cpd = int(rs.choice([1, 2, 4, 4, 4, 8]))                    # channels per deformable group
+        Cc = dg * cpd
+        Co = g * int(rs.choice([1, 3, 8, 16, 32, 64]))
+        if Cc % g or Cc > 128:
+            continue
+        kh, kw = int(rs.choice([1, 2, 3])), int(rs.choice([1, 2, 3, 5]))
+        sh, sw = int(rs.choice([1, 1, 2])), int(rs.choice([1, 1, 2, 3]))
+        ph, pw = int(rs.randint(0, 3)), int(rs.randint(0, 3))
+        dh, dw = int(rs.choice([1, 1, 2])), int(rs.choice([1, 1, 2]))
+        B, H, W = int(rs.randint(1, 3)), int(rs.randint(5, 30)), int(rs.randint(5, 40))
+        Ho = (H + 2 * ph - (dh * (kh - 1) + 1)) // sh + 1
+        Wo = (W + 2 * pw - (dw * (kw - 1) + 1)) // sw + 1
+        if Ho <= 0 or Wo <= 0:
+            continue
+        mod = bool(rs.randint(0, 2))
+        x = rs.standard_normal((B, Cc, H, W)).astype(np.float32)
+        w = (rs.standard_normal((Co, Cc // g, kh, kw)) / np.sqrt(Cc // g * kh * kw)).astype(np.float32)
+        b = rs.standard_normal((Co,)).astype(np.float32) if mod else None
+        off = (rs.standard_normal((B, 2 * dg * kh * kw, Ho, Wo)) * 2.5).astype(np.float32)
+        msk = rs.uniform(0, 1, (B, dg * kh * kw, Ho, Wo)).astype(np.float32) if mod else None
+        go = rs.standard_normal((B, Co, Ho, Wo)).astype(np.float32)
+        cfg = (B, Cc, Co, H, W, kh, kw, sh, sw, ph, pw, dh, dw, g, dg, mod)
+        ref = dcn_forward_ref(x, off, msk, w, b, (sh, sw), (ph, pw), (dh, dw), g, dg)
+        tx, toff, tm, tw, tb, tgo = t(x), t(off), t(msk), t(w), t(b), t(go)
+        need = int(lib.cdfo_dcn_workspace_bytes(B, Cc, H, W, Co, kh, kw, g, dg))
+        fast += need > 0
+        for nbytes in sorted({0, x.size * 4, max(need, x.size * 4)}):
+            ws = torch.empty(nbytes, dtype=torch.uint8, device="cuda") if nbytes else None
+            out = torch.full((B, Co, Ho, Wo), float("nan"), device="cuda")
+            _lib.check(lib.cdfo_dcn_forward(p(tx), p(toff), p(tm), p(tw), p(tb), p(out), B, Cc, H, W, Co, kh, kw, sh, sw, ph, pw,
+                                            dh, dw, g, dg, p(ws), C.c_longlong(nbytes), None), "cdfo_dcn_forward")
+            torch.cuda.synchronize()
+            err = np.abs(out.cpu().numpy() - ref).max()
+            assert err <= 2e-5 * max(1.0, np.abs(ref).max()), (cfg, nbytes, err)
+        want = dcn_backward_ref(x, off, msk, w, go, (sh, sw), (ph, pw), (dh, dw), g, dg, with_bias=mod)
+        gi, goff, gw = torch.zeros_like(tx), torch.full_like(toff, 7.0), torch.zeros_like(tw)
+        gm = torch.full_like(tm, 7.0) if mod else None
+        gb = torch.zeros(Co, device="cuda") if mod else None
+        _lib.check(lib.cdfo_dcn_backward(p(tx), p(toff), p(tm), p(tw), p(tgo), p(gi), p(goff), p(gm), p(gw), p(gb), B, Cc, H, W, Co,
+                                         kh, kw, sh, sw, ph, pw, dh, dw, g, dg, C.c_float(1.0), None), "cdfo_dcn_backward")
+        torch.cuda.synchronize()
+        for got, key in ((gi, "grad_input"), (goff, "grad_offset"), (gw, "grad_weight"), (gm, "grad_mask"), (gb, "grad_bias")):
+            if got is not None:
+                ref_g = want[key]
+                e = np.abs(got.cpu().numpy() - ref_g).max()
+                assert e <= 5e-5 * max(1.0, np.abs(ref_g).max()), (cfg, key, e)
+        done += 1
+    assert fast >= 3          # the sweep reaches the fast forward kernel too

@@ -18,6 +18,7 @@ fp16 hi+lo activations, two MFMA passes, in the 3x3 convolutions of the alignmen
 trunk's body convolutions on CVSR_V8's single-pass fp16 ``Block_`` kernels; the feature extractor stays split-bf16)."""
 from __future__ import annotations
 
+import contextlib
 import math
 from typing import Dict, List, Optional, Sequence
 
@@ -94,6 +95,7 @@ class CVSR_V7(nn.Module):
         self.nf, self.center, self.istraining, self.stride = nf, nframes // 2, istraining, 4
         self.gumbel_uniform: Optional[Sequence[torch.Tensor]] = None
         self.precision = "bf16x3"
+        self.neighbour_streams = 3       # HIP side streams for the twelve independent neighbour pipelines of a pyramid level
         for key, shape, fan_in, init in _param_spec():
             if init == "module":
                 self.MV_deform_align = MVDualAttAlignment(64, 64, 3, padding=1, deformable_groups=16,
@@ -279,6 +281,14 @@ class CVSR_V7(nn.Module):
         align.precision = self.precision
         dev = x.device
         draw = 0
+        nstr = int(getattr(self, "neighbour_streams", 0))
+        main = torch.cuda.current_stream(dev)
+        side = []
+        if nstr > 1:
+            cache = self.__dict__.setdefault("_side_streams", {})
+            side = cache.get((dev, nstr))
+            if side is None:
+                side = cache[(dev, nstr)] = [torch.cuda.Stream(dev) for _ in range(nstr)]
         prev = None
         fused_pyr: List[torch.Tensor] = []
         # 3. per level, coarse to fine (arch.py:4275-4347)
@@ -287,8 +297,7 @@ class CVSR_V7(nn.Module):
             Lf = (K.swap_outer(pyr[lv], B, N) if B > 1 else pyr[lv]).view(N, B, h, wd, NF)
             centre_nchw = K.nhwc_to_nchw(Lf[ctr])
 
-            def neighbour(i, mv_all):
-                nonlocal draw
+            def neighbour(i, mv_all, draw):
                 if lv == 0:
                     mv = mv_all[:, i].contiguous()
                     u_img, r_img = ufs[:, :, i], rms[:, :, i]
@@ -306,19 +315,33 @@ class CVSR_V7(nn.Module):
                     u = torch.rand((B, NF, h, wd), device=dev, dtype=torch.float32).clamp_min_(1e-30)
                 else:
                     u = noise[draw].to(device=dev, dtype=torch.float32).contiguous()
-                draw += 1
                 x_n = self._rdab(w, rms_prior, fea_com, u)
                 fea_i = self._conv([Lf[i], x_n], w["conv_expand_fea_r"], pad=1)
                 out = K.nchw_to_nhwc(align.forward_pm(centre_nchw, Lf[ctr], fea_i, ufs_prior, mv))
                 return out
 
-            back = {i: neighbour(i, mvs[0]) for i in range(N - 1, -1, -1) if i != ctr}
+            # the twelve neighbour pipelines of a level (backward pass i = 6..0 with mvs0, forward pass i = 0..6 with mvs1)
+            # only read the level's features, the previous level's result and the priors: they are issued round-robin on
+            # side streams and joined before fb_fusion.  The noise draw index keeps the reference's call order.
+            jobs = [(0, i) for i in range(N - 1, -1, -1) if i != ctr] + [(1, i) for i in range(N) if i != ctr]
+            for st in side:
+                st.wait_stream(main)
+            res = {}
+            for n, (which, i) in enumerate(jobs):
+                ctx = torch.cuda.stream(side[n % len(side)]) if side else contextlib.nullcontext()
+                with ctx:
+                    res[(which, i)] = neighbour(i, mvs[which], draw + n)
+                if side:
+                    res[(which, i)].record_stream(main)
+            draw += len(jobs)
+            for st in side:
+                main.wait_stream(st)
             cur = torch.empty((N, B, h, wd, NF), dtype=torch.float32, device=dev)
             for i in range(N):
                 if i == ctr:
                     cur[i].copy_(Lf[ctr])
                 else:
-                    self._conv([back[i], neighbour(i, mvs[1])], w["fb_fusion"], out=cur[i])
+                    self._conv([res[(0, i)], res[(1, i)]], w["fb_fusion"], out=cur[i])
             prev = cur
             fused = self._conv([cur[i] for i in range(N)], w["tsa_fusion"], act=K.ACT_LRELU)
             if self.debug_taps is not None:

@@ -47,12 +47,14 @@ def main():
     ap.add_argument("--height", type=int, default=272)
     ap.add_argument("--width", type=int, default=480)
     ap.add_argument("--precision", default="bf16x3")
+    ap.add_argument("--streams", type=int, default=3, help="side streams for the neighbour pipelines (1 = single stream)")
     a = ap.parse_args()
     B, H, W = a.batch, a.height, a.width
     torch.manual_seed(0)
     m = CVSR_V7()                                   # random init of the reference architecture
     m = m.cuda().eval()
     m.precision = a.precision
+    m.neighbour_streams = a.streams
     inp = random_inputs(B, H, W, 1002, levels=(2, 1, 0))
     d = {k: v for k, v in inp.items() if k != "gumbel_u"}
     noise = inp["gumbel_u"]

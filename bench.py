@@ -197,6 +197,8 @@ def main():
             # the path's other operator row, outside the timed region: the fused DCNv2 forward at the
             # alignment module's shape against its HBM roofline (same definitions as tools/bench_dcn.py)
             res["dcn_forward"] = dcn_forward_line(dev, Hp, Wp, B)
+            # SURVEY section 8f n3, also outside the timed region: the DCN-aligned CVSR_V7 on the same synthetic clips
+            res["cvsr_v7"] = cvsr_v7_line(dev, d, Hp, Wp, B)
         print(json.dumps(res))
         if args.breakdown:
             with open(args.breakdown, "w") as f:
@@ -210,6 +212,29 @@ def main():
                             f"{fl[k]/ms[k]/1e9:.2f} {by[k]/ms[k]/1e6:.1f}\n")
     if world > 1:
         dist.destroy_process_group()
+
+
+def cvsr_v7_line(device, d, H, W, B, steps=2):
+    from arch.SIDECVSR_our import CVSR_V7
+    torch.manual_seed(0)
+    m = CVSR_V7().to(device).eval()                      # random init of the reference architecture
+    g = torch.Generator(device=device).manual_seed(7)
+    noise = [torch.rand(B, 64, H >> lv, W >> lv, device=device, generator=g).clamp_min_(1e-6) for lv in (2, 1, 0) for _ in range(12)]
+    out = {}
+    for prec in ("bf16x3", "fp16x2"):
+        m.precision = prec
+        with torch.no_grad():
+            m(d["x"], -d["mvs1"], d["mvs1"], d["pms"], d["rms"], d["ufs"], gumbel_uniform=noise)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                m(d["x"], -d["mvs1"], d["mvs1"], d["pms"], d["rms"], d["ufs"], gumbel_uniform=noise)
+            torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) / steps * 1e3
+        out[prec] = {"ms_per_forward": round(ms, 2), "frames_per_s": round(B / ms * 1e3, 2)}
+    del m
+    torch.cuda.empty_cache()
+    return {"workload": f"CVSR_V7 forward, {B} clips x 7x1x{H}x{W}, fresh path, random init", **out}
 
 
 def dcn_forward_line(device, H, W, B, iters=10):

@@ -82,6 +82,8 @@ def main():
     model.neighbour_streams = args.neighbour_streams
 
     # ---- parity spot-check against the CPU oracle on the reference's own CPU-runnable config (c1: 64x64, B=1)
+    if world > 1:                                          # N ranks share the host's cores for this CPU-side check
+        torch.set_num_threads(max(1, (os.cpu_count() or world) // world))
     max_abs, psnr = float("nan"), float("nan")
     if not args.no_parity:
         c1 = make_inputs(1, 64, 64, 1000)

@@ -63,11 +63,19 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    # CDFO_BENCH_BACKEND=gloo rehearses the N > 1 control flow on a box with fewer GPUs than ranks (ranks then share GPUs and
+    # the one all_gather goes over gloo on the CPU); the measured configuration is "nccl" = RCCL over xGMI, one GPU per rank
+    backend = os.environ.get("CDFO_BENCH_BACKEND", "nccl")
+    if backend == "gloo":
+        local %= max(1, torch.cuda.device_count())
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     from arch.SIDECVSR_our import CVSR_V8
     from cdfo_amd import _lib
@@ -139,7 +147,8 @@ def main():
 
     # ---- the single collective: all_gather of per-rank metrics (time, checksum, parity)
     from cdfo_amd.dist import gather_metrics
-    allm = gather_metrics([elapsed, out.double().mean().item(), max_abs, psnr if psnr != float("inf") else 999.0], dev)
+    allm = gather_metrics([elapsed, out.double().mean().item(), max_abs, psnr if psnr != float("inf") else 999.0],
+                          dev if backend == "nccl" else None)
     t_max = allm[:, 0].max().item()
 
     if rank == 0:

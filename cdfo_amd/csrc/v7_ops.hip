@@ -34,31 +34,47 @@ __global__ __launch_bounds__(256) void chan_pool_kernel(const float* __restrict_
 }
 
 __device__ __forceinline__ float pooled_conv(const float* __restrict__ pooled, const float* __restrict__ w, int H, int W,
-                                             int y, int x, int ks, int first, int step) {
-  // sum over taps t = first, first+step, ... of the [2][ks][ks] kernel, zero padding (ks-1)/2
-  const int r = (ks - 1) / 2, T = ks * ks;
+                                             int y, int x, int ks) {
+  // [2][ks][ks] kernel over the (max, mean) map, zero padding (ks-1)/2; nested loops: no per-tap integer division
+  const int r = (ks - 1) / 2;
   float s = 0.f;
-  for (int t = first; t < 2 * T; t += step) {
-    const int c = t / T, k = t - c * T, dy = k / ks - r, dx = k - (k / ks) * ks - r;
-    const int yy = y + dy, xx = x + dx;
-    if (yy >= 0 && yy < H && xx >= 0 && xx < W) s = fmaf(w[t], pooled[((long long)yy * W + xx) * 2 + c], s);
+  for (int dy = 0; dy < ks; ++dy) {
+    const int yy = y + dy - r;
+    if (yy < 0 || yy >= H) continue;
+    const float* row = pooled + (long long)yy * W * 2;
+    const float* w0 = w + dy * ks;
+    const float* w1 = w + ks * ks + dy * ks;
+    for (int dx = 0; dx < ks; ++dx) {
+      const int xx = x + dx - r;
+      if (xx >= 0 && xx < W) {
+        const float2 pv = *reinterpret_cast<const float2*>(row + xx * 2);
+        s = fmaf(w0[dx], pv.x, fmaf(w1[dx], pv.y, s));
+      }
+    }
   }
   return s;
 }
 
-__global__ __launch_bounds__(256) void spatial_gate_kernel(const float* __restrict__ x, int ld, const float* __restrict__ pooled,
-                                                           const float* __restrict__ w, const float* __restrict__ bias, int B,
-                                                           int H, int W, int ks, float* __restrict__ out, int ldo) {
-  const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
-  const long long p = gid >> 4, npix = (long long)B * H * W;
-  const int l = (int)(gid & 15);
+// gate[p] = sigmoid(conv_ksxks(pooled)[p] + bias): one thread per pixel (2 * ks * ks taps from the L2-resident pooled map)
+__global__ __launch_bounds__(256) void gate_map_kernel(const float* __restrict__ pooled, const float* __restrict__ w,
+                                                       const float* __restrict__ bias, int B, int H, int W, int ks,
+                                                       float* __restrict__ gate) {
+  const long long p = (long long)blockIdx.x * 256 + threadIdx.x, npix = (long long)B * H * W;
   if (p >= npix) return;
   const int b = (int)(p / ((long long)H * W));
-  const int rem = (int)(p - (long long)b * H * W), y = rem / W, xx = rem - y * W;
-  float s = pooled_conv(pooled + (long long)b * H * W * 2, w, H, W, y, xx, ks, l, 16);   // taps split over the 16 lanes
-#pragma unroll
-  for (int o = 8; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
-  const float g = 1.f / (1.f + __expf(-(s + bias[0])));
+  const int rem = (int)(p - (long long)b * H * W), y = rem / W, x = rem - y * W;
+  const float s = pooled_conv(pooled + (long long)b * H * W * 2, w, H, W, y, x, ks);
+  gate[p] = 1.f / (1.f + __expf(-(s + bias[0])));
+}
+
+// out = x * gate[pixel]: 16 lanes per pixel, one float4 each -- a pure HBM stream
+__global__ __launch_bounds__(256) void spatial_gate_kernel(const float* __restrict__ x, int ld, const float* __restrict__ gate,
+                                                           long long npix, float* __restrict__ out, int ldo) {
+  const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
+  const long long p = gid >> 4;
+  const int l = (int)(gid & 15);
+  if (p >= npix) return;
+  const float g = gate[p];
   f32x4 v = *reinterpret_cast<const f32x4*>(x + p * ld + l * 4);
   v[0] *= g; v[1] *= g; v[2] *= g; v[3] *= g;
   *reinterpret_cast<f32x4*>(out + p * ldo + l * 4) = v;
@@ -91,7 +107,7 @@ __global__ __launch_bounds__(128) void rdab_mix_kernel(const float* __restrict__
       sum += e;
     }
     const int y = p / W, x = p - y * W;
-    const float s = pooled_conv(pooled + (long long)b * P * 2, w3, H, W, y, x, 3, 0, 1);
+    const float s = pooled_conv(pooled + (long long)b * P * 2, w3, H, W, y, x, 3);
     add_s[wave][lane] = 1.f / (1.f + __expf(-(s + b3[0])));
     inv_s[wave][lane] = 1.f / sum;
   }
@@ -154,15 +170,17 @@ extern "C" int cdfo_chan_pool(const float* x, int ld, long long npix, int C, flo
 }
 
 extern "C" int cdfo_spatial_gate(const float* x, int ld, const float* pooled, const float* w, const float* bias, int B, int H,
-                                 int W, int C, int ks, float* out, int ldo, void* stream) {
-  if (C != 64 || B <= 0 || H <= 0 || W <= 0 || ks < 1 || !(ks & 1) || ld < 64 || ldo < 64 || ld % 4 || ldo % 4)
+                                 int W, int C, int ks, float* gate_scratch, float* out, int ldo, void* stream) {
+  if (C != 64 || B <= 0 || H <= 0 || W <= 0 || ks < 1 || !(ks & 1) || ld < 64 || ldo < 64 || ld % 4 || ldo % 4 || !gate_scratch)
     return CDFO_EINVAL;
   if (!aligned16(x) || !aligned16(out)) return CDFO_EALIGN;
   hipStream_t st = static_cast<hipStream_t>(stream);
   const long long npix = (long long)B * H * W;
-  CdfoProfScope prof(st, KID_SPATIAL_GATE, 2.0 * npix * 2 * ks * ks, 4.0 * npix * 130.0);
-  hipLaunchKernelGGL(spatial_gate_kernel, dim3((unsigned)((npix * 16 + 255) / 256)), dim3(256), 0, st, x, ld, pooled, w, bias,
-                     B, H, W, ks, out, ldo);
+  CdfoProfScope prof(st, KID_SPATIAL_GATE, 2.0 * npix * 2 * ks * ks, 4.0 * npix * 132.0);
+  hipLaunchKernelGGL(gate_map_kernel, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, st, pooled, w, bias, B, H, W, ks,
+                     gate_scratch);
+  hipLaunchKernelGGL(spatial_gate_kernel, dim3((unsigned)((npix * 16 + 255) / 256)), dim3(256), 0, st, x, ld, gate_scratch, npix,
+                     out, ldo);
   CDFO_LAUNCH_CHECK();
   return 0;
 }

@@ -567,8 +567,9 @@ def spatial_gate(x: torch.Tensor, w: torch.Tensor, bias: torch.Tensor) -> torch.
     """SpatialAttention: x * sigmoid(conv(pool(x))); w: the [1,2,ks,ks] weight."""
     B, H, W, Cc, ld = _chk_act(x)
     out = empty_act(B, H, W, Cc, x.device)
+    gate = torch.empty((B, H, W), dtype=torch.float32, device=x.device)
     check(_lib.lib().cdfo_spatial_gate(_vp(x), ld, _vp(chan_pool(x)), _vp(w), _vp(bias), B, H, W, Cc, int(w.shape[-1]),
-                                       _vp(out), Cc, _stream()), "cdfo_spatial_gate")
+                                       _vp(gate), _vp(out), Cc, _stream()), "cdfo_spatial_gate")
     return out
 
 

@@ -248,7 +248,8 @@ int cdfo_dcn_backward(const float* in, const float* offset, const float* mask, c
  * fp32 pixel-major activations [B,H,W,64] with pitch ld (floats).
  * cdfo_chan_pool:     ChannelPool (arch/SIDECVSR_our.py:1883-1885): out[p] = {max_c x[p][c], mean_c x[p][c]}.
  * cdfo_spatial_gate:  SpatialAttention (arch.py:2719-2730): out = x * sigmoid(conv_ksxks(pooled) + bias), zero padding
- *                     (ks-1)/2, w = the module's [1,2,ks,ks] weight.
+ *                     (ks-1)/2, w = the module's [1,2,ks,ks] weight; gate_scratch: B*H*W floats (the gate map, written
+ *                     by a one-thread-per-pixel pass, then applied by a pure streaming pass).
  * cdfo_rdab_mix:      RDAB.forward's mixing step (arch.py:2836-2845): out = xf * (softmax_c(vmax[b][c] - log(-log(u)))
  *                     + sigmoid(conv3x3(pooled) + b3)); vmax [B,64]; noise u in the reference's NCHW order [B,64,H,W].
  * cdfo_shrink_planes: F.interpolate(scale_factor = 0.5 (level 1) or 0.25 (level 2), bilinear, align_corners=False) of
@@ -257,7 +258,7 @@ int cdfo_dcn_backward(const float* in, const float* offset, const float* mask, c
  * cdfo_lincomb:       out = ca*a + cb*b + cc*c over n floats (b, c may be NULL; out may alias an input). */
 int cdfo_chan_pool(const float* x, int ld, long long npix, int C, float* out, void* stream);
 int cdfo_spatial_gate(const float* x, int ld, const float* pooled, const float* w, const float* bias, int B, int H, int W,
-                      int C, int ks, float* out, int ldo, void* stream);
+                      int C, int ks, float* gate_scratch, float* out, int ldo, void* stream);
 int cdfo_rdab_mix(const float* xf, int ld, const float* pooled, const float* w3, const float* b3, const float* vmax,
                   const float* noise, int B, int H, int W, float* out, int ldo, void* stream);
 int cdfo_shrink_planes(const float* src, long long src_bstride, int planes, int B, int H, int W, int level, float* dst,

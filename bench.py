@@ -5,16 +5,26 @@
 
 A "step" is one forward of the hot path over one batch of clips already resident in HBM: 8 clips per GPU of
 7 x 1 x 272 x 480 luma (270 rows zero-padded to 272) + MV / residual / partition / unfiltered priors ->
-8 HR frames of 1088 x 1920 (crop to 1080).  For N > 1 the driver starts one process per GPU (torchrun); clips are
-sharded by batch (weak scaling: 8 clips per GPU), there is no data-path collective, and ONE all_gather over RCCL
-carries the per-rank metrics.  Rank 0 prints one JSON line.
+8 HR frames of 1088 x 1920 (crop to 1080).  For N > 1 there is one process per GPU (the driver starts them with torchrun;
+a bare `python bench.py --gpus N` starts them itself, see `launch_ranks`); clips are sharded by batch (weak scaling:
+8 clips per GPU), there is no data-path collective, and ONE all_gather over RCCL carries the per-rank metrics.
+Rank 0 prints one JSON line.
+
+What is timed (`value`): K forwards of the DEFAULT path -- Gumbel noise drawn per call like the reference does
+(arch/SIDECVSR_our.py:2169), here inside the mask kernel -- with no per-launch instrumentation.  The per-kernel roofline
+numbers come from a second pass over the same K steps with one HIP-event pair per launch.  Parity (gated: the run fails
+above the 1e-3 bound) is checked on clip 0 of the timed batch against the CPU oracle, replaying the noise that forward
+drew; the same oracle run is the `cpu_baseline`.
 """
 from __future__ import annotations
 
 import argparse
 import ctypes as C
 import json
+import math
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -42,7 +52,28 @@ def flops_per_clip(H, W):
     return EXACT_FLOPS.get((H, W), H * W * (73.55e6 + 1536.0 * (W + H)))
 
 
-def main():
+PARITY_BOUND = 1e-3      # north_star: max-abs vs the fp32 reference path
+
+
+def launch_command(n: int, argv, port: int):
+    """The torchrun command line that starts the N ranks of this script (one process per GPU, rendezvous on 127.0.0.1)."""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+            "--master-port", str(port), os.path.abspath(__file__), *argv]
+
+
+def launch_ranks(n: int, argv) -> int:
+    """`python bench.py --gpus N` without torchrun: start the N ranks as children BEFORE this process touches the GPU
+    (a process that has initialised the GPU must never exec or fork GPU work), relay their output (rank 0 prints the JSON
+    line) and return their exit status."""
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.run(launch_command(n, argv, port), env=env).returncode
+
+
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
@@ -56,13 +87,25 @@ def main():
     ap.add_argument("--streaming", action="store_true", help="time the cached-feature path (pre_L1_fea given: one new frame per clip, test_LD_22_FPS.py:183-189) instead of the fresh path")
     ap.add_argument("--neighbour-streams", type=int, default=0, help="issue the six neighbour-frame pipelines on this many HIP streams (0 = the model's choice: 3 at 8 clips)")
     ap.add_argument("--breakdown", type=str, default="", help="write the per-kernel-family event timings to this file")
-    args = ap.parse_args()
+    ap.add_argument("--injected-noise", action="store_true", help="time the forward with pre-made Gumbel noise tensors (the parity tests' path) instead of the default in-kernel draws")
+    ap.add_argument("--no-extra-modes", action="store_true", help="skip the extra measurements (bf16x3 mode, injected-noise path, DCN / V7 lines)")
+    return ap.parse_args(argv)
+
+
+def main():
+    args = parse_args()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # not under torchrun: become the launcher.  Nothing above has initialised the GPU in this process.
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: start one rank per GPU (torchrun --nproc-per-node "
+                         f"{args.gpus}), or run `python bench.py --gpus {args.gpus}` outside torchrun and let it start them")
     # CDFO_BENCH_BACKEND=gloo rehearses the N > 1 control flow on a box with fewer GPUs than ranks (ranks then share GPUs and
     # the one all_gather goes over gloo on the CPU); the measured configuration is "nccl" = RCCL over xGMI, one GPU per rank
     backend = os.environ.get("CDFO_BENCH_BACKEND", "nccl")
@@ -89,19 +132,8 @@ def main():
     model.precision = args.precision
     model.neighbour_streams = args.neighbour_streams
 
-    # ---- parity spot-check against the CPU oracle on the reference's own CPU-runnable config (c1: 64x64, B=1)
-    if world > 1:                                          # N ranks share the host's cores for this CPU-side check
+    if world > 1:                                          # N ranks share the host's cores for CPU-side checks
         torch.set_num_threads(max(1, (os.cpu_count() or world) // world))
-    max_abs, psnr = float("nan"), float("nan")
-    if not args.no_parity:
-        c1 = make_inputs(1, 64, 64, 1000)
-        with torch.no_grad():
-            ref_out, _ = cvsr_v8_forward(sd, c1["x"], None, c1["mvs1"], c1["pms"], c1["rms"], c1["ufs"], None,
-                                         c1["gumbel_u"])
-            got, _ = model(c1["x"].to(dev), None, c1["mvs1"].to(dev), c1["pms"].to(dev), c1["rms"].to(dev),
-                           c1["ufs"].to(dev), gumbel_uniform=[u.to(dev) for u in c1["gumbel_u"]])
-        max_abs = (got.cpu() - ref_out).abs().max().item()
-        psnr = psnr_y(got.cpu(), ref_out)
 
     # ---- workload: B clips, H padded to a multiple of 8 (test_LD_37.py:24-26 semantics)
     B = args.batch
@@ -109,34 +141,70 @@ def main():
     Wp = (args.width + 7) // 8 * 8
     inp = make_inputs(B, Hp, Wp, 1002 + rank, pad_rows=Hp - args.height)
     d = {k: v.to(dev) for k, v in inp.items() if k != "gumbel_u"}
-    noise = [u.to(dev) for u in inp["gumbel_u"]]
+    injected = [u.to(dev) for u in inp["gumbel_u"]] if args.injected_noise else None
 
     pre = None
     if args.streaming:
         with torch.no_grad():
-            _, pre = model(d["x"], d["mvs0"], d["mvs1"], d["pms"], d["rms"], d["ufs"], gumbel_uniform=noise)
+            _, pre = model(d["x"], d["mvs0"], d["mvs1"], d["pms"], d["rms"], d["ufs"], gumbel_uniform=injected)
 
-    def step():
+    def step(noise=injected):
         with torch.no_grad():
             return model(d["x"], d["mvs0"], d["mvs1"], d["pms"], d["rms"], d["ufs"], pre, gumbel_uniform=noise)
-
-    for _ in range(args.warmup):
-        step()
-    nk = lib.cdfo_prof_kid_count()
-    _lib.check(lib.cdfo_prof_begin(2000 * max(1, args.steps)), "cdfo_prof_begin")
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out, _ = step()
-    barrier()
-    elapsed = time.perf_counter() - t0
+    def timed(nsteps, noise=injected):
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(nsteps):
+            o, _ = step(noise)
+        barrier()
+        return time.perf_counter() - t0, o
 
+    # ---- parity against the CPU oracle, on the path that is timed.  N = 1: clip 0 of the timed batch at the timed size
+    # (the oracle forward on one 272x480 clip is also the cpu_baseline measurement); N > 1: every rank checks the
+    # reference's own CPU-runnable config (c1: 64x64, B=1) -- N oracle forwards at full size would share one host.
+    max_abs, psnr, cpu = float("nan"), float("nan"), None
+    parity_cfg = "skipped (--no-parity)"
+    if not args.no_parity:
+        if world == 1 and not args.streaming:
+            cap = []
+            model.capture_noise = None if args.injected_noise else cap
+            got, _ = step()
+            model.capture_noise = None
+            noise0 = [u[0:1].cpu() for u in (injected if args.injected_noise else cap)]
+            clip0 = {k: (v[0:1].cpu() if v is not None else None) for k, v in d.items()}
+            ref_out, cpu = oracle_clip(sd, clip0, noise0, Hp, Wp, time_it=not args.no_cpu_baseline)
+            g0 = got[0:1].cpu()
+            parity_cfg = f"clip 0 of the timed batch ({Hp}x{Wp}, noise as drawn by the timed path) vs CPU oracle"
+        else:
+            c1 = make_inputs(1, 64, 64, 1000)
+            cap = []
+            model.capture_noise = cap
+            with torch.no_grad():
+                g0, _ = model(c1["x"].to(dev), None, c1["mvs1"].to(dev), c1["pms"].to(dev), c1["rms"].to(dev), c1["ufs"].to(dev))
+                model.capture_noise = None
+                ref_out, _ = cvsr_v8_forward(sd, c1["x"], None, c1["mvs1"], c1["pms"], c1["rms"], c1["ufs"], None,
+                                             [u.cpu() for u in cap])
+            g0 = g0.cpu()
+            parity_cfg = "c1 64x64 B=1 (noise as drawn by the default path) vs CPU oracle, on every rank"
+        max_abs = (g0 - ref_out).abs().max().item()
+        psnr = psnr_y(g0, ref_out)
+
+    for _ in range(args.warmup):
+        step()
+    elapsed, out = timed(args.steps)                      # the headline: no per-launch instrumentation
+    range_info = getattr(model, "last_range", None)
+
+    # ---- second pass over the same steps with one HIP-event pair per launch: per-kernel durations for the roofline
+    nk = lib.cdfo_prof_kid_count()
+    cap_records = 4000 * max(1, args.steps)
+    _lib.check(lib.cdfo_prof_begin(cap_records), "cdfo_prof_begin")
+    elapsed_prof, _ = timed(args.steps)
     launches = (C.c_int * nk)()
     ms = (C.c_double * nk)()
     fl = (C.c_double * nk)()
@@ -144,12 +212,34 @@ def main():
     nrec = lib.cdfo_prof_end(launches, ms, fl, by, nk)
     if nrec < 0:
         raise SystemExit(f"cdfo_prof_end failed: {nrec}")
+    if nrec >= cap_records:
+        raise SystemExit(f"the event profiler ran out of records ({nrec} >= {cap_records}): per-kernel numbers would be truncated")
+
+    # ---- extra measurements (N = 1 only, outside the headline): the fp32-grade mode and the injected-noise path
+    extra = {}
+    if world == 1 and not args.no_extra_modes and not args.streaming:
+        nst = max(2, min(args.steps, 5))
+        other_noise = None if args.injected_noise else [u.to(dev) for u in inp["gumbel_u"]]
+        step(other_noise)
+        t, _ = timed(nst, other_noise)
+        extra["injected_noise_path" if not args.injected_noise else "default_noise_path"] = {
+            "frames_per_s": round(B * nst / t, 3), "ms_per_step": round(1e3 * t / nst, 3), "steps": nst}
+        del other_noise
+        if args.precision != "bf16x3":
+            model.precision = "bf16x3"
+            step()
+            t, _ = timed(nst)
+            extra["bf16x3_fp32_grade"] = {"frames_per_s": round(B * nst / t, 3), "ms_per_step": round(1e3 * t / nst, 3),
+                                          "steps": nst, "note": "split-bf16 3-pass MFMA everywhere: <= 1.2e-5 max-abs vs the fp32 reference"}
+            model.precision = args.precision
 
     # ---- the single collective: all_gather of per-rank metrics (time, checksum, parity)
     from cdfo_amd.dist import gather_metrics
-    allm = gather_metrics([elapsed, out.double().mean().item(), max_abs, psnr if psnr != float("inf") else 999.0],
-                          dev if backend == "nccl" else None)
+    allm = gather_metrics([elapsed, out.double().mean().item(), max_abs, psnr if math.isfinite(psnr) or psnr != psnr else 999.0,
+                           elapsed_prof], dev if backend == "nccl" else None)
     t_max = allm[:, 0].max().item()
+    # parity gate: a numerically broken build must not print a valid-looking line
+    parity_ok = args.no_parity or all(math.isfinite(v) and v <= PARITY_BOUND for v in allm[:, 2].tolist())
 
     if rank == 0:
         clips_total = B * world * args.steps
@@ -174,21 +264,23 @@ def main():
                     "launches_per_step": launches[k] // max(1, args.steps), "avg_launch_ms": round(avg_ms, 4),
                     "share_of_gpu_time": round(ms[k] / max(1e-9, sum(ms)), 4)}
         traffic = None
-        tpath = os.path.join(ROOT, "profiles", "traffic_r01.json")
-        if os.path.exists(tpath):            # HBM bytes per launch from rocprofv3 PMC passes (tools/collect_traffic.py)
+        tpath = next((q for q in (os.path.join(ROOT, "profiles", f"traffic_r{r:02d}.json") for r in (2, 1)) if os.path.exists(q)), "")
+        if tpath:                            # HBM bytes per launch from rocprofv3 PMC passes (tools/collect_traffic.py)
             try:
                 tj = json.load(open(tpath))
                 if tj.get("kernel") == KID_NAMES[dom] and tj.get("precision") == args.precision:
                     traffic = tj.get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
+        wf = F * B * args.steps / t_max / 1e12
         roofline = {"bound": "mfma", **fam(dom), "traffic": traffic,
-                    "whole_forward_tflops": round(F * B * args.steps / t_max / 1e12, 2),
+                    "whole_forward_tflops": round(wf, 2), "whole_forward_frac": round(wf / PEAK_TFLOPS[args.precision], 4),
+                    "measured_in": f"second pass over the same {args.steps} steps with one HIP-event pair per launch on the launch "
+                                   f"stream ({round(1e3 * allm[:, 4].max().item() / args.steps, 3)} ms per step with the events)",
                     # the other matrix-core convolution kernels of the step, same definitions (not the headline entry)
                     "other_mfma_kernels": [fam(k) for k in range(nk) if KID_NAMES[k] in MFMA16 and k != dom and launches[k]]}
-        cpu = None
-        if not args.no_cpu_baseline and world == 1:      # reported on rank 0 at N = 1 only
-            cpu = cpu_baseline(sd, Hp, Wp)
+        if cpu is None and not args.no_cpu_baseline and world == 1:      # reported on rank 0 at N = 1 only
+            cpu = cpu_baseline_scaled(sd, Hp, Wp)       # (--no-parity / --streaming runs: bounded half-size sample)
         res = {
             "metric": "x4 SR frames/sec, 7-frame 270x480->1080p", "value": round(value, 4), "unit": "frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * t_max / args.steps, 3),
@@ -197,14 +289,16 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"JCT-VC ClassB-shape synthetic clips: {B} clips/GPU x 7x1x{args.height}x{args.width} "
                                    f"luma (padded to {Hp}x{Wp}) + MV/residual/partition/unfiltered priors -> "
-                                   f"{4 * args.height}x{4 * args.width}, " + ("streaming path (pre_L1_fea cache hit)" if args.streaming else "fresh path (pre_L1_fea=None)") + f", precision={args.precision}",
+                                   f"{4 * args.height}x{4 * args.width}, " + ("streaming path (pre_L1_fea cache hit)" if args.streaming else "fresh path (pre_L1_fea=None)") + f", precision={args.precision}, "
+                                   + ("pre-made Gumbel noise tensors" if args.injected_noise else "Gumbel noise drawn per forward inside the mask kernel (the reference's default behaviour)"),
                        "clips_per_gpu": B, "lr_padded": [Hp, Wp], "parallelism": f"batch-shard x{world}",
                        "weights": "random init (seed 0)"},
-            "parity": {"config": "c1 64x64 B=1 vs CPU oracle", "max_abs": max_abs, "psnr_y_db": psnr,
+            "parity": {"config": parity_cfg, "max_abs": max_abs, "psnr_y_db": psnr, "bound": PARITY_BOUND,
+                       "verified": bool(parity_ok and not args.no_parity),
                        "per_rank_max_abs": [float(v) for v in allm[:, 2]]},
-            "roofline": roofline, "cpu_baseline": cpu,
+            "roofline": roofline, "cpu_baseline": cpu, "fp16_range_guard": range_info, **extra,
         }
-        if world == 1 and not args.no_parity:
+        if world == 1 and not args.no_parity and not args.no_extra_modes:
             # the path's other operator row, outside the timed region: the fused DCNv2 forward at the
             # alignment module's shape against its HBM roofline (same definitions as tools/bench_dcn.py)
             res["dcn_forward"] = dcn_forward_line(dev, Hp, Wp, B)
@@ -223,6 +317,9 @@ def main():
                             f"{fl[k]/ms[k]/1e9:.2f} {by[k]/ms[k]/1e6:.1f}\n")
     if world > 1:
         dist.destroy_process_group()
+    if not parity_ok:
+        sys.stderr.write(f"bench.py: PARITY FAILED: max-abs vs the CPU oracle {allm[:, 2].tolist()} (bound {PARITY_BOUND})\n")
+        sys.exit(3)
 
 
 def cvsr_v7_line(device, d, H, W, B, steps=2):
@@ -272,8 +369,8 @@ def dcn_forward_line(device, H, W, B, iters=10):
     nbytes = (C + 3 * dg * 9 + Co) * H * W * 4 * B + w.numel() * 4
     ach = nbytes / ms / 1e6
     traffic = None
-    tpath = os.path.join(ROOT, "profiles", "traffic_dcn_r01.json")
-    if os.path.exists(tpath) and (B, H, W) == (8, 272, 480):     # PMC passes of tools/bench_dcn.py at exactly this shape
+    tpath = next((q for q in (os.path.join(ROOT, "profiles", f"traffic_dcn_r{r:02d}.json") for r in (2, 1)) if os.path.exists(q)), "")
+    if tpath and (B, H, W) == (8, 272, 480):     # PMC passes of tools/bench_dcn.py at exactly this shape
         try:
             tj = json.load(open(tpath))
             traffic = tj["hbm_bytes_per_launch"] + tj["prepass_hbm_bytes_per_launch"]
@@ -284,15 +381,51 @@ def dcn_forward_line(device, H, W, B, iters=10):
                          "algorithmic_bytes_per_launch": nbytes, "traffic": traffic}}
 
 
-def cpu_baseline(sd, Hp, Wp):
-    """The oracle (a torch-cpu port of the reference forward) timed on this host on a bounded sample: ONE clip at half
-    the workload's height and width, scaled to the workload by the algorithmic-FLOP ratio."""
-    from oracle.cvsr_v8_ref import cvsr_v8_forward, make_inputs
+def _host_cores():
     cores = min(os.cpu_count() or 1, 32)
     try:
         cores = min(cores, len(os.sched_getaffinity(0)))
     except Exception:
         pass
+    return cores
+
+
+def _cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except Exception:
+        pass
+    return "unknown"
+
+
+def oracle_clip(sd, clip, noise, Hp, Wp, time_it=True):
+    """The CPU oracle (torch-cpu port of the reference forward) on ONE clip of the timed workload at its full size: the
+    parity reference and, timed after a small warm-up forward, the cpu_baseline (frames/s = 1 / seconds per clip)."""
+    from oracle.cvsr_v8_ref import cvsr_v8_forward, make_inputs
+    cores = _host_cores()
+    torch.set_num_threads(cores)
+    with torch.no_grad():
+        w = make_inputs(1, 32, 32, 5)
+        cvsr_v8_forward(sd, w["x"], None, w["mvs1"], w["pms"], w["rms"], w["ufs"], None, w["gumbel_u"])      # warm-up
+        t0 = time.perf_counter()
+        ref, _ = cvsr_v8_forward(sd, clip["x"], None, clip["mvs1"], clip["pms"], clip["rms"], clip["ufs"], None, noise)
+        dt = time.perf_counter() - t0
+    cpu = None
+    if time_it:
+        cpu = {"value": round(1.0 / dt, 5), "unit": "frames/s", "cores": cores, "kind": "port",
+               "sample": f"1 clip 7x1x{Hp}x{Wp} of the timed batch, one full forward = {dt:.2f} s on {cores} torch threads after a "
+                         "32x32 warm-up forward (the clip is also the parity reference)",
+               "cpu_model": _cpu_model(), "torch": torch.__version__}
+    return ref, cpu
+
+
+def cpu_baseline_scaled(sd, Hp, Wp):
+    """Fallback when no full-size oracle run happened (--no-parity / --streaming): ONE clip at half the workload's height
+    and width, scaled to the workload by the algorithmic-FLOP ratio."""
+    from oracle.cvsr_v8_ref import cvsr_v8_forward, make_inputs
+    cores = _host_cores()
     torch.set_num_threads(cores)
     h, w = max(8, Hp // 2 // 8 * 8), max(8, Wp // 2 // 8 * 8)
     s = make_inputs(1, h, w, 77)
@@ -303,7 +436,7 @@ def cpu_baseline(sd, Hp, Wp):
     scale = flops_per_clip(Hp, Wp) / flops_per_clip(h, w)
     return {"value": round(1.0 / (dt * scale), 5), "unit": "frames/s", "cores": cores, "kind": "port",
             "sample": f"1 clip 7x1x{h}x{w} forward = {dt:.2f} s on {cores} torch threads, scaled x{scale:.2f} by "
-                      f"algorithmic FLOPs to {Hp}x{Wp}", "torch": torch.__version__}
+                      f"algorithmic FLOPs to {Hp}x{Wp}", "cpu_model": _cpu_model(), "torch": torch.__version__}
 
 
 if __name__ == "__main__":

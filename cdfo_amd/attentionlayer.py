@@ -9,7 +9,7 @@ import torch.nn as nn
 
 from . import nchw as N
 from .dcn import ModulatedDeformConv
-from .kernels import ACT_NONE, ACT_RELU, ACT_SIGMOID
+from .kernels import ACT_NONE, ACT_RELU, ACT_SIGMOID, on_device
 
 
 class DSTA(nn.Module):
@@ -43,6 +43,10 @@ class DSTA(nn.Module):
             raise NotImplementedError("DSTA (HIP): CPU tensors are not supported")
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
             raise NotImplementedError("DSTA (HIP): forward only -- wrap the call in torch.no_grad()")
+        with on_device(x):
+            return self._forward(x)
+
+    def _forward(self, x):
         c1_ = self._c(self.conv1, x)
         c1 = self._c(self.conv2, c1_)
         v_max = N.maxpool(c1, 7, 3)

@@ -14,13 +14,32 @@ namespace {
 constexpr int ZS = 65;  // LDS pitch for the [pixel][channel] logits (conflict-free both ways)
 constexpr int QS = 72;  // 4 zero floats on both sides of the 64 channels for the 9-tap channel conv
 
+// Philox4x32-10 (Salmon et al., SC'11): counter-based generator, 4 x 32 random bits per (counter, key).
+__device__ __forceinline__ void philox4x32_10(unsigned c0, unsigned c1, unsigned c2, unsigned c3, unsigned k0, unsigned k1,
+                                              unsigned (&o)[4]) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const unsigned long long p0 = (unsigned long long)0xD2511F53u * c0, p1 = (unsigned long long)0xCD9E8D57u * c2;
+    const unsigned n0 = (unsigned)(p1 >> 32) ^ c1 ^ k0, n1 = (unsigned)p1, n2 = (unsigned)(p0 >> 32) ^ c3 ^ k1, n3 = (unsigned)p0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+  o[0] = c0; o[1] = c1; o[2] = c2; o[3] = c3;
+}
+
+// RNG: the uniform draws of gumbel_softmax (arch.py:2169, torch.rand_like + "redraw while any == 0") are generated here
+// instead of being read: u = (24 random bits + 0.5) * 2^-24 lies strictly inside (0, 1), element (image b, channel c,
+// pixel p) takes word c & 3 of Philox(counter = (p, b, c >> 2, draw), key = seed).  noise_out (optional): the drawn
+// values, [B][64][P], for callers that replay the forward elsewhere (parity tests).
+template <bool RNG>
 __global__ __launch_bounds__(256) void rdab_prep_kernel(const float* __restrict__ xq, int ldx,  // [.,128]: q | v
                                                         const float* __restrict__ vmax,         // [B][64]
                                                         const float* __restrict__ noise,        // [B][64][P] (NCHW)
                                                         const float* __restrict__ wW, const float* __restrict__ bW,
                                                         long long P, float* __restrict__ sq, int lds_,
                                                         float* __restrict__ vrow, int ldv, float* __restrict__ qwin,
-                                                        int ldw) {
+                                                        int ldw, unsigned long long seed, unsigned draw,
+                                                        float* __restrict__ noise_out) {
   __shared__ float z[64 * ZS];
   __shared__ float mq[64 * QS];
   __shared__ float vv[64 * QS];
@@ -28,7 +47,20 @@ __global__ __launch_bounds__(256) void rdab_prep_kernel(const float* __restrict_
   const long long p0 = (long long)blockIdx.x * 64;  // P % 64 == 0, so the 64 pixels share one image
   const long long b = p0 / P, pin = p0 - b * P;
   // phase 1: logits z[i][c] = vmax[c] - log(-log(u))   (coalesced along pixels)
-  {
+  if (RNG) {
+    const int i = tid & 63;
+    for (int j = tid >> 6; j < 16; j += 4) {       // channel group j = channels 4j .. 4j+3 of pixel i
+      unsigned o[4];
+      philox4x32_10((unsigned)(pin + i), (unsigned)b, (unsigned)j, draw, (unsigned)seed, (unsigned)(seed >> 32), o);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int c = 4 * j + k;
+        const float u = ((float)(o[k] >> 8) + 0.5f) * (1.f / 16777216.f);
+        if (noise_out) noise_out[(b * 64 + c) * P + pin + i] = u;
+        z[i * ZS + c] = vmax[b * 64 + c] + (-logf(-logf(u)));
+      }
+    }
+  } else {
     const int i = tid & 63;
     for (int c = tid >> 6; c < 64; c += 4) {
       const float u = noise[(b * 64 + c) * P + pin + i];
@@ -398,8 +430,23 @@ extern "C" int cdfo_rdab_prep(const float* xq, int ldx, const float* vmax, const
   if (B <= 0 || P <= 0 || P % 64 || ldx % 4 || lds_ % 4 || ldv % 4 || ldw % 4) return CDFO_EINVAL;
   if (!aligned16(xq) || !aligned16(sq) || !aligned16(vrow) || !aligned16(qwin)) return CDFO_EALIGN;
   CdfoProfScope prof(static_cast<hipStream_t>(stream), KID_RDAB_PREP, 0, 4.0*(128+64+192)*(double)B*P);
-  hipLaunchKernelGGL(rdab_prep_kernel, dim3((unsigned)(B * P / 64)), dim3(256), 0, static_cast<hipStream_t>(stream), xq,
-                     ldx, vmax, noise, wW, bW, P, sq, lds_, vrow, ldv, qwin, ldw);
+  hipLaunchKernelGGL(rdab_prep_kernel<false>, dim3((unsigned)(B * P / 64)), dim3(256), 0, static_cast<hipStream_t>(stream), xq,
+                     ldx, vmax, noise, wW, bW, P, sq, lds_, vrow, ldv, qwin, ldw, 0ull, 0u, nullptr);
+  CDFO_LAUNCH_CHECK();
+  return 0;
+}
+
+// The same with the uniform noise drawn inside the kernel (Philox4x32-10 keyed by `seed`; `draw` numbers the call, so the
+// draws of one forward are independent).  noise_out: optional [B][64][P] copy of the drawn values.
+extern "C" int cdfo_rdab_prep_rng(const float* xq, int ldx, const float* vmax, long long seed, int draw, float* noise_out,
+                                  const float* wW, const float* bW, int B, long long P, float* sq, int lds_, float* vrow,
+                                  int ldv, float* qwin, int ldw, void* stream) {
+  if (B <= 0 || P <= 0 || P % 64 || P >= (1ll << 32) || ldx % 4 || lds_ % 4 || ldv % 4 || ldw % 4) return CDFO_EINVAL;
+  if (!aligned16(xq) || !aligned16(sq) || !aligned16(vrow) || !aligned16(qwin)) return CDFO_EALIGN;
+  CdfoProfScope prof(static_cast<hipStream_t>(stream), KID_RDAB_PREP, 0, 4.0*(128+192)*(double)B*P);
+  hipLaunchKernelGGL(rdab_prep_kernel<true>, dim3((unsigned)(B * P / 64)), dim3(256), 0, static_cast<hipStream_t>(stream), xq,
+                     ldx, vmax, nullptr, wW, bW, P, sq, lds_, vrow, ldv, qwin, ldw, (unsigned long long)seed, (unsigned)draw,
+                     noise_out);
   CDFO_LAUNCH_CHECK();
   return 0;
 }

@@ -165,18 +165,11 @@ extern "C" int cdfo_block_prologue(const float* x, int ldx, int B, int H, int W,
   if ((long long)B * H * W * 4 >= (1ll << 31)) return CDFO_EINVAL;
   if (!aligned16(x) || !aligned16(w_bf16) || !aligned16(u16) || !aligned16(d16) || !bias128) return CDFO_EALIGN;
   hipStream_t st = static_cast<hipStream_t>(stream);
-  static bool attr_set = false;
-  static int cus = 0;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(block_pro_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, BP_LDS);
-    if (e != hipSuccess) return (int)e;
-    int dev = 0;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return CDFO_EINVAL;
-    cus = prop.multiProcessorCount;
-    attr_set = true;
-  }
+  static CdfoAttrOnce once;
+  const hipError_t e = cdfo_set_max_lds(once, reinterpret_cast<const void*>(block_pro_kernel), BP_LDS);
+  if (e != hipSuccess) return (int)e;
+  const int cus = cdfo_num_cus();
+  if (cus <= 0) return CDFO_EINVAL;
   const long long ntiles = (long long)B * cdiv(H, BP_TR) * cdiv(W, BP_TC);
   const int grid = (int)(ntiles < cus ? ntiles : cus);
   bp_args a;

@@ -16,6 +16,37 @@ typedef short bf16x4 __attribute__((ext_vector_type(4)));
     if (e__ != hipSuccess) return (int)e__;         \
   } while (0)
 
+// Per-device host-side caches.  One process normally drives one GPU, but a caller may hold models on several devices:
+// everything cached on the host (CU count, "this kernel's LDS attribute is set") is keyed by the CURRENT device ordinal
+// (the Python wrappers make the operands' device current before every call).
+constexpr int CDFO_MAXDEV = 64;
+static inline int cdfo_cur_device() {
+  int d = 0;
+  return hipGetDevice(&d) == hipSuccess && d >= 0 && d < CDFO_MAXDEV ? d : -1;
+}
+// compute units of the current device (0 on failure)
+static inline int cdfo_num_cus() {
+  static int cus[CDFO_MAXDEV] = {0};
+  const int d = cdfo_cur_device();
+  if (d < 0) return 0;
+  if (!cus[d]) {
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, d) != hipSuccess) return 0;
+    cus[d] = prop.multiProcessorCount;
+  }
+  return cus[d];
+}
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per (call site, device); `done` is the call site's static table
+struct CdfoAttrOnce { bool done[CDFO_MAXDEV] = {false}; };
+static inline hipError_t cdfo_set_max_lds(CdfoAttrOnce& once, const void* func, int bytes) {
+  const int d = cdfo_cur_device();
+  if (d < 0) return hipErrorInvalidDevice;
+  if (once.done[d]) return hipSuccess;
+  const hipError_t e = hipFuncSetAttribute(func, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  if (e == hipSuccess) once.done[d] = true;
+  return e;
+}
+
 static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 

@@ -455,26 +455,13 @@ __global__ __launch_bounds__(RG_THREADS) void conv3x3_ring_kernel(cdfo_conv_args
   }
 }
 
-int rg_num_cus() {
-  static int cus = 0;
-  if (!cus) {
-    int dev = 0;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 0;
-    cus = prop.multiProcessorCount;
-  }
-  return cus;
-}
+int rg_num_cus() { return cdfo_num_cus(); }
 
 template <bool SPARSE, int DBG>
 int rg_launch(const cdfo_conv_args& a, const ring_extra& e, int grid, hipStream_t st) {
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_ring_kernel<SPARSE, DBG>),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, RingLds<SPARSE>::TOTAL);
-    if (err != hipSuccess) return (int)err;
-    attr_set = true;
-  }
+  static CdfoAttrOnce once;
+  const hipError_t err = cdfo_set_max_lds(once, reinterpret_cast<const void*>(conv3x3_ring_kernel<SPARSE, DBG>), RingLds<SPARSE>::TOTAL);
+  if (err != hipSuccess) return (int)err;
   hipLaunchKernelGGL((conv3x3_ring_kernel<SPARSE, DBG>), dim3(grid), dim3(RG_THREADS), RingLds<SPARSE>::TOTAL, st, a, e);
   return 0;
 }

@@ -356,26 +356,13 @@ __global__ __launch_bounds__(WS_THREADS) void conv3x3_c64_ws_kernel(ws_args a) {
   }
 }
 
-int ws_num_cus() {
-  static int cus = 0;
-  if (!cus) {
-    int dev = 0;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 0;
-    cus = prop.multiProcessorCount;
-  }
-  return cus;
-}
+int ws_num_cus() { return cdfo_num_cus(); }
 
 template <int DBG, bool RES = false>
 int ws_launch(const ws_args& a, int grid, hipStream_t st) {
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_c64_ws_kernel<DBG, RES>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, WS_LDS);
-    if (e != hipSuccess) return (int)e;
-    attr_set = true;
-  }
+  static CdfoAttrOnce once;
+  const hipError_t e = cdfo_set_max_lds(once, reinterpret_cast<const void*>(conv3x3_c64_ws_kernel<DBG, RES>), WS_LDS);
+  if (e != hipSuccess) return (int)e;
   hipLaunchKernelGGL((conv3x3_c64_ws_kernel<DBG, RES>), dim3(grid), dim3(WS_THREADS), WS_LDS, st, a);
   return 0;
 }

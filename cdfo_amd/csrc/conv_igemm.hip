@@ -194,12 +194,9 @@ __global__ void pack_weight_kernel(const float* __restrict__ w, float* __restric
 template <int KS, int S, int TH, int NT, int KC>
 int launch(const cdfo_conv_args& a, hipStream_t st) {
   using G = Geo<KS, S, TH, NT, KC>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_f32<KS, S, TH, NT, KC>),
-                        hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES);
-    attr_set = true;
-  }
+  static CdfoAttrOnce once;
+  const hipError_t ea = cdfo_set_max_lds(once, reinterpret_cast<const void*>(&conv_igemm_f32<KS, S, TH, NT, KC>), G::LDS_BYTES);
+  if (ea != hipSuccess) return (int)ea;
   dim3 grid(cdiv(cdiv(a.Wo, TW) * cdiv(a.Ho, TH) * a.B, 8) * 8 * (a.CoutP / G::BN));
   const int kid = KS == 1 ? KID_CONV1 : (S == 2 ? KID_CONV3_S2 : (NT == 2 ? KID_CONV3_WIDE : KID_CONV3_NARROW));
   const double px = (double)a.B * a.Ho * a.Wo;

@@ -24,6 +24,7 @@ constexpr int WSTR = 257;  // LDS row pitch of the staged weights: odd, so that 
 struct DcnArgs {
   const float* in; const float* offset; const float* mask; const float* w; const float* bias; float* out;
   const float* gp;   // optional group-planar copy of `in`: [B][dg][H][W][C/dg] (see dcn_to_gp_kernel)
+  const unsigned* run_if;   // optional device word: the kernel returns at once while it is 0 (re-run request of the fast path)
   int B, C, H, W, Co, Ho, Wo, kh, kw, sh, sw, ph, pw, dh, dw, groups, dg;
 };
 
@@ -43,20 +44,29 @@ __device__ __forceinline__ float bilinear_zero(const float* __restrict__ plane, 
 
 // in NCHW -> group-planar [B][dg][H][W][C/dg]: the C/dg channels that share one sample position become contiguous, so
 // a bilinear corner of a 4-channel chunk is ONE 16-byte gather instead of four 4-byte ones
+// amax (optional): bits of max |in| over the finite elements, by atomicMax on the bit pattern (the fast path's input scale)
 __global__ __launch_bounds__(256) void dcn_to_gp_kernel(const float* __restrict__ in, float* __restrict__ gp, int B, int C,
-                                                        int dg, long long HW) {
+                                                        int dg, long long HW, unsigned* __restrict__ amax) {
   const int Cdg = C / dg;
   const long long n = (long long)B * dg * HW;
   const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
-  if (gid >= n) return;
-  const long long p = gid % HW, bd = gid / HW;                  // bd = b*dg + d
-  const float* src = in + bd * Cdg * HW + p;
-  float* dst = gp + gid * Cdg;
-  for (int c = 0; c < Cdg; c += 4) {
-    f32x4 v;
-    v[0] = src[(long long)c * HW]; v[1] = src[(long long)(c + 1) * HW];
-    v[2] = src[(long long)(c + 2) * HW]; v[3] = src[(long long)(c + 3) * HW];
-    *reinterpret_cast<f32x4*>(dst + c) = v;
+  float m = 0.f;
+  if (gid < n) {
+    const long long p = gid % HW, bd = gid / HW;                  // bd = b*dg + d
+    const float* src = in + bd * Cdg * HW + p;
+    float* dst = gp + gid * Cdg;
+    for (int c = 0; c < Cdg; c += 4) {
+      f32x4 v;
+      v[0] = src[(long long)c * HW]; v[1] = src[(long long)(c + 1) * HW];
+      v[2] = src[(long long)(c + 2) * HW]; v[3] = src[(long long)(c + 3) * HW];
+      *reinterpret_cast<f32x4*>(dst + c) = v;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { const float av = fabsf(v[e]); m = av < 3.0e38f ? fmaxf(m, av) : m; }
+    }
+  }
+  if (amax) {
+    m = wave_max(m);
+    if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(amax, __float_as_uint(m));
   }
 }
 
@@ -74,6 +84,7 @@ __global__ __launch_bounds__(256) void dcn_fwd_kernel(DcnArgs a, int KCH /* = CC
   const int nco = (Cog - co0) < 256 ? (Cog - co0) : 256;
   const int p0 = blockIdx.x * PIXT;
   const int mt = wave >> 1, nt = wave & 1;                       // this wave's 32-cout / 32-pixel sub-tile
+  if (a.run_if && __hip_atomic_load(a.run_if, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) return;   // workgroup-uniform
 
   f32x16 acc[MAXJ];
 #pragma unroll
@@ -187,9 +198,9 @@ __global__ __launch_bounds__(256) void dcn_fwd_kernel(DcnArgs a, int KCH /* = CC
   }
 }
 
-void launch_to_gp(const float* in, float* gp, int B, int C, int dg, long long HW, hipStream_t st) {
+void launch_to_gp(const float* in, float* gp, int B, int C, int dg, long long HW, unsigned* amax, hipStream_t st) {
   const long long n = (long long)B * dg * HW;
-  hipLaunchKernelGGL(dcn_to_gp_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, in, gp, B, C, dg, HW);
+  hipLaunchKernelGGL(dcn_to_gp_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, in, gp, B, C, dg, HW, amax);
 }
 
 }  // namespace
@@ -198,7 +209,8 @@ void launch_to_gp(const float* in, float* gp, int B, int C, int dg, long long HW
 int cdfo_dcn_forward_fast(const float* in, const float* offset, const float* mask, const float* weight, const float* bias,
                           float* out, int B, int C, int H, int W, int Co, int Ho, int Wo, int kh, int kw, int sh, int sw, int ph,
                           int pw, int dh, int dw, int groups, int dg, void* workspace, long long workspace_bytes,
-                          hipStream_t st, void (*to_gp)(const float*, float*, int, int, int, long long, hipStream_t));
+                          hipStream_t st, void (*to_gp)(const float*, float*, int, int, int, long long, unsigned*, hipStream_t),
+                          const unsigned** rerun_flag);
 
 extern "C" int cdfo_dcn_forward(const float* in, const float* offset, const float* mask, const float* weight,
                                 const float* bias, float* out, int B, int C, int H, int W, int Co, int kh, int kw, int sh,
@@ -211,7 +223,7 @@ extern "C" int cdfo_dcn_forward(const float* in, const float* offset, const floa
   const int Ho = (H + 2 * ph - (dh * (kh - 1) + 1)) / sh + 1;
   const int Wo = (W + 2 * pw - (dw * (kw - 1) + 1)) / sw + 1;
   if (Ho <= 0 || Wo <= 0) return CDFO_EINVAL;
-  DcnArgs a{in, offset, mask, weight, bias, out, nullptr, B, C, H, W, Co, Ho, Wo, kh, kw, sh, sw, ph, pw, dh, dw, groups,
+  DcnArgs a{in, offset, mask, weight, bias, out, nullptr, nullptr, B, C, H, W, Co, Ho, Wo, kh, kw, sh, sw, ph, pw, dh, dw, groups,
             deformable_groups};
   // group-planar gathers need: a caller-provided scratch copy of `in`, 4-channel chunks that never straddle a
   // deformable group or a conv group, 16-byte aligned rows
@@ -221,27 +233,32 @@ extern "C" int cdfo_dcn_forward(const float* in, const float* offset, const floa
   const int KCH = (CC * T + 1) / 2 * 2;
   const size_t lds = (size_t)KCH * (PIXT + WSTR) * sizeof(float);
   if (lds > 160 * 1024) return CDFO_EINVAL;
-  static size_t attr = 0;
-  if (lds > attr) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dcn_fwd_kernel<false>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dcn_fwd_kernel<true>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr = lds;
-  }
+  static CdfoAttrOnce once_a, once_b;           // the attribute is set to the CU's whole LDS once per device
+  if (cdfo_set_max_lds(once_a, reinterpret_cast<const void*>(&dcn_fwd_kernel<false>), 160 * 1024) != hipSuccess ||
+      cdfo_set_max_lds(once_b, reinterpret_cast<const void*>(&dcn_fwd_kernel<true>), 160 * 1024) != hipSuccess)
+    return CDFO_EINVAL;
   const int Cog = Co / groups;
   dim3 grid(cdiv(Ho * Wo, PIXT), groups * cdiv(Cog, 256), B);
   hipStream_t st = static_cast<hipStream_t>(stream);
   const double px = (double)B * Ho * Wo;
   CdfoProfScope prof(st, KID_DCN, 2.0 * px * Co * (C / groups) * T,
                      4.0 * (px * (Co + 3.0 * deformable_groups * T) + (double)B * C * H * W + (double)Co * (C / groups) * T));
+  const unsigned* rerun = nullptr;
   const int fast = cdfo_dcn_forward_fast(in, offset, mask, weight, bias, out, B, C, H, W, Co, Ho, Wo, kh, kw, sh, sw, ph, pw, dh,
-                                         dw, groups, deformable_groups, workspace, workspace_bytes, st, &launch_to_gp);
-  if (fast == 1) return 0;
+                                         dw, groups, deformable_groups, workspace, workspace_bytes, st, &launch_to_gp, &rerun);
   if (fast > 1) return fast - 2;
+  if (fast == 1) {
+    // The fast kernel holds the sampled values as scaled fp16 hi + lo.  Where a sample left that range (or was not finite)
+    // it raised `rerun`: the exact-fp32 kernel then recomputes the whole result; otherwise its workgroups return at once.
+    a.gp = static_cast<const float*>(workspace);
+    a.run_if = rerun;
+    hipLaunchKernelGGL(dcn_fwd_kernel<true>, grid, dim3(256), lds, st, a, KCH);
+    CDFO_LAUNCH_CHECK();
+    return 0;
+  }
   if (gp) {
     a.gp = static_cast<const float*>(workspace);
-    launch_to_gp(in, static_cast<float*>(workspace), B, C, deformable_groups, (long long)H * W, st);
+    launch_to_gp(in, static_cast<float*>(workspace), B, C, deformable_groups, (long long)H * W, nullptr, st);
     hipLaunchKernelGGL(dcn_fwd_kernel<true>, grid, dim3(256), lds, st, a, KCH);
   } else {
     hipLaunchKernelGGL(dcn_fwd_kernel<false>, grid, dim3(256), lds, st, a, KCH);

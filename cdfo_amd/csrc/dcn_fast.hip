@@ -18,8 +18,12 @@
 //     accumulation, ~2^-22 relative); the two K halves are summed through LDS and the tile is stored NCHW, coalesced.
 //     The whole K = C*kh*kw (<= 576 rows per chunk, more channels loop) lives in LDS: one barrier pair per 64 pixels
 //     instead of one per 4 input channels.
-// Sampled values are held as fp16 hi + lo: |in * mask| must stay below 65504 (feature maps here are O(1)); callers with
-// larger magnitudes pass workspace = NULL and get the exact-fp32 kernel of dcn.hip.
+// Sampled values are held as fp16 hi + lo.  Range safety: the group-planar prepass also finds max |in|, the sampler
+// multiplies by the power of two that puts it in (8, 16] (undone with the weight scale at the end), so small- and
+// large-magnitude feature maps keep their 22 bits; a sample whose scaled value would still leave the fp16 range
+// (|in * mask| > 3750 max |in|, i.e. a mask far outside [0, 1]) or is not finite raises a device flag, and
+// cdfo_dcn_forward then re-runs the exact-fp32 kernel of dcn.hip over the whole result (its workgroups return at once
+// while the flag is clear).  Callers who want the exact kernel unconditionally pass workspace = NULL.
 #include "common.h"
 
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
@@ -31,7 +35,8 @@ constexpr int KMAX = 288;      // K rows (input channels x taps) resident in LDS
 
 struct FastArgs {
   const float* gp; const float* offset; const float* mask; const float* bias; float* out;
-  const h8* wp_hi; const h8* wp_lo; const unsigned* wmax;    // wmax[0] = bits of max |w| (-> the power-of-two weight scale)
+  const h8* wp_hi; const h8* wp_lo;
+  unsigned* wmax;    // [0] = bits of max |w|, [1] = bits of max |in| (-> the power-of-two scales), [2] = re-run request
   int B, C, H, W, Co, Ho, Wo, kh, kw, sh, sw, ph, pw, dh, dw, dg;
   int CCH;       // input channels per K chunk (multiple of 4)
   int nchunks;   // ceil(C / CCH)
@@ -46,10 +51,12 @@ __global__ __launch_bounds__(256) void dcn_wmax_kernel(const float* __restrict__
   if ((threadIdx.x & 63) == 0 && m < 3.0e38f) atomicMax(wmax, __float_as_uint(m));
 }
 
-__device__ __forceinline__ float weight_scale(const unsigned* wmax) {
-  const float m = __uint_as_float(wmax[0]);
-  return m > 0.f ? exp2f(4.f - ceilf(log2f(m))) : 1.f;               // a power of two: |w| * s in (8, 16]
+__device__ __forceinline__ float pow2_scale(unsigned max_bits) {
+  const float m = __uint_as_float(max_bits);
+  // a power of two: m * s in (8, 16]; the exponent is clamped so that neither s nor 1 / s leaves the fp32 range
+  return m > 0.f ? exp2f(fminf(fmaxf(4.f - ceilf(log2f(m)), -100.f), 100.f)) : 1.f;
 }
+__device__ __forceinline__ float weight_scale(const unsigned* wmax) { return pow2_scale(wmax[0]); }
 
 // one thread per fp16 element of the packed A operand: index = (((chunk*S + s)*MT + mtile)*64 + lane)*8 + j
 __global__ __launch_bounds__(256) void dcn_wpack_kernel(const float* __restrict__ w, const unsigned* __restrict__ wmax,
@@ -99,6 +106,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
   const float* off_b = a.offset + (long long)b * a.dg * 2 * T * P + p;
   const float* msk_b = a.mask ? a.mask + (long long)b * a.dg * T * P + p : nullptr;
   const float* gp_b = a.gp + (long long)b * a.C * a.H * a.W;
+  const float s_in = pow2_scale(a.wmax[1]);
+  bool ovf = false;
   // matrix role: wave = (pixel half, output-channel half, K half)
   const int nt = wave & 1, mh = (wave >> 1) & 1, kh2 = wave >> 2;
   f32x16 acc[MJ];
@@ -188,7 +197,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
             float val[4];
 #pragma unroll
             for (int e = 0; e < 4; ++e)
-              val[e] = (wgt[i][0] * v[i][0][e] + wgt[i][1] * v[i][1][e] + wgt[i][2] * v[i][2][e] + wgt[i][3] * v[i][3][e]) * mm[i];
+              val[e] = (wgt[i][0] * v[i][0][e] + wgt[i][1] * v[i][1][e] + wgt[i][2] * v[i][2][e] + wgt[i][3] * v[i][3][e]) * (mm[i] * s_in);
+            ovf |= !(fmaxf(fmaxf(fabsf(val[0]), fabsf(val[1])), fmaxf(fabsf(val[2]), fabsf(val[3]))) < 60000.f) ||
+                   val[0] != val[0] || val[1] != val[1] || val[2] != val[2] || val[3] != val[3];
             // fp16 hi + lo with the packed round-toward-zero conversion (hi truncated, lo = the exact remainder truncated:
             // hi + lo still carries 22 bits)
             typedef __fp16 hp2 __attribute__((ext_vector_type(2)));
@@ -240,6 +251,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
       }
     }
   }
+  if (ovf) atomicOr(a.wmax + 2, 1u);      // out of the fp16 hi + lo range somewhere: the exact kernel re-runs (dcn.hip)
   // ---- sum the two K halves through LDS, then store D[row = cout][col = pixel] (+ bias), NCHW, coalesced along pixels
   __syncthreads();
   float* red = reinterpret_cast<float*>(smem);                       // [4 waves][MJ][16][64]
@@ -251,7 +263,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
   }
   __syncthreads();
   if (!kh2) {
-    const float inv = 1.f / weight_scale(a.wmax);
+    const float inv = (1.f / weight_scale(a.wmax)) * (1.f / s_in);
     const int pp = p0 + nt * 32 + (lane & 31);
     if (pp < P) {
 #pragma unroll
@@ -291,7 +303,8 @@ extern "C" long long cdfo_dcn_workspace_bytes(int B, int C, int H, int W, int Co
 int cdfo_dcn_forward_fast(const float* in, const float* offset, const float* mask, const float* weight, const float* bias,
                           float* out, int B, int C, int H, int W, int Co, int Ho, int Wo, int kh, int kw, int sh, int sw, int ph,
                           int pw, int dh, int dw, int groups, int dg, void* workspace, long long workspace_bytes,
-                          hipStream_t st, void (*to_gp)(const float*, float*, int, int, int, long long, hipStream_t)) {
+                          hipStream_t st, void (*to_gp)(const float*, float*, int, int, int, long long, unsigned*, hipStream_t),
+                          const unsigned** rerun_flag) {
   const long long need = cdfo_dcn_workspace_bytes(B, C, H, W, Co, kh, kw, groups, dg);
   if (!need || !workspace || workspace_bytes < need || !aligned16(workspace)) return 0;
   const int T = kh * kw;
@@ -309,8 +322,9 @@ int cdfo_dcn_forward_fast(const float* in, const float* offset, const float* mas
   _Float16* whi = reinterpret_cast<_Float16*>(ws + gpb);
   _Float16* wlo = reinterpret_cast<_Float16*>(ws + gpb + wpb);
   unsigned* scale = reinterpret_cast<unsigned*>(ws + gpb + 2 * wpb);
-  to_gp(in, gp, B, C, dg, (long long)H * W, st);
-  if (hipMemsetAsync(scale, 0, 4, st) != hipSuccess) return 2 + (int)hipGetLastError();
+  if (hipMemsetAsync(scale, 0, 16, st) != hipSuccess) return 2 + (int)hipGetLastError();
+  to_gp(in, gp, B, C, dg, (long long)H * W, scale + 1, st);
+  *rerun_flag = scale + 2;
   const long long nwt = (long long)Co * C * T;
   hipLaunchKernelGGL(dcn_wmax_kernel, dim3((unsigned)((nwt + 2047) / 2048 < 256 ? (nwt + 2047) / 2048 : 256)), dim3(256), 0, st, weight,
                      nwt, scale);
@@ -319,19 +333,13 @@ int cdfo_dcn_forward_fast(const float* in, const float* offset, const float* mas
                      CCH, nchunks, S);
   FastArgs a{gp, offset, mask, bias, out, reinterpret_cast<const h8*>(whi), reinterpret_cast<const h8*>(wlo), scale,
              B, C, H, W, Co, Ho, Wo, kh, kw, sh, sw, ph, pw, dh, dw, dg, CCH, nchunks, S};
-  static size_t attr1 = 0, attr2 = 0;
+  static CdfoAttrOnce once1, once2;            // the attribute is set to the CU's whole LDS once per device
   dim3 grid(cdiv(Ho * Wo, 64), B);
   if (MT <= 2) {
-    if (lds > attr1) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dcn_fast_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      attr1 = lds;
-    }
+    if (cdfo_set_max_lds(once1, reinterpret_cast<const void*>(&dcn_fast_kernel<1>), 160 * 1024) != hipSuccess) return 2 + (int)hipErrorInvalidValue;
     hipLaunchKernelGGL(dcn_fast_kernel<1>, grid, dim3(512), lds, st, a);
   } else {
-    if (lds > attr2) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dcn_fast_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      attr2 = lds;
-    }
+    if (cdfo_set_max_lds(once2, reinterpret_cast<const void*>(&dcn_fast_kernel<2>), 160 * 1024) != hipSuccess) return 2 + (int)hipErrorInvalidValue;
     hipLaunchKernelGGL(dcn_fast_kernel<2>, grid, dim3(512), lds, st, a);
   }
   hipError_t e = hipGetLastError();

@@ -37,7 +37,41 @@ __global__ void swap_outer_kernel(const f32x4* __restrict__ in, f32x4* __restric
   }
 }
 
+// slots[0] = max over the finite |x| (bit pattern of a non-negative float: integer max == float max), slots[1] |= 1 if any
+// element is NaN or infinite.  The caller zeroes the slots; several probes may share one buffer (different slot pairs).
+__global__ __launch_bounds__(256) void range_probe_kernel(const f32x4* __restrict__ x, long long n4, unsigned* __restrict__ slots) {
+  float m = 0.f;
+  bool bad = false;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+    const f32x4 v = x[i];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float a = fabsf(v[k]);
+      if (a < 3.0e38f) m = fmaxf(m, a); else bad = true;      // NaN compares false: counted as bad
+    }
+  }
+  m = wave_max(m);
+  const bool any_bad = __any(bad);
+  if ((threadIdx.x & 63) == 0) {
+    if (m > 0.f) atomicMax(slots, __float_as_uint(m));
+    if (any_bad) atomicOr(slots + 1, 1u);
+  }
+}
+
 }  // namespace
+
+// Range probe of a dense fp32 buffer (n % 4 == 0): see range_probe_kernel.  Used by CVSR_V8's fp16 range guard.
+extern "C" int cdfo_range_probe(const float* x, long long n, void* slots2, void* stream) {
+  if (!x || n <= 0 || n % 4 || !slots2) return CDFO_EINVAL;
+  if (!aligned16(x)) return CDFO_EALIGN;
+  long long blocks = (n / 4 + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  CdfoProfScope prof(static_cast<hipStream_t>(stream), KID_LAYOUT, 0, 4.0 * (double)n);
+  hipLaunchKernelGGL(range_probe_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     reinterpret_cast<const f32x4*>(x), n / 4, static_cast<unsigned*>(slots2));
+  CDFO_LAUNCH_CHECK();
+  return 0;
+}
 
 extern "C" int cdfo_nchw_to_nhwc(const float* in, float* out, int B, int C, int H, int W, int ldo, void* stream) {
   if (B <= 0 || C <= 0 || H <= 0 || W <= 0 || ldo < C) return CDFO_EINVAL;

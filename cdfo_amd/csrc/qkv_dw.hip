@@ -262,16 +262,7 @@ __global__ __launch_bounds__(QD_THREADS) void qkv_dw_kernel(qd_args a) {
 
 }  // namespace
 
-static int qd_cu_count() {                      // one process drives one GPU: queried once
-  static int cus = 0;
-  if (cus == 0) {
-    int dev = 0;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 0;
-    cus = prop.multiProcessorCount;
-  }
-  return cus;
-}
+static int qd_cu_count() { return cdfo_num_cus(); }     // of the current device
 
 // Number of per-image slots the fused Gram pass needs for these shapes on this device (>= 1).
 extern "C" int cdfo_qkv_dw_gram_slots(int B, int H, int W) {
@@ -290,13 +281,9 @@ extern "C" int cdfo_qkv_dw(const float* x, int ldx, int B, int H, int W, const v
   if ((long long)B * H * W >= (1ll << 31)) return CDFO_EINVAL;
   if (!aligned16(x) || !aligned16(w_bf16) || !aligned16(out) || !dw_w) return CDFO_EALIGN;
   hipStream_t st = static_cast<hipStream_t>(stream);
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(qkv_dw_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, QD_LDS);
-    if (e != hipSuccess) return (int)e;
-    attr_set = true;
-  }
+  static CdfoAttrOnce once;
+  const hipError_t e = cdfo_set_max_lds(once, reinterpret_cast<const void*>(qkv_dw_kernel), QD_LDS);
+  if (e != hipSuccess) return (int)e;
   const int cus = qd_cu_count();
   if (cus <= 0) return CDFO_EINVAL;
   const long long ntiles = (long long)B * cdiv(H, QD_TR) * cdiv(W, QD_TC);

@@ -237,6 +237,10 @@ class CVSR_V7(nn.Module):
     def forward(self, x, mvs0, mvs1, pms, rms, ufs, pre_L1_fea=None, gumbel_uniform=None):
         if not x.is_cuda:
             raise NotImplementedError("CVSR_V7 (HIP): CPU tensors are not supported; there is no CPU fallback")
+        with K.on_device(x):     # the operands' device becomes the current one: streams, per-device caches of the library
+            return self._forward(x, mvs0, mvs1, pms, rms, ufs, pre_L1_fea, gumbel_uniform)
+
+    def _forward(self, x, mvs0, mvs1, pms, rms, ufs, pre_L1_fea=None, gumbel_uniform=None):
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
             raise NotImplementedError("CVSR_V7 (HIP): forward only -- wrap the call in torch.no_grad()")
         B, N, C, H, W = x.shape

@@ -9,8 +9,11 @@ Differences, all deliberate:
   * forward needs CUDA (ROCm) tensors and ``torch.no_grad()``/``eval`` use: there is NO CPU or autograd fallback --
     it raises ``NotImplementedError`` like the reference's own CUDA-only operator does (ops/dcn/deform_conv.py:136).
   * ``gumbel_uniform=`` (kwarg or attribute): the six uniform draws of ``LLongRangAttention.gumbel_softmax``
-    (arch.py:2169) may be injected as six ``[B,64,H,W]`` tensors; default is to draw them with ``torch.rand`` like
-    the reference.
+    (arch.py:2169) may be injected as six ``[B,64,H,W]`` tensors; by default they are drawn like the reference does
+    (fresh uniforms per call, never 0), by a Philox4x32-10 generator inside the mask kernel, keyed per forward from
+    torch's default generator (``torch.manual_seed`` reproduces a run); ``capture_noise = []`` collects the values drawn.
+  * ``range_guard`` (default True): in the default ``fp16x2`` mode a forward whose activations leave fp16's range is
+    detected (max |trunk input| outside [2^-6, 2^11], or a non-finite result) and repeated in ``bf16x3``.
   * ``precision`` attribute: "f32" | "bf16x3" | "fp16x2" (default) | "bf16" selects the matrix-core arithmetic of the
     wide 3x3 convolutions; "f32", "bf16x3" and "fp16x2" meet the 1e-3 max-abs parity bound against the fp32 reference
     (1e-6, 1e-5 and 3-5e-4 respectively), "bf16" does not (6e-3).
@@ -152,6 +155,14 @@ class CVSR_V8(nn.Module):
                 t.zero_()
             _register(self, key, nn.Parameter(t))
         self.debug_taps: Optional[dict] = None      # set to {} to collect stage outputs (tests only)
+        self.capture_noise: Optional[list] = None   # set to [] to receive the six uniform tensors the default path drew
+        self._noise_seed = 0
+        # fp16 range guard of the fp16x2 mode (see forward); costs one 16-byte device->host readback per forward.  Callers
+        # that capture the forward into a HIP graph (no synchronisation allowed) set it to False
+        self.range_guard = True
+        self.last_range: Optional[dict] = None
+        self._probe = None
+        self._warned_range = False
         self._packed: Optional[dict] = None
         self._packed_sig = None
 
@@ -297,7 +308,12 @@ class CVSR_V8(nn.Module):
         vmax = K.vec_mlp(part, n, t.shape[1] * t.shape[2], raw["RDAB.conv_du_re2.0.weight"],
                          raw["RDAB.conv_du_re2.0.bias"], 64, K.ACT_RELU)
         xq = self._conv(x, w["RDAB.input_conv"])
-        sq, vrow, qwin = K.rdab_prep(xq, vmax, noise, raw["RDAB.directW1_conv.weight"], raw["RDAB.directW1_conv.bias"])
+        if isinstance(noise, tuple):      # ("rng", seed, draw, capture): draw the uniforms inside the kernel (default path)
+            _, seed, draw, capture = noise
+            sq, vrow, qwin = K.rdab_prep_rng(xq, vmax, seed, draw, raw["RDAB.directW1_conv.weight"],
+                                             raw["RDAB.directW1_conv.bias"], noise_out=capture)
+        else:
+            sq, vrow, qwin = K.rdab_prep(xq, vmax, noise, raw["RDAB.directW1_conv.weight"], raw["RDAB.directW1_conv.bias"])
         cat = K.empty_act(B, H, W, 128, x.device)
         rowo = K.seq_attn(sq, vrow, 0)
         qc = K.colconv9(sq, raw["RDAB.directH1_conv.weight"], raw["RDAB.directH1_conv.bias"])
@@ -387,6 +403,41 @@ class CVSR_V8(nn.Module):
     def forward(self, x, mvs0, mvs1, pms, rms, ufs, pre_L1_fea=None, gumbel_uniform=None):
         if not x.is_cuda:
             raise NotImplementedError("CVSR_V8 (HIP): CPU tensors are not supported; there is no CPU fallback")
+        with K.on_device(x):     # the operands' device becomes the current one: streams, per-device caches of the library
+            noise = gumbel_uniform if gumbel_uniform is not None else self.gumbel_uniform
+            if noise is None:
+                self._noise_seed = K.next_noise_seed(x.device)
+            guard = self.precision == "fp16x2" and self.range_guard
+            self._probe = torch.zeros(4, dtype=torch.int32, device=x.device) if guard else None
+            res = self._forward(x, mvs0, mvs1, pms, rms, ufs, pre_L1_fea, noise)
+            if not guard:
+                return res
+            # fp16 range guard (one 16-byte readback per forward): the fp16x2 mode keeps the trunk's tensors (and the
+            # alignment's residual blocks) in fp16.  Outside fp16's comfortable range -- max |trunk input| not in
+            # [2^-6, 2^11], or a NaN / infinity in the result, which is what an overflowed fp16 store turns into --
+            # the forward is repeated in the split-bf16 mode (fp32 exponent range, fp32-grade products).
+            bits = self._probe.cpu()
+            self._probe = None
+            amax = bits[0:1].view(torch.float32).item()
+            self.last_range = {"trunk_input_amax": amax, "nonfinite": bool(bits[1].item() | bits[3].item()), "fallback": False}
+            if not self.last_range["nonfinite"] and (amax == 0.0 or self.FP16_WINDOW[0] <= amax <= self.FP16_WINDOW[1]):
+                return res
+            if not self._warned_range:
+                import warnings
+                warnings.warn(f"CVSR_V8 (HIP): activations leave the fp16 range (max |trunk input| = {amax:.3g}, non-finite "
+                              f"result: {self.last_range['nonfinite']}); this forward and others like it are recomputed with "
+                              "precision='bf16x3'.  Set model.precision = 'bf16x3' to avoid the repeated work.")
+                self._warned_range = True
+            self.last_range["fallback"] = True
+            self.precision = "bf16x3"
+            try:
+                return self._forward(x, mvs0, mvs1, pms, rms, ufs, pre_L1_fea, noise)
+            finally:
+                self.precision = "fp16x2"
+
+    FP16_WINDOW = (2.0 ** -6, 2.0 ** 11)
+
+    def _forward(self, x, mvs0, mvs1, pms, rms, ufs, pre_L1_fea=None, gumbel_uniform=None):
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
             raise NotImplementedError("CVSR_V8 (HIP): forward only -- wrap the call in torch.no_grad() "
                                       "(backward kernels are not part of this path yet)")
@@ -426,7 +477,7 @@ class CVSR_V8(nn.Module):
             ufs, rms = ufs.transpose(1, 2), rms.transpose(1, 2)
         ufs = ufs.contiguous().float()
         rms = rms.contiguous().float()
-        noise = gumbel_uniform if gumbel_uniform is not None else self.gumbel_uniform
+        noise = gumbel_uniform        # resolved by forward(): injected tensors, or None = draw inside the mask kernel
         aligned: List[torch.Tensor] = []
         draw = 0
         # The six neighbour pipelines are independent of each other: with `neighbour_streams` > 1 they are issued
@@ -458,6 +509,8 @@ class CVSR_V8(nn.Module):
 
         # 3. temporal fusion, 4. reconstruction trunk, 5. upsampling + skip (arch.py:4463-4481)
         fused = self._conv(aligned, w["tsa_fusion"], act=K.ACT_LRELU)
+        if self._probe is not None:
+            K.range_probe(fused, self._probe[0:2])
         t = self._trunk(w, fused)
         if self.debug_taps is not None:
             self.debug_taps.update(L1_fea=L1, fused=fused, trunk=t)
@@ -467,6 +520,8 @@ class CVSR_V8(nn.Module):
             out = K.conv_last(t, raw["conv_last.weight"], raw["conv_last.bias"], x[:, ctr], N * P)
         else:   # upconv2 writes conv_last's nine per-tap channel sums instead of the 64-channel HR map
             out = K.upconv_last(t, w["upconv2"], raw["conv_last.weight"], raw["conv_last.bias"], x[:, ctr], N * P)
+        if self._probe is not None:
+            K.range_probe(out, self._probe[2:4])
         return out, L1.permute(0, 3, 1, 2)
 
     def _neighbour(self, w, raw, Lf, i, ctr, ufs, rms, mvs1, noise, draw, B, H, W, P, N, keep):
@@ -477,7 +532,13 @@ class CVSR_V8(nn.Module):
         rms_prior, fea_com = K.stem_conv(rms[:, 0, i], N * P, B, H, W, raw["conv_expand_rms.weight"],
                                          raw["conv_expand_rms.bias"], add=Lf[i])
         if noise is None:
-            u = torch.rand((B, NF, H, W), device=x_dev, dtype=torch.float32).clamp_min_(1e-30)
+            # the reference's default (torch.rand_like per call, arch.py:2169): the draws are generated INSIDE rdab_prep
+            # (Philox4x32-10), the [B,64,H,W] noise tensor never exists; `capture_noise` (tests) asks for a copy
+            cap = None
+            if self.capture_noise is not None:
+                cap = torch.empty((B, NF, H, W), device=x_dev, dtype=torch.float32)
+                self.capture_noise.append(cap)
+            u = ("rng", self._noise_seed, draw, cap)
         else:
             u = noise[draw].to(device=x_dev, dtype=torch.float32).contiguous()
         x_n = self._rdab(w, rms_prior, fea_com, u)

@@ -11,8 +11,18 @@ import ctypes as C
 
 import torch
 
+import os
+
 from . import _lib
-from .kernels import _stream
+from .kernels import _stream, on_device
+
+# Forward arithmetic.  False (default): shapes the fused fast kernel covers (groups == 1, (C/dg) % 4 == 0, Co % 32 == 0,
+# Co <= 128) run on split-fp16 MFMA (fp32-grade: <= 2e-5 * max|out| against the C oracle); the kernel scales its operands by
+# powers of two taken from max|input| / max|weight| and, should a sampled value still leave the fp16 range (or be
+# non-finite), the library re-runs the exact-fp32 kernel over the whole result -- so the fast path is range-safe.
+# True (or CDFO_DCN_EXACT=1 in the environment): always the exact-fp32 MFMA kernel (v_mfma_f32_32x32x2_f32, bitwise an
+# fp32 fma chain), ~3.5x slower at the alignment module's shape.
+EXACT_FP32 = os.environ.get("CDFO_DCN_EXACT", "0") not in ("", "0")
 
 
 def _check_cuda_f32(*ts):
@@ -48,13 +58,18 @@ def _fwd(input, weight, bias, offset, mask, output, kh, kw, sh, sw, ph, pw, dh, 
     offset = offset.contiguous()
     mask = None if mask is None else mask.contiguous()
     p = lambda t: C.c_void_p(None if t is None else t.data_ptr())  # noqa: E731
-    # device scratch (plumbing, no arithmetic): what the fast kernel asks for, else room for a group-planar copy of `input`
-    nbytes = max(int(_lib.lib().cdfo_dcn_workspace_bytes(B, Cc, H, W, Co, kh, kw, group, dg)), input.numel() * 4)
-    ws = torch.empty(nbytes, dtype=torch.uint8, device=input.device)
-    _lib.check(_lib.lib().cdfo_dcn_forward(p(input), p(offset), p(mask), p(weight), p(bias), p(output), B, Cc, H, W,
-                                           Co, kh, kw, sh, sw, ph, pw, dh, dw, group, dg, p(ws),
-                                           C.c_longlong(nbytes), _stream()),
-               "cdfo_dcn_forward")
+    with on_device(input):
+        # device scratch (plumbing, no arithmetic): what the fast kernel asks for, else room for a group-planar copy of
+        # `input`.  EXACT_FP32: the fast kernel's request is withheld, so the library takes its exact-fp32 kernel.
+        fast = 0 if EXACT_FP32 else int(_lib.lib().cdfo_dcn_workspace_bytes(B, Cc, H, W, Co, kh, kw, group, dg))
+        nbytes = max(fast, input.numel() * 4)
+        if EXACT_FP32:
+            nbytes = input.numel() * 4          # < the fast path's request whenever that path applies
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=input.device)
+        _lib.check(_lib.lib().cdfo_dcn_forward(p(input), p(offset), p(mask), p(weight), p(bias), p(output), B, Cc, H, W,
+                                               Co, kh, kw, sh, sw, ph, pw, dh, dw, group, dg, p(ws),
+                                               C.c_longlong(nbytes), _stream()),
+                   "cdfo_dcn_forward")
 
 
 def deform_conv_forward_cuda(input, weight, offset, output, columns, ones, kW, kH, dW, dH, padW, padH, dilationW,
@@ -103,10 +118,11 @@ def _bwd(input, offset, mask, weight, grad_output, grad_input, grad_offset, grad
     offset, grad_output = offset.contiguous(), grad_output.contiguous()
     mask = None if mask is None else mask.contiguous()
     p = lambda t: C.c_void_p(None if t is None else t.data_ptr())  # noqa: E731
-    _lib.check(_lib.lib().cdfo_dcn_backward(p(input), p(offset), p(mask), p(weight), p(grad_output), p(grad_input),
-                                            p(grad_offset), p(grad_mask), p(grad_weight), p(grad_bias), B, Cc, H, W, Co,
-                                            kh, kw, sh, sw, ph, pw, dh, dw, group, dg, float(scale), _stream()),
-               "cdfo_dcn_backward")
+    with on_device(input):
+        _lib.check(_lib.lib().cdfo_dcn_backward(p(input), p(offset), p(mask), p(weight), p(grad_output), p(grad_input),
+                                                p(grad_offset), p(grad_mask), p(grad_weight), p(grad_bias), B, Cc, H, W,
+                                                Co, kh, kw, sh, sw, ph, pw, dh, dw, group, dg, float(scale), _stream()),
+                   "cdfo_dcn_backward")
 
 
 def deform_conv_backward_input_cuda(input, offset, gradOutput, gradInput, gradOffset, weight, columns, kW, kH, dW, dH,

@@ -19,7 +19,17 @@ PREC_F32, PREC_BF16X3, PREC_BF16, PREC_FP16X2, PREC_FP16, PREC_FP16X1 = 0, 1, 2,
 
 
 def _stream() -> C.c_void_p:
+    """The CURRENT device's current stream.  Every public entry point (module forwards, the DCN operator, the metrics)
+    makes its operands' device current first (`on_device`), and `_chk_act` refuses operands of another device, so a
+    launch never pairs one device's stream with another device's pointers."""
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def on_device(t: torch.Tensor):
+    """Context manager: make `t`'s device the current one (stream lookup, per-device caches of libcdfo_hip.so)."""
+    if not t.is_cuda:
+        raise NotImplementedError("the HIP path needs device tensors (there is no CPU fallback)")
+    return torch.cuda.device(t.device)
 
 
 def _p(t: Optional[torch.Tensor]) -> Optional[int]:
@@ -29,6 +39,9 @@ def _p(t: Optional[torch.Tensor]) -> Optional[int]:
 def _chk_act(t: torch.Tensor, name: str = "tensor", dtype=torch.float32):
     if not t.is_cuda:
         raise NotImplementedError(f"{name}: the HIP path needs device tensors (no CPU fallback)")
+    if t.device.index != torch.cuda.current_device():
+        raise CdfoError(f"{name} lives on {t.device} but the current device is cuda:{torch.cuda.current_device()}: "
+                        "enter kernels.on_device(tensor) (the module forwards do) before calling the wrappers")
     if t.dtype != dtype or t.dim() != 4 or t.stride(3) != 1:
         raise ValueError(f"{name}: expected fp32 [B,H,W,C] with contiguous channels, got {t.dtype} {tuple(t.shape)} "
                          f"strides {t.stride()}")
@@ -61,6 +74,14 @@ def nhwc_to_nchw(x: torch.Tensor) -> torch.Tensor:
     check(_lib.lib().cdfo_nhwc_to_nchw(C.c_void_p(x.data_ptr()), ld, C.c_void_p(out.data_ptr()), B, Cc, H, W,
                                        _stream()), "cdfo_nhwc_to_nchw")
     return out
+
+
+def range_probe(x: torch.Tensor, slots: torch.Tensor) -> None:
+    """slots (int32[2], zeroed by the caller): [0] = bits of max finite |x|, [1] = 1 if x holds a NaN / infinity."""
+    if not x.is_contiguous() or x.dtype != torch.float32 or x.numel() % 4:
+        raise ValueError("range_probe: dense fp32 tensor with a multiple of 4 elements expected")
+    check(_lib.lib().cdfo_range_probe(C.c_void_p(x.data_ptr()), C.c_longlong(x.numel()), C.c_void_p(slots.data_ptr()),
+                                      _stream()), "cdfo_range_probe")
 
 
 # ----------------------------------------------------------------------------------------------- conv
@@ -670,6 +691,41 @@ def rdab_prep(xq: torch.Tensor, vmax: torch.Tensor, noise: torch.Tensor, wW: tor
     check(_lib.lib().cdfo_rdab_prep(_vp(xq), ld, _vp(vmax), _vp(noise), _vp(wW), _vp(bW), B, C.c_longlong(H * W),
                                     _vp(sq), 64, _vp(vrow), 64, _vp(qwin), 64, _stream()), "cdfo_rdab_prep")
     return sq, vrow, qwin
+
+
+def rdab_prep_rng(xq: torch.Tensor, vmax: torch.Tensor, seed: int, draw: int, wW: torch.Tensor, bW: torch.Tensor,
+                  noise_out: Optional[torch.Tensor] = None):
+    """rdab_prep with the uniform draws of arch.py:2169 generated inside the kernel (Philox4x32-10, key = seed, `draw` =
+    index of the call within the forward).  noise_out: optional fp32 [B,64,H,W] tensor that receives the drawn values."""
+    B, H, W, Cc, ld = _chk_act(xq)
+    assert Cc == 128
+    if noise_out is not None and (tuple(noise_out.shape) != (B, 64, H, W) or not noise_out.is_contiguous()
+                                  or noise_out.dtype != torch.float32):
+        raise ValueError("rdab_prep_rng: noise_out must be a contiguous fp32 [B,64,H,W] tensor")
+    sq = empty_act(B, H, W, 64, xq.device)
+    vrow = empty_act(B, H, W, 64, xq.device)
+    qwin = empty_act(B, H, W, 64, xq.device)
+    check(_lib.lib().cdfo_rdab_prep_rng(_vp(xq), ld, _vp(vmax), C.c_longlong(seed & 0x7FFFFFFFFFFFFFFF), draw, _vp(noise_out),
+                                        _vp(wW), _vp(bW), B, C.c_longlong(H * W), _vp(sq), 64, _vp(vrow), 64, _vp(qwin), 64,
+                                        _stream()), "cdfo_rdab_prep_rng")
+    return sq, vrow, qwin
+
+
+_seed_counter = 0
+
+
+def next_noise_seed(device) -> int:
+    """A fresh 63-bit Philox key per forward, reproducible under torch.manual_seed: taken from (and advancing) the state
+    of torch's default generator of `device` -- plumbing only, no random numbers are drawn by torch."""
+    global _seed_counter
+    try:
+        g = torch.cuda.default_generators[device.index if device.index is not None else torch.cuda.current_device()]
+        base, off = int(g.initial_seed()), int(g.get_offset())
+        g.set_offset(off + 4)
+    except Exception:
+        base, off = int(torch.initial_seed()), 4 * _seed_counter
+        _seed_counter += 1
+    return (base * 0x9E3779B97F4A7C15 + off * 0xD1B54A32D192ED03 + 0x632BE59BD9B4E019) & 0x7FFFFFFFFFFFFFFF
 
 
 def colconv9(x: torch.Tensor, wH: torch.Tensor, bH: torch.Tensor) -> torch.Tensor:

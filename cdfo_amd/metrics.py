@@ -13,7 +13,7 @@ import math
 import torch
 
 from . import _lib
-from .kernels import _stream, _vp
+from .kernels import _stream, _vp, on_device
 
 
 def _partials(a: torch.Tensor, b: torch.Tensor, crop: int, metric: int, from_unit_range: bool, round8: bool):
@@ -27,9 +27,11 @@ def _partials(a: torch.Tensor, b: torch.Tensor, crop: int, metric: int, from_uni
     N = a.shape[0]
     part = torch.empty((N, 1024), dtype=torch.float64, device=a.device)
     nb = C.c_int(0)
-    _lib.check(_lib.lib().cdfo_metric_partials(_vp(a), _vp(b), N, H, W, crop, C.c_float(255.0 if from_unit_range else 1.0),
-                                               int(from_unit_range), int(round8), metric, _vp(part), part.numel(),
-                                               C.byref(nb), _stream()), "cdfo_metric_partials")
+    with on_device(a):
+        _lib.check(_lib.lib().cdfo_metric_partials(_vp(a), _vp(b), N, H, W, crop,
+                                                   C.c_float(255.0 if from_unit_range else 1.0), int(from_unit_range),
+                                                   int(round8), metric, _vp(part), part.numel(), C.byref(nb), _stream()),
+                   "cdfo_metric_partials")
     # the kernel packs its partial sums as [N][nblocks]; fixed-order fp64 sum per frame
     return part.view(-1)[:N * nb.value].view(N, nb.value).sum(dim=1), H - 2 * crop, W - 2 * crop
 

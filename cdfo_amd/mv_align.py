@@ -64,8 +64,9 @@ class MVDualAttAlignment(ModulatedDeformConvPack):
         if self.in_channels != 64 or self.out_channels != 64:
             raise NotImplementedError("MVDualAttAlignment (HIP): specialised for 64 channels (arch.py:4242)")
         x = x.contiguous().float()
-        return self.forward_pm(x, K.nchw_to_nhwc(x), K.nchw_to_nhwc(extra_feat.float()), K.nchw_to_nhwc(pred_feat.float()),
-                               flow_1.contiguous().float())
+        with K.on_device(x):
+            return self.forward_pm(x, K.nchw_to_nhwc(x), K.nchw_to_nhwc(extra_feat.float()),
+                                   K.nchw_to_nhwc(pred_feat.float()), flow_1.contiguous().float())
 
     def forward_pm(self, x, xq, extra, pred, flow):
         """The same computation for callers that already hold pixel-major tensors (``CVSR_V7``): ``x`` NCHW (the DCN's

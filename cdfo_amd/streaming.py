@@ -123,8 +123,17 @@ class StreamingSR:
         ins = [x, m0, m1, p, r, u, self.fea.contiguous()] + ([] if noise is None else list(noise))
         if self._graph is None:
             st = [t.clone() for t in ins]
-            call = lambda: self.model(st[0], st[1], st[2], st[3], st[4], st[5], st[6],
+            # no host synchronisation may happen inside a captured forward: the fp16 range guard (a readback) is off for the
+            # captured step (the eager first frame of the sequence ran with it).  With noise=None the Philox key of the mask
+            # kernels is a launch argument and therefore frozen into the graph: every replay draws the same uniforms.
+            def call():
+                guard = getattr(self.model, "range_guard", False)
+                self.model.range_guard = False
+                try:
+                    return self.model(st[0], st[1], st[2], st[3], st[4], st[5], st[6],
                                       gumbel_uniform=None if noise is None else st[7:])
+                finally:
+                    self.model.range_guard = guard
             side = torch.cuda.Stream(self.dev)
             side.wait_stream(torch.cuda.current_stream(self.dev))
             with torch.cuda.stream(side), torch.no_grad():          # warm-up on a side stream, as graph capture requires

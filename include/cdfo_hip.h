@@ -123,6 +123,9 @@ int cdfo_nchw_to_nhwc(const float* in, float* out, int B, int C, int H, int W, i
 int cdfo_nhwc_to_nchw(const float* in, int ldi, float* out, int B, int C, int H, int W, void* stream);
 /* out[n][b] = in[b][n] for blocks of `block` floats (clip-major <-> frame-major feature stacks).  */
 int cdfo_swap_outer(const float* in, float* out, int B, int N, long long block, void* stream);
+/* Range probe of a dense fp32 buffer (n % 4 == 0): slots2[0] = max |x| over the finite elements (as the bit pattern of a
+ * float, combined by atomicMax), slots2[1] |= 1 if any element is NaN / infinite.  Caller zeroes the two words. */
+int cdfo_range_probe(const float* x, long long n, void* slots2, void* stream);
 
 /* ---- bandwidth-bound pixel-major kernels (pointwise.hip) ------------------------------------------------- */
 /* 3x3 conv 1 -> 64 channels on a single-channel plane [B][H][W] (image pitch img_bstride floats); raw OIHW weight
@@ -179,6 +182,12 @@ int cdfo_vec_mlp(const float* sum_partial, int nchunk, long long P, const float*
 /* noise: the uniform draws of arch.py:2169 as [B][64][H*W]. */
 int cdfo_rdab_prep(const float* xq, int ldx, const float* vmax, const float* noise, const float* wW, const float* bW,
                    int B, long long P, float* sq, int lds_, float* vrow, int ldv, float* qwin, int ldw, void* stream);
+/* The same with the uniform draws generated inside the kernel (Philox4x32-10 keyed by seed, `draw` = index of the call
+ * within the forward): the reference's default behaviour, torch.rand_like at arch.py:2169, without the 256 B/pixel noise
+ * tensor.  noise_out: optional [B][64][H*W] copy of the drawn values (parity tests replay them through the oracle). */
+int cdfo_rdab_prep_rng(const float* xq, int ldx, const float* vmax, long long seed, int draw, float* noise_out,
+                       const float* wW, const float* bW, int B, long long P, float* sq, int lds_, float* vrow, int ldv,
+                       float* qwin, int ldw, void* stream);
 int cdfo_colconv9(const float* in, int ldi, const float* wH, const float* bH, int B, int H, int W, float* out, int ldo,
                   void* stream);
 /* Evaluation metrics on the device (metric/psnr_ssim.py:278-317 calculate_psnr, :320-399 _ssim / calculate_ssim): fp64

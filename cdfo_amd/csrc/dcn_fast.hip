@@ -333,13 +333,13 @@ int cdfo_dcn_forward_fast(const float* in, const float* offset, const float* mas
                      CCH, nchunks, S);
   FastArgs a{gp, offset, mask, bias, out, reinterpret_cast<const h8*>(whi), reinterpret_cast<const h8*>(wlo), scale,
              B, C, H, W, Co, Ho, Wo, kh, kw, sh, sw, ph, pw, dh, dw, dg, CCH, nchunks, S};
-  static CdfoAttrOnce once1, once2;            // the attribute is set to the CU's whole LDS once per device
+  static CdfoAttrOnce once1, once2;            // set once per device to the CU's LDS minus the kernel's 512 B of static tables
   dim3 grid(cdiv(Ho * Wo, 64), B);
   if (MT <= 2) {
-    if (cdfo_set_max_lds(once1, reinterpret_cast<const void*>(&dcn_fast_kernel<1>), 160 * 1024) != hipSuccess) return 2 + (int)hipErrorInvalidValue;
+    if (cdfo_set_max_lds(once1, reinterpret_cast<const void*>(&dcn_fast_kernel<1>), 160 * 1024 - 1024) != hipSuccess) return 2 + (int)hipErrorInvalidValue;
     hipLaunchKernelGGL(dcn_fast_kernel<1>, grid, dim3(512), lds, st, a);
   } else {
-    if (cdfo_set_max_lds(once2, reinterpret_cast<const void*>(&dcn_fast_kernel<2>), 160 * 1024) != hipSuccess) return 2 + (int)hipErrorInvalidValue;
+    if (cdfo_set_max_lds(once2, reinterpret_cast<const void*>(&dcn_fast_kernel<2>), 160 * 1024 - 1024) != hipSuccess) return 2 + (int)hipErrorInvalidValue;
     hipLaunchKernelGGL(dcn_fast_kernel<2>, grid, dim3(512), lds, st, a);
   }
   hipError_t e = hipGetLastError();

@@ -25,14 +25,24 @@ from .kernels import _stream, on_device
 EXACT_FP32 = os.environ.get("CDFO_DCN_EXACT", "0") not in ("", "0")
 
 
-def _check_cuda_f32(*ts):
+_DTYPES = {torch.float32: 0, torch.float16: 1, torch.float64: 2}     # CDFO_DTYPE_* of include/cdfo_hip.h
+
+
+def _check_cuda(*ts):
+    """Device tensors of ONE of the reference's three dtypes (AT_DISPATCH_FLOATING_TYPES_AND_HALF,
+    deform_conv_cuda_kernel.cu:258): returns the library's dtype tag."""
+    dt = None
     for t in ts:
         if t is None:
             continue
         if not t.is_cuda:
             raise NotImplementedError("deform_conv_cuda (HIP): CPU tensors are not supported")
-        if t.dtype != torch.float32:
-            raise NotImplementedError("deform_conv_cuda (HIP): fp32 only in this round")
+        if t.dtype not in _DTYPES:
+            raise RuntimeError(f'"deform_conv" not implemented for \'{t.dtype}\' (float, double and half are)')
+        if dt is not None and t.dtype != dt:
+            raise RuntimeError(f"expected scalar type {dt} but found {t.dtype}")
+        dt = t.dtype
+    return _DTYPES[dt]
 
 
 def _fwd(input, weight, bias, offset, mask, output, kh, kw, sh, sw, ph, pw, dh, dw, group, dg):
@@ -40,7 +50,7 @@ def _fwd(input, weight, bias, offset, mask, output, kh, kw, sh, sw, ph, pw, dh, 
         raise RuntimeError("input tensor has to be contiguous")      # cpp:493
     if not weight.is_contiguous():
         raise RuntimeError("weight tensor has to be contiguous")     # cpp:494
-    _check_cuda_f32(input, weight, bias, offset, mask, output)
+    dt = _check_cuda(input, weight, bias, offset, mask, output)
     B, Cc, H, W = input.shape
     Co, Ck, kh_, kw_ = weight.shape
     if (kh_, kw_) != (kh, kw):
@@ -57,19 +67,22 @@ def _fwd(input, weight, bias, offset, mask, output, kh, kw, sh, sw, ph, pw, dh, 
         raise RuntimeError("output must be a contiguous tensor of B*Co*Ho*Wo elements")
     offset = offset.contiguous()
     mask = None if mask is None else mask.contiguous()
+    bias = None if bias is None else bias.contiguous()
     p = lambda t: C.c_void_p(None if t is None else t.data_ptr())  # noqa: E731
+    L = _lib.lib()
     with on_device(input):
-        # device scratch (plumbing, no arithmetic): what the fast kernel asks for, else room for a group-planar copy of
-        # `input`.  EXACT_FP32: the fast kernel's request is withheld, so the library takes its exact-fp32 kernel.
-        fast = 0 if EXACT_FP32 else int(_lib.lib().cdfo_dcn_workspace_bytes(B, Cc, H, W, Co, kh, kw, group, dg))
-        nbytes = max(fast, input.numel() * 4)
-        if EXACT_FP32:
-            nbytes = input.numel() * 4          # < the fast path's request whenever that path applies
-        ws = torch.empty(nbytes, dtype=torch.uint8, device=input.device)
-        _lib.check(_lib.lib().cdfo_dcn_forward(p(input), p(offset), p(mask), p(weight), p(bias), p(output), B, Cc, H, W,
-                                               Co, kh, kw, sh, sw, ph, pw, dh, dw, group, dg, p(ws),
-                                               C.c_longlong(nbytes), _stream()),
-                   "cdfo_dcn_forward")
+        # device scratch (plumbing, no arithmetic): what the library asks for these shapes -- the fast kernel's packed
+        # operands / the group-planar copy of `input` (fp32), plus the widened operands (half).  EXACT_FP32: only the
+        # group-planar copy is offered, which is less than the fast kernel wants, so the exact-fp32 kernel runs.
+        nbytes = int(L.cdfo_dcn_workspace_bytes_dt(dt, 0, B, Cc, H, W, Co, kh, kw, sh, sw, ph, pw, dh, dw, group, dg))
+        if nbytes < 0:
+            raise RuntimeError("deform_conv_cuda (HIP): unsupported shape")
+        if EXACT_FP32 and dt == 0:
+            nbytes = input.numel() * 4
+        ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=input.device)
+        _lib.check(L.cdfo_dcn_forward_dt(dt, p(input), p(offset), p(mask), p(weight), p(bias), p(output), B, Cc, H, W,
+                                         Co, kh, kw, sh, sw, ph, pw, dh, dw, group, dg, p(ws), C.c_longlong(nbytes),
+                                         _stream()), "cdfo_dcn_forward_dt")
 
 
 def deform_conv_forward_cuda(input, weight, offset, output, columns, ones, kW, kH, dW, dH, padW, padH, dilationW,
@@ -94,7 +107,7 @@ def _bwd(input, offset, mask, weight, grad_output, grad_input, grad_offset, grad
         raise RuntimeError("input tensor has to be contiguous")      # cpp:574
     if not weight.is_contiguous():
         raise RuntimeError("weight tensor has to be contiguous")     # cpp:575
-    _check_cuda_f32(input, offset, mask, weight, grad_output, grad_input, grad_offset, grad_mask, grad_weight, grad_bias)
+    dt = _check_cuda(input, offset, mask, weight, grad_output, grad_input, grad_offset, grad_mask, grad_weight, grad_bias)
     B, Cc, H, W = input.shape
     Co, Ck, kh_, kw_ = weight.shape
     if (kh_, kw_) != (kh, kw):
@@ -118,11 +131,16 @@ def _bwd(input, offset, mask, weight, grad_output, grad_input, grad_offset, grad
     offset, grad_output = offset.contiguous(), grad_output.contiguous()
     mask = None if mask is None else mask.contiguous()
     p = lambda t: C.c_void_p(None if t is None else t.data_ptr())  # noqa: E731
+    L = _lib.lib()
     with on_device(input):
-        _lib.check(_lib.lib().cdfo_dcn_backward(p(input), p(offset), p(mask), p(weight), p(grad_output), p(grad_input),
-                                                p(grad_offset), p(grad_mask), p(grad_weight), p(grad_bias), B, Cc, H, W,
-                                                Co, kh, kw, sh, sw, ph, pw, dh, dw, group, dg, float(scale), _stream()),
-                   "cdfo_dcn_backward")
+        nbytes = int(L.cdfo_dcn_workspace_bytes_dt(dt, 1, B, Cc, H, W, Co, kh, kw, sh, sw, ph, pw, dh, dw, group, dg))
+        if nbytes < 0:
+            raise RuntimeError("deform_conv_cuda (HIP): unsupported shape")
+        ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=input.device)
+        _lib.check(L.cdfo_dcn_backward_dt(dt, p(input), p(offset), p(mask), p(weight), p(grad_output), p(grad_input),
+                                          p(grad_offset), p(grad_mask), p(grad_weight), p(grad_bias), B, Cc, H, W, Co,
+                                          kh, kw, sh, sw, ph, pw, dh, dw, group, dg, float(scale), p(ws),
+                                          C.c_longlong(nbytes), _stream()), "cdfo_dcn_backward_dt")
 
 
 def deform_conv_backward_input_cuda(input, offset, gradOutput, gradInput, gradOffset, weight, columns, kW, kH, dW, dH,

@@ -25,6 +25,7 @@ extern "C" {
 
 enum { CDFO_ACT_NONE = 0, CDFO_ACT_LRELU = 1, CDFO_ACT_RELU = 2, CDFO_ACT_SIGMOID = 3 };
 enum { CDFO_STORE_PLAIN = 0, CDFO_STORE_SHUFFLE2 = 1, CDFO_STORE_S2D = 2, CDFO_STORE_TAPS9 = 3 };
+enum { CDFO_DTYPE_F32 = 0, CDFO_DTYPE_F16 = 1, CDFO_DTYPE_F64 = 2 };   /* element type tag of the *_dt entry points */
 enum { CDFO_PREC_F32 = 0, CDFO_PREC_BF16X3 = 1, CDFO_PREC_BF16 = 2, CDFO_PREC_FP16X2 = 3, CDFO_PREC_FP16 = 4, CDFO_PREC_FP16X1 = 5 };
 
 /* ABI version / build info.  */
@@ -252,6 +253,25 @@ int cdfo_dcn_backward(const float* in, const float* offset, const float* mask, c
                       const float* grad_out, float* grad_in, float* grad_offset, float* grad_mask, float* grad_weight,
                       float* grad_bias, int B, int C, int H, int W, int Co, int kh, int kw, int sh, int sw, int ph,
                       int pw, int dh, int dw, int groups, int deformable_groups, float scale, void* stream);
+
+/* ---- the operator's other dtypes (dcn_typed.hip) --------------------------------------------------------------
+ * The reference instantiates its kernels for float, double and half (AT_DISPATCH_FLOATING_TYPES_AND_HALF,
+ * ops/dcn/src/deform_conv_cuda_kernel.cu:258,352,450,780,812,845).  Same tensors and conventions as cdfo_dcn_forward /
+ * cdfo_dcn_backward with elements of `dtype` (CDFO_DTYPE_*): F32 forwards to those; F16 = fp16 tensors, fp32 arithmetic
+ * (operands widened into `workspace`, the fp32 kernels run, results narrowed once; accumulating gradients are added to the
+ * fp16 tensors); F64 = fp64 VALU kernels, fp64 atomics (correctness-first).  `workspace` must hold
+ * cdfo_dcn_workspace_bytes_dt(...) bytes, 16-byte aligned (`backward` = 0 / 1; F64 needs none; returns -1 on bad shapes). */
+long long cdfo_dcn_workspace_bytes_dt(int dtype, int backward, int B, int C, int H, int W, int Co, int kh, int kw, int sh,
+                                      int sw, int ph, int pw, int dh, int dw, int groups, int deformable_groups);
+int cdfo_dcn_forward_dt(int dtype, const void* in, const void* offset, const void* mask, const void* weight,
+                        const void* bias, void* out, int B, int C, int H, int W, int Co, int kh, int kw, int sh, int sw,
+                        int ph, int pw, int dh, int dw, int groups, int deformable_groups, void* workspace,
+                        long long workspace_bytes, void* stream);
+int cdfo_dcn_backward_dt(int dtype, const void* in, const void* offset, const void* mask, const void* weight,
+                         const void* grad_out, void* grad_in, void* grad_offset, void* grad_mask, void* grad_weight,
+                         void* grad_bias, int B, int C, int H, int W, int Co, int kh, int kw, int sh, int sw, int ph, int pw,
+                         int dh, int dw, int groups, int deformable_groups, float scale, void* workspace,
+                         long long workspace_bytes, void* stream);
 
 /* ---- pixel-local operators of the CVSR_V7 forward (v7_ops.hip) ---------------------------
  * fp32 pixel-major activations [B,H,W,64] with pitch ld (floats).

@@ -31,16 +31,21 @@ def _dcn_lib():
         _lib.dcn_forward_ref.argtypes = [C.c_void_p] * 6 + [C.c_int] * 15
         _lib.dcn_backward_ref.restype = C.c_int
         _lib.dcn_backward_ref.argtypes = [C.c_void_p] * 10 + [C.c_int] * 15 + [C.c_float]
+        _lib.dcn_forward_ref_f64.restype = C.c_int
+        _lib.dcn_forward_ref_f64.argtypes = [C.c_void_p] * 6 + [C.c_int] * 15
+        _lib.dcn_backward_ref_f64.restype = C.c_int
+        _lib.dcn_backward_ref_f64.argtypes = [C.c_void_p] * 10 + [C.c_int] * 15 + [C.c_double]
     return _lib
 
 
-def dcn_forward_ref(x, offset, mask, weight, bias, stride=1, pad=0, dil=1, groups=1, dg=1):
-    """numpy fp32 arrays in the reference's layouts -> output [B,Co,Ho,Wo] (DCNv1 when mask is None)."""
-    x = np.ascontiguousarray(x, np.float32)
-    offset = np.ascontiguousarray(offset, np.float32)
-    weight = np.ascontiguousarray(weight, np.float32)
-    mask = None if mask is None else np.ascontiguousarray(mask, np.float32)
-    bias = None if bias is None else np.ascontiguousarray(bias, np.float32)
+def dcn_forward_ref(x, offset, mask, weight, bias, stride=1, pad=0, dil=1, groups=1, dg=1, dtype=np.float32):
+    """numpy arrays in the reference's layouts -> output [B,Co,Ho,Wo] (DCNv1 when mask is None); dtype float32 (default)
+    or float64 (the C oracle's double instantiation)."""
+    x = np.ascontiguousarray(x, dtype)
+    offset = np.ascontiguousarray(offset, dtype)
+    weight = np.ascontiguousarray(weight, dtype)
+    mask = None if mask is None else np.ascontiguousarray(mask, dtype)
+    bias = None if bias is None else np.ascontiguousarray(bias, dtype)
     B, Cc, H, W = x.shape
     Co, _, kh, kw = weight.shape
     sh, sw = (stride, stride) if isinstance(stride, int) else stride
@@ -48,20 +53,22 @@ def dcn_forward_ref(x, offset, mask, weight, bias, stride=1, pad=0, dil=1, group
     dh, dw = (dil, dil) if isinstance(dil, int) else dil
     Ho = (H + 2 * ph - (dh * (kh - 1) + 1)) // sh + 1
     Wo = (W + 2 * pw - (dw * (kw - 1) + 1)) // sw + 1
-    out = np.empty((B, Co, Ho, Wo), np.float32)
+    out = np.empty((B, Co, Ho, Wo), dtype)
     p = lambda a: None if a is None else a.ctypes.data  # noqa: E731
-    rc = _dcn_lib().dcn_forward_ref(p(x), p(offset), p(mask), p(weight), p(bias), p(out), B, Cc, H, W, Co, kh, kw, sh, sw,
+    fn = _dcn_lib().dcn_forward_ref if dtype == np.float32 else _dcn_lib().dcn_forward_ref_f64
+    rc = fn(p(x), p(offset), p(mask), p(weight), p(bias), p(out), B, Cc, H, W, Co, kh, kw, sh, sw,
                                     ph, pw, dh, dw, groups, dg)
     if rc != 0:
         raise ValueError("dcn_forward_ref rejected the shapes")
     return out
 
 
-def dcn_backward_ref(x, offset, mask, weight, gout, stride=1, pad=0, dil=1, groups=1, dg=1, scale=1.0, with_bias=True):
+def dcn_backward_ref(x, offset, mask, weight, gout, stride=1, pad=0, dil=1, groups=1, dg=1, scale=1.0, with_bias=True,
+                     dtype=np.float32):
     """numpy fp32 arrays -> dict(grad_input, grad_offset, grad_mask (DCNv2 only), grad_weight, grad_bias) computed by
     oracle/dcn_ref.c:dcn_backward_ref from zero-initialised gradients, as the reference's autograd Functions do
     (ops/dcn/deform_conv.py:60-99, 150-172)."""
-    f = lambda a: None if a is None else np.ascontiguousarray(a, np.float32)  # noqa: E731
+    f = lambda a: None if a is None else np.ascontiguousarray(a, dtype)  # noqa: E731
     x, offset, mask, weight, gout = f(x), f(offset), f(mask), f(weight), f(gout)
     B, Cc, H, W = x.shape
     Co, _, kh, kw = weight.shape
@@ -72,9 +79,10 @@ def dcn_backward_ref(x, offset, mask, weight, gout, stride=1, pad=0, dil=1, grou
     if mask is not None:
         g["grad_mask"] = np.zeros_like(mask)
     if with_bias:
-        g["grad_bias"] = np.zeros((Co,), np.float32)
+        g["grad_bias"] = np.zeros((Co,), dtype)
     p = lambda a: None if a is None else a.ctypes.data  # noqa: E731
-    rc = _dcn_lib().dcn_backward_ref(p(x), p(offset), p(mask), p(weight), p(gout), p(g["grad_input"]), p(g["grad_offset"]),
+    fn = _dcn_lib().dcn_backward_ref if dtype == np.float32 else _dcn_lib().dcn_backward_ref_f64
+    rc = fn(p(x), p(offset), p(mask), p(weight), p(gout), p(g["grad_input"]), p(g["grad_offset"]),
                                      p(g.get("grad_mask")), p(g["grad_weight"]), p(g.get("grad_bias")), B, Cc, H, W, Co,
                                      kh, kw, sh, sw, ph, pw, dh, dw, groups, dg, float(scale))
     if rc != 0:

@@ -18,11 +18,19 @@
 #include <stdlib.h>
 #include <string.h>
 
-static float bilinear(const float* im, int H, int W, float h, float w) {
-  int h_low = (int)floorf(h), w_low = (int)floorf(w);
+/* One source, two element types: compiled as is for float (the reference's default dtype) and, through dcn_ref_f64.c,
+ * for double (the reference instantiates its kernels for float, double and half: deform_conv_cuda_kernel.cu:258). */
+#ifndef REAL
+#define REAL float
+#define NAME(x) x
+#define FLOOR_ floorf
+#endif
+
+static REAL NAME(bilinear)(const REAL* im, int H, int W, REAL h, REAL w) {
+  int h_low = (int)FLOOR_(h), w_low = (int)FLOOR_(w);
   int h_high = h_low + 1, w_high = w_low + 1;
-  float lh = h - h_low, lw = w - w_low, hh = 1 - lh, hw = 1 - lw;
-  float v1 = 0, v2 = 0, v3 = 0, v4 = 0;
+  REAL lh = h - h_low, lw = w - w_low, hh = 1 - lh, hw = 1 - lw;
+  REAL v1 = 0, v2 = 0, v3 = 0, v4 = 0;
   if (h_low >= 0 && w_low >= 0) v1 = im[h_low * W + w_low];
   if (h_low >= 0 && w_high <= W - 1) v2 = im[h_low * W + w_high];
   if (h_high <= H - 1 && w_low >= 0) v3 = im[h_high * W + w_low];
@@ -31,32 +39,32 @@ static float bilinear(const float* im, int H, int W, float h, float w) {
 }
 
 /* mask == NULL -> DCNv1 (no modulation); bias == NULL -> no bias.  Returns 0, or -1 on a bad shape. */
-int dcn_forward_ref(const float* in, const float* offset, const float* mask, const float* weight, const float* bias,
-                    float* out, int B, int C, int H, int W, int Co, int kh, int kw, int sh, int sw, int ph, int pw,
+int NAME(dcn_forward_ref)(const REAL* in, const REAL* offset, const REAL* mask, const REAL* weight, const REAL* bias,
+                    REAL* out, int B, int C, int H, int W, int Co, int kh, int kw, int sh, int sw, int ph, int pw,
                     int dh, int dw, int groups, int dg) {
   if (C % groups || Co % groups || C % dg) return -1;
   const int Ho = (H + 2 * ph - (dh * (kh - 1) + 1)) / sh + 1;
   const int Wo = (W + 2 * pw - (dw * (kw - 1) + 1)) / sw + 1;
   if (Ho <= 0 || Wo <= 0) return -1;
   const int T = kh * kw, P = Ho * Wo, Cg = C / groups, Cog = Co / groups, Cdg = C / dg;
-  float* col = (float*)malloc(sizeof(float) * (size_t)C * T * P); /* the reference's `columns` buffer */
+  REAL* col = (REAL*)malloc(sizeof(REAL) * (size_t)C * T * P); /* the reference's `columns` buffer */
   if (!col) return -1;
   for (int b = 0; b < B; ++b) {
     for (int c = 0; c < C; ++c) {
       const int d = c / Cdg;
-      const float* im = in + ((size_t)b * C + c) * H * W;
-      const float* off = offset + ((size_t)b * dg + d) * 2 * T * P;
-      const float* msk = mask ? mask + ((size_t)b * dg + d) * T * P : NULL;
+      const REAL* im = in + ((size_t)b * C + c) * H * W;
+      const REAL* off = offset + ((size_t)b * dg + d) * 2 * T * P;
+      const REAL* msk = mask ? mask + ((size_t)b * dg + d) * T * P : NULL;
       for (int i = 0; i < kh; ++i)
         for (int j = 0; j < kw; ++j) {
           const int t = i * kw + j;
           for (int ho = 0; ho < Ho; ++ho)
             for (int wo = 0; wo < Wo; ++wo) {
               const int p = ho * Wo + wo;
-              const float h_im = (float)(ho * sh - ph + i * dh) + off[(size_t)(2 * t) * P + p];
-              const float w_im = (float)(wo * sw - pw + j * dw) + off[(size_t)(2 * t + 1) * P + p];
-              float v = 0.f;
-              if (h_im > -1 && w_im > -1 && h_im < H && w_im < W) v = bilinear(im, H, W, h_im, w_im);
+              const REAL h_im = (REAL)(ho * sh - ph + i * dh) + off[(size_t)(2 * t) * P + p];
+              const REAL w_im = (REAL)(wo * sw - pw + j * dw) + off[(size_t)(2 * t + 1) * P + p];
+              REAL v = 0.f;
+              if (h_im > -1 && w_im > -1 && h_im < H && w_im < W) v = NAME(bilinear)(im, H, W, h_im, w_im);
               if (msk) v *= msk[(size_t)t * P + p];
               col[((size_t)c * T + t) * P + p] = v;
             }
@@ -65,12 +73,12 @@ int dcn_forward_ref(const float* in, const float* offset, const float* mask, con
     for (int g = 0; g < groups; ++g)
       for (int o = 0; o < Cog; ++o) {
         const int oc = g * Cog + o;
-        const float* wr = weight + (size_t)oc * Cg * T;
-        float* orow = out + ((size_t)b * Co + oc) * P;
+        const REAL* wr = weight + (size_t)oc * Cg * T;
+        REAL* orow = out + ((size_t)b * Co + oc) * P;
         for (int p = 0; p < P; ++p) {
           double s = 0.0;
           for (int k = 0; k < Cg * T; ++k) s += (double)wr[k] * (double)col[((size_t)g * Cg * T + k) * P + p];
-          orow[p] = (float)s + (bias ? bias[oc] : 0.f);
+          orow[p] = (REAL)s + (bias ? bias[oc] : 0.f);
         }
       }
   }
@@ -90,19 +98,19 @@ int dcn_forward_ref(const float* in, const float* offset, const float* mask, con
  *                                              0 when the sample lies at or beyond -1 / H / W)
  *   ops/dcn/src/deform_conv_cuda_kernel.cu:525-567 / 143-187   coordinate weight (d sample / d h, d sample / d w)
  *   ops/dcn/src/deform_conv_cuda_kernel.cu:634-766             col2im and col2im_coord loops
- * The reference holds no vector for the backward; tests/test_dcn_oracle.py pins this restatement against float64
+ * The reference holds no vector for the backward; tests/test_dcn_oracle.py pins this restatement against REAL64
  * autograd through an independent gather-based statement of the forward.
  * Any of gin / goff / gmask / gw / gbias may be NULL (skipped).  gin, gw, gbias are ACCUMULATED into (the reference's
  * callers zero them first, deform_conv.py:71-72,85,154-158); goff, gmask are assigned. */
-int dcn_backward_ref(const float* in, const float* offset, const float* mask, const float* weight, const float* gout,
-                     float* gin, float* goff, float* gmask, float* gw, float* gbias, int B, int C, int H, int W, int Co,
-                     int kh, int kw, int sh, int sw, int ph, int pw, int dh, int dw, int groups, int dg, float scale) {
+int NAME(dcn_backward_ref)(const REAL* in, const REAL* offset, const REAL* mask, const REAL* weight, const REAL* gout,
+                     REAL* gin, REAL* goff, REAL* gmask, REAL* gw, REAL* gbias, int B, int C, int H, int W, int Co,
+                     int kh, int kw, int sh, int sw, int ph, int pw, int dh, int dw, int groups, int dg, REAL scale) {
   if (C % groups || Co % groups || C % dg) return -1;
   const int Ho = (H + 2 * ph - (dh * (kh - 1) + 1)) / sh + 1;
   const int Wo = (W + 2 * pw - (dw * (kw - 1) + 1)) / sw + 1;
   if (Ho <= 0 || Wo <= 0) return -1;
   const int T = kh * kw, P = Ho * Wo, Cg = C / groups, Cog = Co / groups, Cdg = C / dg;
-  float* col = (float*)malloc(sizeof(float) * (size_t)C * T * P);
+  REAL* col = (REAL*)malloc(sizeof(REAL) * (size_t)C * T * P);
   if (!col) return -1;
   for (int b = 0; b < B; ++b) {
     /* columns[g] = weight[g]^T x grad_output[b][g]   (cpp:617-620) */
@@ -113,40 +121,40 @@ int dcn_backward_ref(const float* in, const float* offset, const float* mask, co
           double s = 0.0;
           for (int o = 0; o < Cog; ++o)
             s += (double)weight[((size_t)(g * Cog + o) * Cg + cl) * T + t] * (double)gout[((size_t)b * Co + g * Cog + o) * P + p];
-          col[((size_t)c * T + t) * P + p] = (float)s;
+          col[((size_t)c * T + t) * P + p] = (REAL)s;
         }
     }
     for (int d = 0; d < dg; ++d) {
-      const float* off = offset + ((size_t)b * dg + d) * 2 * T * P;
-      const float* msk = mask ? mask + ((size_t)b * dg + d) * T * P : NULL;
+      const REAL* off = offset + ((size_t)b * dg + d) * 2 * T * P;
+      const REAL* msk = mask ? mask + ((size_t)b * dg + d) * T * P : NULL;
       for (int i = 0; i < kh; ++i)
         for (int j = 0; j < kw; ++j) {
           const int t = i * kw + j;
           for (int ho = 0; ho < Ho; ++ho)
             for (int wo = 0; wo < Wo; ++wo) {
               const int p = ho * Wo + wo;
-              const float h_im = (float)(ho * sh - ph + i * dh) + off[(size_t)(2 * t) * P + p];
-              const float w_im = (float)(wo * sw - pw + j * dw) + off[(size_t)(2 * t + 1) * P + p];
-              const float m = msk ? msk[(size_t)t * P + p] : 1.f;
+              const REAL h_im = (REAL)(ho * sh - ph + i * dh) + off[(size_t)(2 * t) * P + p];
+              const REAL w_im = (REAL)(wo * sw - pw + j * dw) + off[(size_t)(2 * t + 1) * P + p];
+              const REAL m = msk ? msk[(size_t)t * P + p] : 1.f;
               const int valid = !(h_im <= -1 || w_im <= -1 || h_im >= H || w_im >= W);
-              float vh = 0.f, vw = 0.f, mv = 0.f;
+              REAL vh = 0.f, vw = 0.f, mv = 0.f;
               if (valid) {
-                const int hl = (int)floorf(h_im), wl = (int)floorf(w_im), hhi = hl + 1, whi = wl + 1;
-                const float lh = h_im - hl, lw = w_im - wl, hh = 1 - lh, hw = 1 - lw;
+                const int hl = (int)FLOOR_(h_im), wl = (int)FLOOR_(w_im), hhi = hl + 1, whi = wl + 1;
+                const REAL lh = h_im - hl, lw = w_im - wl, hh = 1 - lh, hw = 1 - lw;
                 const int c1 = hl >= 0 && wl >= 0, c2 = hl >= 0 && whi <= W - 1, c3 = hhi <= H - 1 && wl >= 0,
                           c4 = hhi <= H - 1 && whi <= W - 1;
                 for (int cc = 0; cc < Cdg; ++cc) {
                   const int c = d * Cdg + cc;
-                  const float* im = in + ((size_t)b * C + c) * H * W;
-                  const float cg = col[((size_t)c * T + t) * P + p];
-                  const float v1 = c1 ? im[hl * W + wl] : 0.f, v2 = c2 ? im[hl * W + whi] : 0.f,
+                  const REAL* im = in + ((size_t)b * C + c) * H * W;
+                  const REAL cg = col[((size_t)c * T + t) * P + p];
+                  const REAL v1 = c1 ? im[hl * W + wl] : 0.f, v2 = c2 ? im[hl * W + whi] : 0.f,
                               v3 = c3 ? im[hhi * W + wl] : 0.f, v4 = c4 ? im[hhi * W + whi] : 0.f;
                   mv += cg * (hh * hw * v1 + hh * lw * v2 + lh * hw * v3 + lh * lw * v4);       /* cu:733-736 */
                   vh += (-hw * v1 - lw * v2 + hw * v3 + lw * v4) * cg * m;                       /* cu:543-553 */
                   vw += (-hh * v1 + hh * v2 - lh * v3 + lh * v4) * cg * m;                       /* cu:554-564 */
                   if (gin) {                                                                     /* cu:667-683 */
-                    float* gi = gin + ((size_t)b * C + c) * H * W;
-                    const float tg = cg * m;
+                    REAL* gi = gin + ((size_t)b * C + c) * H * W;
+                    const REAL tg = cg * m;
                     if (c1) gi[hl * W + wl] += hh * hw * tg;
                     if (c2) gi[hl * W + whi] += hh * lw * tg;
                     if (c3) gi[hhi * W + wl] += lh * hw * tg;
@@ -166,19 +174,19 @@ int dcn_backward_ref(const float* in, const float* offset, const float* mask, co
       /* im2col again (cpp:637-641), then grad_weight[g] += grad_output[b][g] x columns[g]^T (cpp:650-655) */
       for (int c = 0; c < C; ++c) {
         const int d = c / Cdg;
-        const float* im = in + ((size_t)b * C + c) * H * W;
-        const float* off = offset + ((size_t)b * dg + d) * 2 * T * P;
-        const float* msk = mask ? mask + ((size_t)b * dg + d) * T * P : NULL;
+        const REAL* im = in + ((size_t)b * C + c) * H * W;
+        const REAL* off = offset + ((size_t)b * dg + d) * 2 * T * P;
+        const REAL* msk = mask ? mask + ((size_t)b * dg + d) * T * P : NULL;
         for (int i = 0; i < kh; ++i)
           for (int j = 0; j < kw; ++j) {
             const int t = i * kw + j;
             for (int ho = 0; ho < Ho; ++ho)
               for (int wo = 0; wo < Wo; ++wo) {
                 const int p = ho * Wo + wo;
-                const float h_im = (float)(ho * sh - ph + i * dh) + off[(size_t)(2 * t) * P + p];
-                const float w_im = (float)(wo * sw - pw + j * dw) + off[(size_t)(2 * t + 1) * P + p];
-                float v = 0.f;
-                if (h_im > -1 && w_im > -1 && h_im < H && w_im < W) v = bilinear(im, H, W, h_im, w_im);
+                const REAL h_im = (REAL)(ho * sh - ph + i * dh) + off[(size_t)(2 * t) * P + p];
+                const REAL w_im = (REAL)(wo * sw - pw + j * dw) + off[(size_t)(2 * t + 1) * P + p];
+                REAL v = 0.f;
+                if (h_im > -1 && w_im > -1 && h_im < H && w_im < W) v = NAME(bilinear)(im, H, W, h_im, w_im);
                 if (msk) v *= msk[(size_t)t * P + p];
                 col[((size_t)c * T + t) * P + p] = v;
               }
@@ -186,18 +194,18 @@ int dcn_backward_ref(const float* in, const float* offset, const float* mask, co
       }
       for (int oc = 0; oc < Co; ++oc) {
         const int g = oc / Cog;
-        const float* go = gout + ((size_t)b * Co + oc) * P;
+        const REAL* go = gout + ((size_t)b * Co + oc) * P;
         if (gw)
           for (int k = 0; k < Cg * T; ++k) {
             double s = 0.0;
-            const float* cr = col + ((size_t)g * Cg * T + k) * P;
+            const REAL* cr = col + ((size_t)g * Cg * T + k) * P;
             for (int p = 0; p < P; ++p) s += (double)go[p] * (double)cr[p];
-            gw[(size_t)oc * Cg * T + k] += scale * (float)s;
+            gw[(size_t)oc * Cg * T + k] += scale * (REAL)s;
           }
         if (gbias) {
           double s = 0.0;
           for (int p = 0; p < P; ++p) s += go[p];
-          gbias[oc] += (float)s;
+          gbias[oc] += (REAL)s;
         }
       }
     }

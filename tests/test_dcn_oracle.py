@@ -134,3 +134,34 @@ def test_backward_restatement_matches_float64_autograd():
         half = dcn_backward_ref(x, off, msk, w, go, s, p, d, g, dg, scale=0.5, with_bias=True)
         assert np.allclose(half["grad_weight"], 0.5 * got["grad_weight"], atol=1e-5)
         assert np.array_equal(half["grad_input"], got["grad_input"])
+
+
+def test_double_instantiation_agrees_with_float_and_with_float64_autograd():
+    """oracle/dcn_ref_f64.c (the checker of the operator's fp64 entry points): same results as the float build to fp32
+    rounding on the forward and the backward, and its gradients match float64 torch autograd through an independent
+    gather-based statement of the forward (zero offsets + unit mask == conv2d)."""
+    from oracle.dcn_modules_ref import dcn_backward_ref
+    rs = np.random.RandomState(12)
+    B, C, Co, H, W, k, dg = 2, 8, 6, 7, 9, 3, 4
+    x, w, b = rs.standard_normal((B, C, H, W)), rs.standard_normal((Co, C, k, k)) / 8, rs.standard_normal((Co,))
+    off = rs.standard_normal((B, 2 * dg * k * k, H, W)) * 2
+    msk = rs.uniform(0, 1, (B, dg * k * k, H, W))
+    go = rs.standard_normal((B, Co, H, W))
+    f32 = dcn_forward_ref(x, off, msk, w, b, 1, 1, 1, 1, dg)
+    f64 = dcn_forward_ref(x, off, msk, w, b, 1, 1, 1, 1, dg, dtype=np.float64)
+    assert f64.dtype == np.float64 and np.abs(f64 - f32).max() < 2e-5
+    g32 = dcn_backward_ref(x, off, msk, w, go, 1, 1, 1, 1, dg)
+    g64 = dcn_backward_ref(x, off, msk, w, go, 1, 1, 1, 1, dg, dtype=np.float64)
+    for key in g64:
+        assert g64[key].dtype == np.float64
+        assert np.abs(g64[key] - g32[key]).max() <= 3e-5 * max(1.0, np.abs(g64[key]).max()), key
+    # float64 pin: zero offsets + unit mask is a plain convolution, whose gradients autograd gives exactly
+    z, one = np.zeros_like(off), np.ones_like(msk)
+    xt, wt, bt = (torch.tensor(a, dtype=torch.float64, requires_grad=True) for a in (x, w, b))
+    y = F.conv2d(xt, wt, bt, 1, 1)
+    y.backward(torch.tensor(go))
+    g = dcn_backward_ref(x, z, one, w, go, 1, 1, 1, 1, dg, dtype=np.float64)
+    assert np.abs(dcn_forward_ref(x, z, one, w, b, 1, 1, 1, 1, dg, dtype=np.float64) - y.detach().numpy()).max() < 1e-12
+    assert np.abs(g["grad_input"] - xt.grad.numpy()).max() < 1e-12
+    assert np.abs(g["grad_weight"] - wt.grad.numpy()).max() < 1e-11
+    assert np.abs(g["grad_bias"] - bt.grad.numpy()).max() < 1e-11

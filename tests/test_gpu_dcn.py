@@ -322,3 +322,62 @@ def test_dcn_random_shapes_forward_and_backward_through_the_cabi():
                 assert e <= 5e-5 * max(1.0, np.abs(ref_g).max()), (cfg, key, e)
         done += 1
     assert fast >= 3          # the sweep reaches the fast forward kernel too
+
+
+
+# ---- the operator's other dtypes (AT_DISPATCH_FLOATING_TYPES_AND_HALF, deform_conv_cuda_kernel.cu:258,780): the eight
+# CASES in half and double, forward and backward, against the C oracle (its float / double instantiations)
+@pytest.mark.parametrize("dtype", ["half", "double"])
+@pytest.mark.parametrize("B,C,Co,H,W,k,s,p,d,g,dg,mod", CASES)
+def test_dcn_dtypes_forward_and_backward_match_oracle(B, C, Co, H, W, k, s, p, d, g, dg, mod, dtype):
+    from cdfo_amd.dcn import deform_conv, modulated_deform_conv
+    from oracle.dcn_modules_ref import dcn_backward_ref
+    rs = np.random.RandomState(B * 1000 + C * 10 + Co + 7)
+    Ho = (H + 2 * p - (d * (k - 1) + 1)) // s + 1
+    Wo = (W + 2 * p - (d * (k - 1) + 1)) // s + 1
+    tdt, ndt = (torch.float16, np.float32) if dtype == "half" else (torch.float64, np.float64)
+    # values a half tensor represents exactly, so that both sides start from the same numbers
+    q = (lambda a: a.astype(np.float16).astype(ndt)) if dtype == "half" else (lambda a: a.astype(ndt))
+    x = q(rs.standard_normal((B, C, H, W)))
+    w = q(rs.standard_normal((Co, C // g, k, k)) / np.sqrt(C // g * k * k))
+    b = q(rs.standard_normal((Co,)))
+    off = q(rs.standard_normal((B, 2 * dg * k * k, Ho, Wo)) * 3.0)
+    msk = q(rs.uniform(0, 1, (B, dg * k * k, Ho, Wo)))
+    go = q(rs.standard_normal((B, Co, Ho, Wo)))
+    t = lambda a, rg=True: torch.from_numpy(a).to(tdt).cuda().requires_grad_(rg)  # noqa: E731
+    tx, tw, tb, toff, tm = t(x), t(w), t(b), t(off), t(msk)
+    if mod:
+        out = modulated_deform_conv(tx, toff, tm, tw, tb, s, p, d, g, dg)
+        ref = dcn_forward_ref(x, off, msk, w, b, s, p, d, g, dg, dtype=ndt)
+        gref = dcn_backward_ref(x, off, msk, w, go, s, p, d, g, dg, dtype=ndt)
+    else:
+        out = deform_conv(tx, toff, tw, s, p, d, g, dg)
+        ref = dcn_forward_ref(x, off, None, w, None, s, p, d, g, dg, dtype=ndt)
+        gref = dcn_backward_ref(x, off, None, w, go, s, p, d, g, dg, with_bias=False, dtype=ndt)
+    assert out.dtype == tdt and tuple(out.shape) == ref.shape
+    out.backward(torch.from_numpy(go).to(tdt).cuda())
+    torch.cuda.synchronize()
+    # half: one rounding of the fp32 result to half (2^-11 relative) on top of the fp32 kernels' own error; double: fp64
+    rel = 1.5e-3 if dtype == "half" else 1e-11
+    scale = max(1.0, float(np.abs(ref).max()))
+    assert np.abs(out.detach().double().cpu().numpy() - ref).max() <= rel * scale
+    got = {"grad_input": tx.grad, "grad_offset": toff.grad, "grad_weight": tw.grad}
+    if mod:
+        got["grad_mask"], got["grad_bias"] = tm.grad, tb.grad
+    for key, gt in got.items():
+        assert gt is not None and gt.dtype == tdt, key
+        want = gref[key]
+        e = np.abs(gt.double().cpu().numpy() - want).max()
+        assert e <= rel * max(1.0, float(np.abs(want).max())), (key, e)
+
+
+def test_dcn_rejects_mixed_and_unsupported_dtypes():
+    from cdfo_amd.dcn import modulated_deform_conv
+    x = torch.randn(1, 4, 6, 6, device="cuda")
+    w = torch.randn(4, 4, 3, 3, device="cuda")
+    off = torch.zeros(1, 18, 6, 6, device="cuda")
+    m = torch.ones(1, 9, 6, 6, device="cuda")
+    with pytest.raises(RuntimeError):
+        modulated_deform_conv(x.double(), off, m, w, None, 1, 1, 1, 1, 1)          # mixed float / double
+    with pytest.raises(RuntimeError):
+        modulated_deform_conv(x.bfloat16(), off.bfloat16(), m.bfloat16(), w.bfloat16(), None, 1, 1, 1, 1, 1)   # no bf16 (cu:258)

@@ -14,7 +14,7 @@ import os
 import torch  # noqa: F401,E402
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libcdfo_hip.so")
+LIB_PATH = os.environ.get("CDFO_LIB_PATH") or os.path.join(_HERE, "lib", "libcdfo_hip.so")   # (env: developer A/B builds)
 
 _lib = None
 

@@ -47,6 +47,18 @@ static inline hipError_t cdfo_set_max_lds(CdfoAttrOnce& once, const void* func, 
   return e;
 }
 
+// the same for kernels whose dynamic LDS size depends on the shapes: the attribute only ever grows (a larger value than
+// needed can cost residency: the runtime may budget the declared maximum)
+struct CdfoAttrGrow { int cur[CDFO_MAXDEV] = {0}; };
+static inline hipError_t cdfo_grow_max_lds(CdfoAttrGrow& g, const void* func, int bytes) {
+  const int d = cdfo_cur_device();
+  if (d < 0) return hipErrorInvalidDevice;
+  if (bytes <= g.cur[d]) return hipSuccess;
+  const hipError_t e = hipFuncSetAttribute(func, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  if (e == hipSuccess) g.cur[d] = bytes;
+  return e;
+}
+
 static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 

@@ -12,6 +12,7 @@
 // pixel-shuffle store); every source must be a multiple of 64 channels wide.  Replaces the 1x1 convolutions of the
 // CVSR_V8 path (qkv, project_out folded, input_conv, fuse, fusion_out, down.0 / up.0, tsa_fusion, upconv1/2).
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -209,6 +210,9 @@ __global__ __launch_bounds__(256, 2) void conv1x1_bf16x3_kernel(cdfo_conv_args a
 
 }  // namespace
 
+// conv1x1_stream.hip: the persistent LDS-DMA streaming form (plain store, CoutP <= 128, weights + rings within LDS)
+int cdfo_conv1x1_stream_try(const cdfo_conv_args& a, hipStream_t st);
+
 extern "C" int cdfo_conv1x1_bf16x3(const cdfo_conv_args* pa, void* stream) {
   const cdfo_conv_args& a = *pa;
   hipStream_t st = static_cast<hipStream_t>(stream);
@@ -229,6 +233,14 @@ extern "C" int cdfo_conv1x1_bf16x3(const cdfo_conv_args* pa, void* stream) {
   if ((a.res1 && (a.ldr1 % 4 || !aligned16(a.res1))) || (!taps && a.res2 && (a.ldr2 % 4 || !aligned16(a.res2)))) return CDFO_EALIGN;
   if (a.ln_gamma && !(a.nsrc == 1 && a.cs[0] == 64 && a.ln_beta && aligned16(a.ln_gamma) && aligned16(a.ln_beta))) return CDFO_EINVAL;
   const long long P = (long long)a.H * a.W;
+  {
+    static const bool use_stream = [] { const char* e = getenv("CDFO_CONV1X1_STREAM"); return !(e && e[0] == '0'); }();   // developer A/B switch
+    if (use_stream && !taps) {
+      const int r = cdfo_conv1x1_stream_try(a, st);
+      if (r == 1) return 0;
+      if (r != 0) return r;
+    }
+  }
   dim3 grid((unsigned)((P + PXT - 1) / PXT), a.B);
   const double px = (double)a.B * P;
   CdfoProfScope prof(st, KID_CONV1, 2.0 * px * a.Cout * a.Cin, 4.0 * (px * a.Cout + px * a.Cin + (double)a.Cin * a.Cout));

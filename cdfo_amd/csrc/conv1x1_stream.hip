@@ -1,0 +1,337 @@
+// 1x1 convolution as a persistent HBM stream: LDS-DMA rings, no workgroup barrier in the steady state.
+//
+// conv1x1_bf16x3.hip (one 128-pixel tile per workgroup: load -> split -> LDS -> barrier -> MFMA -> LDS transpose -> store)
+// reaches 2.2-3.4 TB/s of algorithmic traffic: its phases are separated by barriers, only two workgroups fit a CU, and
+// HBM is idle whenever both are computing or storing.  The 1x1 convolutions of the CVSR_V8 forward (arch.py: attention
+// apply of MDTA :1573-1575 and DualAttAlignment :3459-3491 as per-image folded weights, RDAB.input_conv / fuse
+// :2196,2246, conv_du_re.0 :2148, fusion_out :3441, Block_.up.0 :381) move 4*(Cin+Cout) bytes per pixel for 2*Cin*Cout
+// FLOP: pure streams.  Here
+//   * one 256-thread workgroup per CU is persistent over a contiguous range of 128-pixel tiles; each of its four waves owns
+//     32 pixels of the tile and a PRIVATE ring of 8 KB LDS stages that it fills itself by LDS-DMA
+//     (buffer_load_dwordx4 ... lds): the fp32 pixel-major activations of one 64-channel K block (32 pixels x 256 B), and
+//     after the last K block the tile's residual operands, arrive as 8 pieces of 1 KiB with NS-1 stages in flight behind a
+//     counted s_waitcnt -- no staging registers, no barrier, the waves drift freely;
+//   * the LDS image is [pixel][16-byte part ^ (pixel & 15)] (the swizzle is applied on the DMA's per-lane source
+//     address), so the fragment reads -- a lane's 8 consecutive input channels of its pixel, two ds_read_b128 -- are
+//     conflict-free; the lane splits them to bf16 hi / lo in registers and feeds the MFMA directly (no LDS write pass);
+//   * same arithmetic as conv1x1_bf16x3: split-bf16, a_lo*w_hi + a_hi*w_lo + a_hi*w_hi, fp32 accumulation (fp32-grade);
+//     the weights (also the per-image folded attention weights) are split once per image into LDS, rows permuted so that
+//     a lane's accumulators are 8 consecutive output channels of its pixel (transposed product, as conv3x3_ws.hip): the
+//     epilogue (bias, activation, up to two residuals read from their LDS stages) stores 32 contiguous bytes per lane
+//     straight from registers.
+// Contract: cdfo_conv_args as cdfo_conv1x1_bf16x3 with plain store, Cin % 64 == 0 per source, Cout % 8 == 0,
+// CoutP in {64, 128}, weights + ring within the CU's LDS (Cin * CoutP <= 192 * 64); everything else stays on that kernel.
+#include "common.h"
+
+namespace {
+
+constexpr int ST_THREADS = 256;
+constexpr int ST_STAGE = 8192;                 // 32 pixels x 64 channels x 4 B
+constexpr int ST_MAXNS = 4;
+
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+
+struct st_item { const float* base; int ld; int ch0; };     // one 64-channel slice of a pixel-major operand
+
+struct st_args {
+  st_item act[CDFO_MAXSRC * 4];    // K blocks in order (<= 12 used: Cin <= 768 guarded by the LDS test anyway)
+  int nkb;
+  st_item res[2];                  // residual operands (ch0 = 0), res[i].base == nullptr: absent
+  const float* w; long long w_bstride; const float* bias;
+  int Cin, Cout, CoutP, act_fn;
+  float* out; int ldo;
+  int B; long long P;              // pixels per image
+  int tiles_per_image; long long tiles;
+  int ns;                          // ring stages per wave
+};
+
+__device__ __forceinline__ unsigned st_pack_bf16(float a, float b) {
+  const __bf16 ha = (__bf16)a, hb = (__bf16)b;
+  return (unsigned)__builtin_bit_cast(unsigned short, ha) | ((unsigned)__builtin_bit_cast(unsigned short, hb) << 16);
+}
+__device__ __forceinline__ float st_bf16_round(float a) { return (float)(__bf16)a; }
+
+// eight 1 KiB pieces of one stage: lane l of piece k writes LDS bytes lds + 1024 k + 16 l from (buffer base + voff[k])
+__device__ __forceinline__ void st_dma8(const unsigned (&voff)[8], i32x4 rsrc, unsigned lds) {
+  unsigned keep;
+  asm volatile(
+      "s_nop 4\n\t"
+      "s_mov_b32 %0, m0\n\t"
+      "s_mov_b32 m0, %10\n\ts_nop 0\n\t"
+      "buffer_load_dwordx4 %1, %9, 0 offen lds\n\t"
+      "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\t"
+      "buffer_load_dwordx4 %2, %9, 0 offen lds\n\t"
+      "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\t"
+      "buffer_load_dwordx4 %3, %9, 0 offen lds\n\t"
+      "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\t"
+      "buffer_load_dwordx4 %4, %9, 0 offen lds\n\t"
+      "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\t"
+      "buffer_load_dwordx4 %5, %9, 0 offen lds\n\t"
+      "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\t"
+      "buffer_load_dwordx4 %6, %9, 0 offen lds\n\t"
+      "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\t"
+      "buffer_load_dwordx4 %7, %9, 0 offen lds\n\t"
+      "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\t"
+      "buffer_load_dwordx4 %8, %9, 0 offen lds\n\t"
+      "s_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(voff[0]), "v"(voff[1]), "v"(voff[2]), "v"(voff[3]), "v"(voff[4]), "v"(voff[5]), "v"(voff[6]), "v"(voff[7]),
+        "s"(rsrc), "s"(lds)
+      : "memory", "scc");
+}
+
+// NCB: 64-wide output-channel blocks (1 or 2)
+template <int NCB>
+__global__ __launch_bounds__(ST_THREADS) void conv1x1_stream_kernel(st_args a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, r = lane & 31;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nkb = a.nkb, NS = a.ns;
+  // LDS map: weights hi [nkb*4 chunks][2 k-halves][NCB*64 rows][8 bf16] | weights lo (same) | bias [NCB*64 floats] |
+  //          4 waves x NS stages
+  const int w_half = nkb * 4 * 2 * NCB * 64 * 16;
+  unsigned char* sWh = smem;
+  unsigned char* sWl = smem + w_half;
+  float* sBias = reinterpret_cast<float*>(smem + 2 * w_half);
+  const int ring_off = 2 * w_half + NCB * 64 * 4;
+  unsigned char* ring = smem + ring_off + wave * NS * ST_STAGE;
+  const unsigned ring_lds = (unsigned)(unsigned long long)(smem) + ring_off + wave * NS * ST_STAGE;
+
+  // MFMA row m of a 32-channel block holds channel (m>>4)*16 + ((m>>2)&1)*8 + ((m>>3)&1)*4 + (m&3) (see conv3x3_ws.hip):
+  // a lane's accumulator registers then are 8 consecutive channels of each 16-channel group
+  auto chan_of_row = [](int n) { const int m = n & 31; return (n & ~31) + ((m >> 4) & 1) * 16 + ((m >> 2) & 1) * 8 + ((m >> 3) & 1) * 4 + (m & 3); };
+
+  // this workgroup's contiguous tile range
+  const long long t_lo = a.tiles * blockIdx.x / gridDim.x, t_hi = a.tiles * (blockIdx.x + 1) / gridDim.x;
+  if (t_lo >= t_hi) return;
+  const int nres = (a.res[0].base ? 1 : 0) + (a.res[1].base ? 1 : 0);
+  const int items_per_tile = nkb + nres * NCB;
+  const float slope = a.act_fn == CDFO_ACT_NONE ? 1.f : (a.act_fn == CDFO_ACT_LRELU ? 0.1f : 0.f);
+
+  // per-lane DMA slot geometry: piece k, lane l -> slot s = 64 k + l -> pixel p = s >> 4 (0..31), part (s & 15) ^ (p & 15)
+  int d_px[8], d_part[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const int s = 64 * k + lane, p = s >> 4;
+    d_px[k] = p;
+    d_part[k] = (s & 15) ^ (p & 15);
+  }
+  // fragment read offsets of this lane's pixel r: 16-byte part q lives at r*256 + ((q ^ (r & 15)) << 4)
+  auto part_off = [&](int q) { return r * 256 + ((q ^ (r & 15)) << 4); };
+
+  for (long long img_t0 = t_lo; img_t0 < t_hi;) {
+    const int b = (int)(img_t0 / a.tiles_per_image);
+    const long long img_end = (long long)(b + 1) * a.tiles_per_image;
+    const long long seg_hi = img_end < t_hi ? img_end : t_hi;           // tiles [img_t0, seg_hi) belong to image b
+    // ---- this image's weights -> LDS (split bf16 hi | lo, rows permuted).  No DMA is in flight here.
+    __syncthreads();                                                     // previous image's MFMAs are done with sW
+    {
+      const float* wb = a.w + (long long)b * a.w_bstride;
+      const int ngrp = (a.Cin >> 2) * NCB * 64;                          // (group of 4 input channels, row position)
+      for (int i = tid; i < ngrp; i += ST_THREADS) {
+        const int rowpos = i % (NCB * 64), kg = i / (NCB * 64);
+        const int n = chan_of_row(rowpos);
+        f32x4 wv = {0.f, 0.f, 0.f, 0.f};
+        if (n < a.CoutP) wv = *reinterpret_cast<const f32x4*>(wb + ((long long)kg * a.CoutP + n) * 4);
+        const int c = kg >> 2, hh = (kg >> 1) & 1, j0 = (kg & 1) * 4;
+        u32x2 hi, lo;
+        hi[0] = st_pack_bf16(wv[0], wv[1]); hi[1] = st_pack_bf16(wv[2], wv[3]);
+        lo[0] = st_pack_bf16(wv[0] - st_bf16_round(wv[0]), wv[1] - st_bf16_round(wv[1]));
+        lo[1] = st_pack_bf16(wv[2] - st_bf16_round(wv[2]), wv[3] - st_bf16_round(wv[3]));
+        const int off = ((c * 2 + hh) * (NCB * 64) + rowpos) * 16 + j0 * 2;
+        *reinterpret_cast<u32x2*>(sWh + off) = hi;
+        *reinterpret_cast<u32x2*>(sWl + off) = lo;
+      }
+      for (int i = tid; i < NCB * 64; i += ST_THREADS) sBias[i] = (a.bias && i < a.Cout) ? a.bias[i] : 0.f;   // by channel
+    }
+    __syncthreads();
+
+    // ---- the item stream of this wave for tiles [img_t0, seg_hi): per tile nkb K blocks, then the residual stages
+    const long long n_items = (seg_hi - img_t0) * items_per_tile;
+    long long issued = 0;
+    auto issue = [&](long long it) {
+      const long long tile = img_t0 + it / items_per_tile;
+      const int k = (int)(it % items_per_tile);
+      const long long p0 = (tile - (long long)b * a.tiles_per_image) * 128 + wave * 32;      // first pixel (inside image b)
+      st_item src;
+      int chan0;
+      if (k < nkb) { src = a.act[k]; chan0 = src.ch0; }
+      else {                     // residual operands are packed from slot 0 by the host wrapper
+        const int j = k - nkb;
+        src = a.res[j / NCB];
+        chan0 = (j % NCB) * 64;
+      }
+      // descriptor based at the wave's first pixel: offsets stay small whatever the tensor's size
+      const long long rows_left = a.P - p0;                               // may be <= 0: everything out of range
+      const float* base = src.base + ((long long)b * a.P + (rows_left > 0 ? p0 : 0)) * src.ld + chan0;
+      const unsigned long long pb = reinterpret_cast<unsigned long long>(base);
+      i32x4 rsrc;
+      rsrc[0] = __builtin_amdgcn_readfirstlane((int)(unsigned)pb);
+      rsrc[1] = __builtin_amdgcn_readfirstlane((int)(unsigned)(pb >> 32));
+      const long long bytes = rows_left > 0 ? (rows_left < 32 ? rows_left : 32) * (long long)src.ld * 4 : 0;
+      rsrc[2] = __builtin_amdgcn_readfirstlane((int)bytes);               // lanes beyond the image read zeros
+      rsrc[3] = 0x00020000;
+      unsigned voff[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) voff[q] = (unsigned)(d_px[q] * src.ld * 4 + d_part[q] * 16);
+      st_dma8(voff, rsrc, __builtin_amdgcn_readfirstlane(ring_lds + (unsigned)(it % NS) * ST_STAGE));
+    };
+    for (; issued < NS - 1 && issued < n_items; ++issued) issue(issued);
+
+    f32x16 acc[NCB][2];
+    for (long long it = 0; it < n_items; ++it) {
+      const int k = (int)(it % items_per_tile);
+      // item `it` has landed when at most the 8 * (younger items in flight) youngest DMA pieces are outstanding
+      // (pieces retire in order among themselves; stores in flight only make the wait more conservative)
+      const long long younger = issued - it - 1;
+      if (younger >= 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+      else if (younger == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      const unsigned char* st = ring + (it % NS) * ST_STAGE;
+      if (k == 0) {
+#pragma unroll
+        for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+          for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[cb][ni][e] = 0.f;
+      }
+      if (k < nkb) {
+        // ---- one K block: 4 chunks of 16 channels; this lane's operand = channels c*16 + h*8 .. +7 of pixel r
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const f32x4 v0 = *reinterpret_cast<const f32x4*>(st + part_off(c * 4 + h * 2));
+          const f32x4 v1 = *reinterpret_cast<const f32x4*>(st + part_off(c * 4 + h * 2 + 1));
+          union { unsigned u[4]; bf16x8_t v; } ph, pl;
+          ph.u[0] = st_pack_bf16(v0[0], v0[1]); ph.u[1] = st_pack_bf16(v0[2], v0[3]);
+          ph.u[2] = st_pack_bf16(v1[0], v1[1]); ph.u[3] = st_pack_bf16(v1[2], v1[3]);
+          pl.u[0] = st_pack_bf16(v0[0] - st_bf16_round(v0[0]), v0[1] - st_bf16_round(v0[1]));
+          pl.u[1] = st_pack_bf16(v0[2] - st_bf16_round(v0[2]), v0[3] - st_bf16_round(v0[3]));
+          pl.u[2] = st_pack_bf16(v1[0] - st_bf16_round(v1[0]), v1[1] - st_bf16_round(v1[1]));
+          pl.u[3] = st_pack_bf16(v1[2] - st_bf16_round(v1[2]), v1[3] - st_bf16_round(v1[3]));
+          const int wrow = ((k * 4 + c) * 2 + h) * (NCB * 64) + r;
+#pragma unroll
+          for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni) {
+              const bf16x8_t wh = *reinterpret_cast<const bf16x8_t*>(sWh + (wrow + cb * 64 + ni * 32) * 16);
+              const bf16x8_t wl = *reinterpret_cast<const bf16x8_t*>(sWl + (wrow + cb * 64 + ni * 32) * 16);
+              acc[cb][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, pl.v, acc[cb][ni], 0, 0, 0);
+              acc[cb][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl, ph.v, acc[cb][ni], 0, 0, 0);
+              acc[cb][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, ph.v, acc[cb][ni], 0, 0, 0);
+            }
+        }
+        if (k == nkb - 1) {      // bias + activation, in place: acc[cb][ni][8 jj + q] = channel cb*64 + ni*32 + jj*16 + h*8 + q
+#pragma unroll
+          for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+              for (int e = 0; e < 16; ++e) {
+                const float t = acc[cb][ni][e] + sBias[cb * 64 + ni * 32 + (e >> 3) * 16 + h * 8 + (e & 7)];
+                acc[cb][ni][e] = fmaxf(t, 0.f) + slope * fminf(t, 0.f);
+              }
+        }
+      } else {
+        // ---- a residual stage: 64 channels of block cb of the tile's residual operand
+        const int cb = (k - nkb) % NCB;
+#pragma unroll
+        for (int cc = 0; cc < NCB; ++cc) {
+          if (cc != cb) continue;
+#pragma unroll
+          for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj) {
+              const int q = (ni * 32 + jj * 16 + h * 8) >> 2;
+              const f32x4 r0 = *reinterpret_cast<const f32x4*>(st + part_off(q));
+              const f32x4 r1 = *reinterpret_cast<const f32x4*>(st + part_off(q + 1));
+#pragma unroll
+              for (int e = 0; e < 4; ++e) { acc[cc][ni][8 * jj + e] += r0[e]; acc[cc][ni][8 * jj + 4 + e] += r1[e]; }
+            }
+        }
+      }
+      // the stage may be overwritten once its reads have returned: the next DMA below targets the stage of item it-1... wait
+      // for this item's own LDS reads too (they were consumed by the MFMAs / adds above, so they have returned)
+      if (issued < n_items) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); issue(issued); ++issued; }
+      if (k == items_per_tile - 1) {
+        // ---- store: 32 contiguous bytes per lane and 16-channel group
+        const long long tile = img_t0 + it / items_per_tile;
+        const long long pin = (tile - (long long)b * a.tiles_per_image) * 128 + wave * 32 + r;
+        if (pin < a.P) {
+          float* op = a.out + ((long long)b * a.P + pin) * a.ldo;
+#pragma unroll
+          for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+              for (int jj = 0; jj < 2; ++jj) {
+                const int n = cb * 64 + ni * 32 + jj * 16 + h * 8;
+                if (n < a.Cout) {
+                  f32x4 v0, v1;
+#pragma unroll
+                  for (int e = 0; e < 4; ++e) { v0[e] = acc[cb][ni][8 * jj + e]; v1[e] = acc[cb][ni][8 * jj + 4 + e]; }
+                  *reinterpret_cast<f32x4*>(op + n) = v0;
+                  *reinterpret_cast<f32x4*>(op + n + 4) = v1;
+                }
+              }
+        }
+      }
+    }
+    img_t0 = seg_hi;
+  }
+}
+
+}  // namespace
+
+// Returns 1 when the streaming kernel took the launch, 0 when the shapes are outside its contract (the caller falls back to
+// cdfo_conv1x1_bf16x3), < 0 / hipError_t on errors.  Same argument block as cdfo_conv1x1_bf16x3.
+int cdfo_conv1x1_stream_try(const cdfo_conv_args& a, hipStream_t st) {
+  if (a.store_mode != CDFO_STORE_PLAIN || a.ln_gamma || a.CoutP % 64 || a.CoutP > 128 || a.Cout % 8) return 0;
+  const int ncb = a.CoutP / 64, nkb = a.Cin / 64;
+  if (nkb < 1 || nkb > CDFO_MAXSRC * 4) return 0;
+  const int w_bytes = 2 * nkb * 4 * 2 * ncb * 64 * 16 + ncb * 64 * 4;
+  int ns = (160 * 1024 - 256 - w_bytes) / (4 * ST_STAGE);
+  if (ns > ST_MAXNS) ns = ST_MAXNS;
+  if (ns < 3) return 0;
+  const long long P = (long long)a.H * a.W;
+  st_args s{};
+  int k = 0;
+  for (int i = 0; i < a.nsrc; ++i) {
+    if ((long long)a.ld[i] * 4 * 32 >= (1ll << 31)) return 0;
+    for (int c = 0; c < a.cs[i]; c += 64) { s.act[k].base = a.src[i]; s.act[k].ld = a.ld[i]; s.act[k].ch0 = c; ++k; }
+  }
+  if (k != nkb) return 0;
+  s.nkb = nkb;
+  // residual operands are staged 64 channels at a time: they must be at least NCB*64 channels wide in memory terms only
+  // where Cout needs it (a narrower tensor would be read past its pitch): require ld >= CoutP
+  int nr = 0;
+  if (a.res1) { if (a.ldr1 < a.CoutP) return 0; s.res[nr].base = a.res1; s.res[nr].ld = a.ldr1; ++nr; }
+  if (a.res2) { if (a.ldr2 < a.CoutP) return 0; s.res[nr].base = a.res2; s.res[nr].ld = a.ldr2; ++nr; }
+  s.w = a.w; s.w_bstride = a.w_bstride; s.bias = a.bias;
+  s.Cin = a.Cin; s.Cout = a.Cout; s.CoutP = a.CoutP; s.act_fn = a.act;
+  s.out = a.out; s.ldo = a.ldo; s.B = a.B; s.P = P;
+  s.tiles_per_image = (int)((P + 127) / 128);
+  s.tiles = (long long)a.B * s.tiles_per_image;
+  s.ns = ns;
+  const int cus = cdfo_num_cus();
+  if (cus <= 0) return CDFO_EINVAL;
+  const int grid = (int)(s.tiles < cus ? s.tiles : cus);
+  const int lds = w_bytes + 4 * ns * ST_STAGE;
+  const double px = (double)a.B * P;
+  CdfoProfScope prof(st, KID_CONV1, 2.0 * px * a.Cout * a.Cin, 4.0 * (px * a.Cout * (1 + nr) + px * a.Cin + (double)a.Cin * a.Cout));
+  if (ncb == 1) {
+    static CdfoAttrOnce once;
+    const hipError_t e = cdfo_set_max_lds(once, reinterpret_cast<const void*>(conv1x1_stream_kernel<1>), 160 * 1024 - 256);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(conv1x1_stream_kernel<1>, dim3(grid), dim3(ST_THREADS), lds, st, s);
+  } else {
+    static CdfoAttrOnce once;
+    const hipError_t e = cdfo_set_max_lds(once, reinterpret_cast<const void*>(conv1x1_stream_kernel<2>), 160 * 1024 - 256);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(conv1x1_stream_kernel<2>, dim3(grid), dim3(ST_THREADS), lds, st, s);
+  }
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 1 : (int)e;
+}

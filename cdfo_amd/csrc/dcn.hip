@@ -65,8 +65,11 @@ __global__ __launch_bounds__(256) void dcn_to_gp_kernel(const float* __restrict_
     }
   }
   if (amax) {
+    // one atomic per wave at most, and only while it would still raise the maximum (a plain read first: the running
+    // maximum settles within the first workgroups, after which nobody touches the contended word any more)
     m = wave_max(m);
-    if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(amax, __float_as_uint(m));
+    if ((threadIdx.x & 63) == 0 && m > 0.f && __float_as_uint(m) > __hip_atomic_load(amax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+      atomicMax(amax, __float_as_uint(m));
   }
 }
 
@@ -233,9 +236,9 @@ extern "C" int cdfo_dcn_forward(const float* in, const float* offset, const floa
   const int KCH = (CC * T + 1) / 2 * 2;
   const size_t lds = (size_t)KCH * (PIXT + WSTR) * sizeof(float);
   if (lds > 160 * 1024) return CDFO_EINVAL;
-  static CdfoAttrOnce once_a, once_b;           // the attribute is set to the CU's whole LDS once per device
-  if (cdfo_set_max_lds(once_a, reinterpret_cast<const void*>(&dcn_fwd_kernel<false>), 160 * 1024) != hipSuccess ||
-      cdfo_set_max_lds(once_b, reinterpret_cast<const void*>(&dcn_fwd_kernel<true>), 160 * 1024) != hipSuccess)
+  static CdfoAttrGrow grow_a, grow_b;
+  if (cdfo_grow_max_lds(grow_a, reinterpret_cast<const void*>(&dcn_fwd_kernel<false>), (int)lds) != hipSuccess ||
+      cdfo_grow_max_lds(grow_b, reinterpret_cast<const void*>(&dcn_fwd_kernel<true>), (int)lds) != hipSuccess)
     return CDFO_EINVAL;
   const int Cog = Co / groups;
   dim3 grid(cdiv(Ho * Wo, PIXT), groups * cdiv(Cog, 256), B);

@@ -23,6 +23,8 @@ from .kernels import _stream, on_device
 # True (or CDFO_DCN_EXACT=1 in the environment): always the exact-fp32 MFMA kernel (v_mfma_f32_32x32x2_f32, bitwise an
 # fp32 fma chain), ~3.5x slower at the alignment module's shape.
 EXACT_FP32 = os.environ.get("CDFO_DCN_EXACT", "0") not in ("", "0")
+_DEBUG_KEEP_WS = os.environ.get("CDFO_DCN_DEBUG", "0") not in ("", "0")      # developer switch: keep the last workspace alive
+_debug_last: list = []
 
 
 _DTYPES = {torch.float32: 0, torch.float16: 1, torch.float64: 2}     # CDFO_DTYPE_* of include/cdfo_hip.h
@@ -83,6 +85,9 @@ def _fwd(input, weight, bias, offset, mask, output, kh, kw, sh, sw, ph, pw, dh, 
         _lib.check(L.cdfo_dcn_forward_dt(dt, p(input), p(offset), p(mask), p(weight), p(bias), p(output), B, Cc, H, W,
                                          Co, kh, kw, sh, sw, ph, pw, dh, dw, group, dg, p(ws), C.c_longlong(nbytes),
                                          _stream()), "cdfo_dcn_forward_dt")
+        if _DEBUG_KEEP_WS:
+            _debug_last.clear()
+            _debug_last.extend([ws, nbytes])
 
 
 def deform_conv_forward_cuda(input, weight, offset, output, columns, ones, kW, kH, dW, dH, padW, padH, dilationW,

@@ -486,3 +486,39 @@ def test_split_fp16_conv_on_ring_kernel(B, H, W):
     out = K.conv_ring(hl, K.pack_conv_hilo(w.cuda(), b.cuda()), res1=_nhwc(r1).cuda(), res2=_nhwc(r2).cuda(), plane_wrap=8)
     torch.cuda.synchronize()
     _cmp(out, ref, 2e-5, "split-fp16 conv on the ring kernel")
+
+
+@pytest.mark.parametrize("srcs,Cout,nres,per_image", [([64], 64, 2, True), ([64, 64], 64, 1, False), ([64, 128], 64, 0, True),
+                                                      ([64], 128, 0, False), ([128], 128, 1, False)])
+def test_conv1x1_stream_many_tiles_across_images(srcs, Cout, nres, per_image):
+    """The persistent streaming form of the 1x1 convolution (conv1x1_stream.hip) with more tiles than workgroups, so
+    that workgroups walk several tiles, cross image boundaries (weights reloaded per image) and end on a ragged tile;
+    against torch, and against the one-tile-per-workgroup kernel it replaces (CDFO_CONV1X1_STREAM=0 is a process-wide
+    switch, so that comparison is numerical: same split-bf16 arithmetic, fp32 accumulation)."""
+    from cdfo_amd import kernels as K
+    g = torch.Generator().manual_seed(sum(srcs) * 7 + Cout + nres)
+    B, H, W = 5, 104, 105                     # 10,920 pixels = 85.3 tiles per image, 430 tiles in all
+    xs = [torch.randn(B, c, H, W, generator=g) for c in srcs]
+    cin = sum(srcs)
+    b = torch.randn(Cout, generator=g)
+    if per_image:
+        ws = torch.randn(B, Cout, cin, 1, 1, generator=g) / cin ** 0.5
+        y = torch.cat([F.conv2d(torch.cat([t[i:i + 1] for t in xs], 1), ws[i]) for i in range(B)], 0)
+        packs = [K.pack_conv(ws[i].cuda(), None) for i in range(B)]
+        pc = K.PackedConv(torch.stack([p.w for p in packs]).contiguous(), None, Cout, cin, 1, packs[0].CoutP, False,
+                          packs[0].w.numel())
+    else:
+        w = torch.randn(Cout, cin, 1, 1, generator=g) / cin ** 0.5
+        y = F.conv2d(torch.cat(xs, 1), w, b)
+        pc = K.pack_conv(w.cuda(), b.cuda())
+    ref = F.relu(y)
+    rs = [torch.randn(B, Cout, H, W, generator=g) for _ in range(nres)]
+    for r in rs:
+        ref = ref + r
+    dev_r = [_nhwc(r).cuda() for r in rs] + [None, None]
+    out = K.conv([_nhwc(t).cuda() for t in xs], pc, act=K.ACT_RELU, res1=dev_r[0], res2=dev_r[1], prec=K.PREC_BF16X3)
+    torch.cuda.synchronize()
+    _cmp(out, ref, 3e-5, "conv1x1 stream")
+    out2 = K.conv([_nhwc(t).cuda() for t in xs], pc, act=K.ACT_RELU, res1=dev_r[0], res2=dev_r[1], prec=K.PREC_BF16X3)
+    torch.cuda.synchronize()
+    assert torch.equal(out, out2)             # no atomics, fixed summation order

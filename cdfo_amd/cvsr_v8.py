@@ -6,8 +6,10 @@ ufs, pre_L1_fea=None) -> (out, L1_fea)`` and the same 261 ``state_dict`` entries
 ``.pth`` loads with ``load_state_dict(strict=True)``.
 
 Differences, all deliberate:
-  * forward needs CUDA (ROCm) tensors and ``torch.no_grad()``/``eval`` use: there is NO CPU or autograd fallback --
-    it raises ``NotImplementedError`` like the reference's own CUDA-only operator does (ops/dcn/deform_conv.py:136).
+  * forward needs CUDA (ROCm) tensors: there is NO CPU fallback -- it raises ``NotImplementedError`` like the reference's
+    own CUDA-only operator does (ops/dcn/deform_conv.py:136).  Under ``torch.no_grad()`` the fused inference schedule of
+    this file runs; with gradients enabled (``train_LD_37.py:376-381``) the call goes to ``cvsr_v8_train.forward_train``:
+    the plain operator graph under torch autograd, exact-fp32 HIP kernels forward and backward.
   * ``gumbel_uniform=`` (kwarg or attribute): the six uniform draws of ``LLongRangAttention.gumbel_softmax``
     (arch.py:2169) may be injected as six ``[B,64,H,W]`` tensors; by default they are drawn like the reference does
     (fresh uniforms per call, never 0), by a Philox4x32-10 generator inside the mask kernel, keyed per forward from
@@ -407,6 +409,16 @@ class CVSR_V8(nn.Module):
             noise = gumbel_uniform if gumbel_uniform is not None else self.gumbel_uniform
             if noise is None:
                 self._noise_seed = K.next_noise_seed(x.device)
+            if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+                # training call (train_LD_37.py:376-381): the operator graph under autograd, exact-fp32 HIP kernels in both
+                # directions (cdfo_amd/cvsr_v8_train.py); the fused inference schedule below is forward-only
+                if pre_L1_fea is not None:
+                    raise NotImplementedError("CVSR_V8 (HIP): the cached-feature path is an inference path; training uses fresh clips")
+                for prm in self.parameters():
+                    if not prm.is_cuda or prm.dtype != torch.float32:
+                        raise NotImplementedError("CVSR_V8 (HIP): fp32 parameters on the GPU expected")
+                from .cvsr_v8_train import forward_train
+                return forward_train(self, x, mvs0, mvs1, pms, rms, ufs, noise)
             guard = self.precision == "fp16x2" and self.range_guard
             self._probe = torch.zeros(4, dtype=torch.int32, device=x.device) if guard else None
             res = self._forward(x, mvs0, mvs1, pms, rms, ufs, pre_L1_fea, noise)
@@ -438,9 +450,6 @@ class CVSR_V8(nn.Module):
     FP16_WINDOW = (2.0 ** -6, 2.0 ** 11)
 
     def _forward(self, x, mvs0, mvs1, pms, rms, ufs, pre_L1_fea=None, gumbel_uniform=None):
-        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
-            raise NotImplementedError("CVSR_V8 (HIP): forward only -- wrap the call in torch.no_grad() "
-                                      "(backward kernels are not part of this path yet)")
         B, N, C, H, W = x.shape
         if N != NFRAMES or C != 1:
             raise ValueError(f"expected x of shape [B,7,1,H,W], got {tuple(x.shape)}")

@@ -273,6 +273,48 @@ int cdfo_dcn_backward_dt(int dtype, const void* in, const void* offset, const vo
                          int dh, int dw, int groups, int deformable_groups, float scale, void* workspace,
                          long long workspace_bytes, void* stream);
 
+/* ---- backward kernels of the CVSR_V8 training path (train_ops.hip) ------------------------
+ * cdfo_amd/autograd.py runs the module under torch autograd (train_LD_37.py:376-381): every Function's forward is one of
+ * the exact-fp32 forward entry points above, its backward either the same entry points with adjoint operands (flipped /
+ * transposed weights) or one of these.  fp32 pixel-major tensors with pitch ld (floats).
+ * cdfo_conv_wgrad:   out[a][b][ky][kx] = sum_{n,y,x} S[n,y,x,a] * L[n, y*stride+ky-pad, x*stride+kx-pad, b]  -- a
+ *                    convolution's weight gradient with S = grad_out, L = input (OIHW), a transposed convolution's with
+ *                    S = input, L = grad_out (IOHW).  Split-K exact-fp32 MFMA into `slab`
+ *                    (cdfo_conv_wgrad_slab_floats(...) floats), slices summed in a fixed order into
+ *                    dw[(a*Btot + b_off + b)*ks*ks + tap] (b_off / Btot: channel offset of this source in a concatenated input).
+ * cdfo_coldot:       out[img][c] = scale * sum_p a[img][p][c] * (b ? b[img][p][c] : 1)  (bias / gate / pooled gradients);
+ *                    part = nimg*nchunk*C floats of scratch.
+ * cdfo_ew:           mode 0 a*b, 1 a*(1-b), 2 a+b, 3 a*act'(y=b) (aux = CDFO_ACT_*), 4 out[p][c] = a[p/P][c]*scale.
+ * cdfo_layernorm64_bwd, cdfo_dwconv3x3_wgrad, cdfo_spatial_gate16_bwd, cdfo_chanconv9 (9 taps along the channel axis,
+ * flip = adjoint), cdfo_corr9 (weight gradient of a 9-tap convolution along the channel axis (0) or the image rows (1)),
+ * cdfo_gumbel_mask (the hard mask of arch.py:2168-2195 as a tensor), cdfo_seq_attn_bwd (adjoint of cdfo_seq_attn, modes
+ * 0-2, probabilities recomputed), cdfo_flow_warp_bwd (scatter with fp32 atomics into a zero-filled dx),
+ * cdfo_resample2_bwd (adjoints of bilinear x2 / x0.5). */
+long long cdfo_conv_wgrad_slab_floats(int A, int Bc, int ks, int nsplit);
+int cdfo_conv_wgrad(const float* S, int lds_, int A, const float* L, int ldl, int Bc, int N, int Hs, int Ws, int Hl, int Wl,
+                    int ks, int stride, int pad, int nsplit, float* slab, float* dw, int Btot, int b_off, void* stream);
+int cdfo_coldot(const float* a, int lda, const float* b, int ldb, int nimg, long long P, int C, int nchunk, float scale,
+                float* part, float* out, void* stream);
+int cdfo_ew(const float* a, int lda, const float* b, int ldb, long long rows, int C, int mode, int aux, float scale, long long P,
+            float* out, int ldo, void* stream);
+int cdfo_layernorm64_bwd(const float* x, int ldx, const float* g, int ldg, const float* gamma, long long npix, float* dx,
+                         int ldo, float* part, int nblk, void* stream);
+int cdfo_dwconv3x3_wgrad(const float* x, int ldx, const float* g, int ldg, int B, int H, int W, int C, float* part, int nblk,
+                         void* stream);
+int cdfo_spatial_gate16_bwd(const float* t, int ldt, const float* g, int ldg, const float* w, const float* bias, int B, int H,
+                            int W, float* scratch, float* dt, int ldo, float* dw99, void* stream);
+int cdfo_gumbel_mask(const float* vmax, const float* noise, long long seed, int draw, float* noise_out, int B, long long P,
+                     float* mask, int ldm, void* stream);
+int cdfo_chanconv9(const float* in, int ldi, const float* w9, const float* bias, int flip, long long npix, float* out, int ldo,
+                   void* stream);
+int cdfo_corr9(const float* in, int ldi, const float* g, int ldg, int axis, int B, int H, int W, float* part, int nblk,
+               void* stream);
+int cdfo_seq_attn_bwd(const float* q, int ldq, const float* v, int ldv, const float* o, int ldo, const float* g, int ldg,
+                      float* dq, int lddq, float* dv, int lddv, int B, int H, int W, int mode, void* stream);
+int cdfo_flow_warp_bwd(const float* g, int ldg, const float* mv, long long mv_bstride, int B, int H, int W, int C, float* dx,
+                       int ldo, void* stream);
+int cdfo_resample2_bwd(const float* g, int ldg, int B, int H, int W, int C, int up, float* din, int ldo, void* stream);
+
 /* ---- pixel-local operators of the CVSR_V7 forward (v7_ops.hip) ---------------------------
  * fp32 pixel-major activations [B,H,W,64] with pitch ld (floats).
  * cdfo_chan_pool:     ChannelPool (arch/SIDECVSR_our.py:1883-1885): out[p] = {max_c x[p][c], mean_c x[p][c]}.

@@ -349,6 +349,64 @@ def run_case_v7(ref, name, B, H, W, wseed, iseed, layout, cached):
     print(f"v7 {name}: out {tuple(out.shape)} mean {out.mean():.6f} -> {path} ({os.path.getsize(path)/1024:.0f} KiB)")
 
 
+GRAD_CASES = {
+    # name: (B, H, W, weight_seed, input_seed)   -- training-mode gradients of the REAL reference (train_LD_37.py:376-381)
+    "grad_b1_8x8": (1, 8, 8, 21, 201),
+    "grad_b2_16x16": (2, 16, 16, 22, 202),
+}
+GRAD_STRIDE = 53          # every parameter's gradient is stored as its moments + every 53rd element; small ones in full
+
+
+def charbonnier(x, y):
+    """opt/loss.py:20-31 as train_LD_37.py:377 calls it: sum(sqrt(diff^2 + 1e-4))."""
+    d = x - y
+    return torch.sum(torch.sqrt(d * d + 1e-4))
+
+
+def run_grad_case(ref, name, B, H, W, wseed, iseed):
+    """One training step's forward + backward of the real reference class: model.train(); sr, _ = model(...);
+    loss = CharbonnierLoss(sr, hr); loss.backward()  -- the outputs kept are the loss, `out`, and every parameter's .grad
+    (moments + strided sample; in full when it has at most 4096 elements)."""
+    sd = make_state_dict(wseed)
+    model = ref.CVSR_V8()
+    model.load_state_dict(sd, strict=True)
+    model.train()
+    inp = make_inputs(B, H, W, iseed, "b1n")
+    hr = torch.from_numpy(np.random.RandomState(iseed + 7).uniform(0, 1, (B, 1, 4 * H, 4 * W)).astype(np.float32))
+    queue = list(inp["gumbel_u"])
+    real_rand_like = torch.rand_like
+
+    def fake_rand_like(t, *a, **k):
+        u = queue.pop(0)
+        assert u.shape == t.shape
+        return u
+
+    torch.rand_like = fake_rand_like
+    try:
+        out, _ = model(inp["x"], inp["mvs0"], inp["mvs1"], inp["pms"], inp["rms"], inp["ufs"])
+    finally:
+        torch.rand_like = real_rand_like
+    loss = charbonnier(out, hr)
+    loss.backward()
+    rec = dict(B=B, H=H, W=W, wseed=wseed, iseed=iseed, out=out.detach().numpy(), loss=np.float64(loss.item()), hr_seed=iseed + 7,
+               stride=GRAD_STRIDE)
+    none = []
+    for k, prm in model.named_parameters():
+        if prm.grad is None:
+            none.append(k)
+            continue
+        g = prm.grad.detach()
+        rec["m:" + k] = moments(g)
+        rec["s:" + k] = g.flatten()[::GRAD_STRIDE].numpy().copy()
+        if g.numel() <= 4096:
+            rec["f:" + k] = g.numpy().copy()
+    rec["none"] = np.array(none)
+    path = os.path.join(REPO, "tests", "golden", f"cvsr_v8_{name}.npz")
+    np.savez_compressed(path, **rec)
+    print(f"{name}: loss {loss.item():.6f}, {len(none)} parameters without gradient {none[:4]} -> {path} "
+          f"({os.path.getsize(path)/1024:.0f} KiB)")
+
+
 def main():
     if sys.argv[1:] == ["streaming"]:
         return gen_streaming_helpers()
@@ -360,6 +418,10 @@ def main():
         if only and name not in only:
             continue
         run_case(ref, name, *cfg)
+    for name, cfg in GRAD_CASES.items():
+        if only and name not in only:
+            continue
+        run_grad_case(ref, name, *cfg)
     for name, cfg in V7_CASES.items():
         if only and "v7_" + name not in only:
             continue

@@ -49,6 +49,15 @@ def main():
         for d in dbgs:
             ms = timeit(lambda: K.conv_ring(src, pc, res1=res, out=out, dbg=d))
             line += f" dbg{d} {ms:6.3f}"
+        if sparse:       # the four-tap form with its whole epilogue: half-resolution residual (bilinear x2) + fp16 chunk-planar copy
+            up = torch.randn(B, H // 2, W // 2, Cout, device="cuda")
+            o16 = torch.empty(B, Cout // 16, H, W, 16, device="cuda", dtype=torch.float16)
+            ms = timeit(lambda: K.conv_ring(src, pc, res1=res, out=out, res_up2=up, out2_cp16=o16))
+            line += f" | full epilogue {ms:6.3f} ms {fl/ms/1e9:6.1f} TF/s"
+        else:
+            o16 = torch.empty(B, Cout // 16, H, W, 16, device="cuda", dtype=torch.float16)
+            ms = timeit(lambda: K.conv_ring(src, pc, res1=res, out=out, out2_cp16=o16))
+            line += f" | + cp16 copy {ms:6.3f} ms"
         print(line, flush=True)
 
 

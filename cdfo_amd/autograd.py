@@ -268,7 +268,9 @@ class _SmallConv16(Function):
         x, weight, y = ctx.saved_tensors
         stride, pad, out_pad, transposed, act = ctx.meta
         gp = act_bwd(_c(g), y, act) if act != ACT_NONE else _c(g)
-        H, Ho = x.shape[1], gp.shape[1]
+        H, Ho, W, Wo = x.shape[1], gp.shape[1], x.shape[2], gp.shape[2]
+        if not transposed and H - ((Ho - 1) * stride - 2 * pad + 3) != W - ((Wo - 1) * stride - 2 * pad + 3):
+            raise NotImplementedError("small_conv16 backward: rows and columns need the same output padding (H, W of equal parity)")
         zero = torch.zeros(16, device=g.device)
         dW = torch.empty_like(weight)
         if not transposed:
@@ -394,18 +396,21 @@ class _ScaleChannels(Function):
 
 
 class _MulMask(Function):
-    """x * mask (inv = False) or x * (1 - mask); the hard mask carries no gradient (arch.py:2194-2195: masked_fill)."""
+    """x * mask (inv = False) or x * (1 - mask); the hard mask carries no gradient (arch.py:2194-2195: masked_fill).
+    `anchor` (optional scalar built from the mask generator's parameters) receives a zero gradient, so that those parameters end
+    the backward pass with zero-filled .grad tensors as they do in the reference (not None: Adam's weight decay sees them)."""
 
     @staticmethod
-    def forward(ctx, x, mask, inv):
+    def forward(ctx, x, mask, inv, anchor):
         ctx.save_for_backward(mask)
         ctx.inv = inv
+        ctx.has_anchor = anchor is not None
         return ew(_dense_rows(x.detach()), mask, 1 if inv else 0)
 
     @staticmethod
     def backward(ctx, g):
         (mask,) = ctx.saved_tensors
-        return ew(_c(g), mask, 1 if ctx.inv else 0), None, None
+        return ew(_c(g), mask, 1 if ctx.inv else 0), None, None, (g.new_zeros(()) if ctx.has_anchor else None)
 
 
 def gumbel_mask(vmax: torch.Tensor, noise, B: int, H: int, W: int, capture: Optional[list] = None) -> torch.Tensor:
@@ -569,5 +574,5 @@ def channel_attention(q, k, v, temp, heads):
     return _ChannelAttention.apply(q, k, v, temp, heads)
 
 
-def mul_mask(x, mask, inv=False):
-    return _MulMask.apply(x, mask, inv)
+def mul_mask(x, mask, inv=False, anchor=None):
+    return _MulMask.apply(x, mask, inv, anchor)

@@ -58,9 +58,12 @@ def _rdab(P, res, x, noise, capture):
         vmax = K.vec_mlp(part, n, t.shape[1] * t.shape[2], P[r + "conv_du_re2.0.weight"].detach().contiguous(),
                          P[r + "conv_du_re2.0.bias"].detach().contiguous(), 64, ACT_RELU)
         mask = A.gumbel_mask(vmax, noise, B, H, W, capture)
+    # zero-gradient anchor of the generator's parameters (parameter-sized arithmetic): their .grad becomes zeros, as in the reference
+    anchor = sum((P[r + k].sum() * 0.0 for k in ("conv_du_re.0.weight", "conv_du_re.0.bias", "conv_du_re.2.weight", "conv_du_re.2.bias",
+                                                 "conv_du_re2.0.weight", "conv_du_re2.0.bias")), torch.zeros((), device=x.device))
     xq = A.conv(x, P[r + "input_conv.weight"], P[r + "input_conv.bias"])
     q4, v4 = xq[..., 0:64], xq[..., 64:128]
-    sq = A.chanconv9(A.mul_mask(q4, mask, False), P[r + "directW1_conv.weight"], P[r + "directW1_conv.bias"])
+    sq = A.chanconv9(A.mul_mask(q4, mask, False, anchor), P[r + "directW1_conv.weight"], P[r + "directW1_conv.bias"])
     vv = A.chanconv9(v4, P[r + "directW1_conv.weight"], P[r + "directW1_conv.bias"])
     rowo = A.seq_attn(sq, vv, 0)
     qc = A.colconv9(sq, P[r + "directH1_conv.weight"], P[r + "directH1_conv.bias"])

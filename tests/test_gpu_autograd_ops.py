@@ -102,7 +102,7 @@ def test_layernorm_dwconv():
           {"x": R(2, 192, 9, 13, seed=4), "w": R(192, 1, 3, 3, seed=5, scale=0.3)}, nhwc_in=["x"], name="dwconv")
 
 
-@pytest.mark.parametrize("transposed,out_pad,H,W", [(False, 0, 16, 16), (False, 0, 9, 18), (True, 0, 6, 6), (True, 1, 9, 9), (True, 1, 5, 10)])
+@pytest.mark.parametrize("transposed,out_pad,H,W", [(False, 0, 16, 16), (False, 0, 9, 17), (True, 0, 6, 6), (True, 1, 9, 9), (True, 1, 5, 10)])
 def test_small_conv16(transposed, out_pad, H, W):
     from cdfo_amd import autograd as A
     inp = {"x": R(2, 16, H, W, seed=1), "w": R(16, 16, 3, 3, seed=2, scale=0.1), "b": R(16, seed=3)}

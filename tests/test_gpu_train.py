@@ -2,9 +2,17 @@
 -- model.train(); optimizer.zero_grad(); sr, _ = model(...); loss = CharbonnierLoss(sr, hr); loss.backward();
 optimizer.step() -- with HIP kernels forward and backward, against
 
-  * the gradients of the REAL reference's training step (tests/golden/cvsr_v8_grad_*.npz): every parameter, <= 1e-3 of its
-    gradient's magnitude (the forward `out` <= 1e-5: exact-fp32 kernels);
-  * the CPU oracle's autograd at another size / batch (pinned to the reference by tests/test_oracle_grad_golden.py)."""
+  * the gradients of the REAL reference's training step (tests/golden/cvsr_v8_grad_*.npz): every parameter; the forward
+    `out` <= 1e-5 (exact-fp32 kernels);
+  * the CPU oracle's autograd at another size / batch (pinned to the reference by tests/test_oracle_grad_golden.py), in
+    float64 as the truth and in float32 as the yardstick.
+
+Tolerances.  A gradient of this network is only defined to ~1e-3 of its magnitude in fp32: ReLU / LeakyReLU derivatives are
+discontinuous, so activations that differ in the last bits flip individual gradient contributions.  Measured on the CPU
+restatement itself at 16x16, B = 2: float32 against float64 autograd differ by up to 5.8e-3 of max |g| (3.5e-3 relative L2,
+`conv_expand_rms.weight`), 6-9e-4 for a dozen other tensors.  Hence: at 8x8 (few kinks) 1e-3 of max |g| per tensor against the
+reference; at 16x16 3e-3 of max |g| and 2e-3 relative L2 against the reference (both fp32); and against the float64 oracle
+the HIP gradients must be as close as the float32 CPU gradients are (within 3x, floor 1e-3)."""
 import glob
 import os
 
@@ -47,30 +55,34 @@ def test_hip_training_step_matches_reference_gradients(path):
     m, out, loss, grads = _hip_step(int(g["wseed"]), inp, hr, [u.cuda() for u in inp["gumbel_u"]])
     assert np.abs(out.numpy() - g["out"]).max() <= 1e-5
     assert abs(loss - float(g["loss"])) <= 1e-5 * abs(float(g["loss"]))
-    worst = compare_with_golden(g, grads, 1e-3)
+    small = H * W <= 64
+    worst = compare_with_golden(g, grads, 1e-3 if small else 3e-3, rel_l2=None if small else 2e-3)
     print(f"HIP training step vs the reference's gradients ({os.path.basename(path)}): worst relative error {worst}")
 
 
 def test_hip_training_step_matches_oracle_autograd_at_another_size():
-    """B = 2 clips of 24x16 (non-square, two images per launch: per-image attention weights, batch strides)."""
+    """B = 2 clips of 24x16 (non-square, two images per launch: per-image attention weights, batch strides).  Truth = the
+    oracle's float64 autograd; the HIP (fp32) gradients must be as close to it as the oracle's own float32 gradients are."""
     from oracle.cvsr_v8_ref import make_inputs
     fake = dict(B=2, H=24, W=16, wseed=31, iseed=301, hr_seed=308, stride=53)
-    out_o, loss_o, grads_o = oracle_grads(fake)
+    out_o, loss_o, g64 = oracle_grads(fake, torch.float64)
+    _, _, g32 = oracle_grads(fake, torch.float32)
     inp = make_inputs(2, 24, 16, 301, "b1n")
     hr = torch.from_numpy(np.random.RandomState(308).uniform(0, 1, (2, 1, 96, 64)).astype(np.float32))
     m, out, loss, grads = _hip_step(31, inp, hr, [u.cuda() for u in inp["gumbel_u"]])
-    assert (out - out_o).abs().max().item() <= 1e-5
-    worst = (0.0, "")
-    for k, go in grads_o.items():
+    assert (out.double() - out_o).abs().max().item() <= 1e-5
+    worst = (0.0, "", 0.0)
+    for k, go in g64.items():
         if go is None:
             assert grads[k] is None or grads[k].abs().max().item() == 0.0, k
             continue
         scale = go.abs().max().item()
-        err = (grads[k].cpu() - go).abs().max().item()
+        err = (grads[k].cpu().double() - go).abs().max().item()
+        err32 = (g32[k].double() - go).abs().max().item()
         if scale > 0 and err / scale > worst[0]:
-            worst = (err / scale, k)
-        assert err <= 1e-3 * scale + 1e-12, (k, err, scale)
-    print("HIP vs oracle autograd at 24x16, B=2: worst relative error", worst)
+            worst = (err / scale, k, err32 / scale)
+        assert err <= max(3.0 * err32, 1e-3 * scale) + 1e-12, (k, err / max(scale, 1e-30), err32 / max(scale, 1e-30))
+    print("HIP vs float64 oracle autograd at 24x16, B=2: worst relative error %.2e (%s; float32 CPU oracle there: %.2e)" % worst)
 
 
 def test_train_script_call_pattern_runs_and_learns():

@@ -11,12 +11,12 @@ import torch
 GOLD = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "cvsr_v8_grad_*.npz")))
 
 
-def oracle_grads(g):
+def oracle_grads(g, dtype=torch.float32):
     from oracle.cvsr_v8_ref import cvsr_v8_forward, make_inputs, make_state_dict
     B, H, W = int(g["B"]), int(g["H"]), int(g["W"])
-    sd = {k: v.clone().requires_grad_(True) for k, v in make_state_dict(int(g["wseed"])).items()}
-    inp = make_inputs(B, H, W, int(g["iseed"]), "b1n")
-    hr = torch.from_numpy(np.random.RandomState(int(g["hr_seed"])).uniform(0, 1, (B, 1, 4 * H, 4 * W)).astype(np.float32))
+    sd = {k: v.clone().to(dtype).requires_grad_(True) for k, v in make_state_dict(int(g["wseed"])).items()}
+    inp = {k: ([u.to(dtype) for u in v] if k == "gumbel_u" else v.to(dtype)) for k, v in make_inputs(B, H, W, int(g["iseed"]), "b1n").items()}
+    hr = torch.from_numpy(np.random.RandomState(int(g["hr_seed"])).uniform(0, 1, (B, 1, 4 * H, 4 * W)).astype(np.float32)).to(dtype)
     out, _ = cvsr_v8_forward(sd, inp["x"], None, inp["mvs1"], inp["pms"], inp["rms"], inp["ufs"], None, inp["gumbel_u"])
     d = out - hr
     loss = torch.sum(torch.sqrt(d * d + 1e-4))
@@ -24,8 +24,9 @@ def oracle_grads(g):
     return out.detach(), loss.item(), {k: v.grad for k, v in sd.items()}
 
 
-def compare_with_golden(g, grads, rel, zero_ok=True):
-    """Every parameter the reference gave a gradient: strided sample (and the full tensor where stored) within rel * max|g|."""
+def compare_with_golden(g, grads, rel, zero_ok=True, rel_l2=None):
+    """Every parameter the reference gave a gradient: strided sample (and the full tensor where stored) within rel * max|g|
+    (and, if given, the sample's relative L2 error within rel_l2)."""
     none = set(g["none"].tolist())
     stride = int(g["stride"])
     worst = (0.0, "")
@@ -43,6 +44,9 @@ def compare_with_golden(g, grads, rel, zero_ok=True):
         if scale > 0 and err / scale > worst[0]:
             worst = (err / scale, key)
         assert err <= rel * scale + 1e-12, f"{key}: max |dg| = {err:.3e} vs max |g| = {scale:.3e}"
+        if rel_l2 is not None and scale > 0:
+            d = got.reshape(-1)[::stride] - want_s
+            assert np.linalg.norm(d) <= rel_l2 * np.linalg.norm(want_s) + 1e-12, f"{key}: relative L2 error {np.linalg.norm(d) / np.linalg.norm(want_s):.3e}"
     for key in none:
         assert grads.get(key) is None or float(grads[key].abs().max()) == 0.0, key
     return worst

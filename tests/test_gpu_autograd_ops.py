@@ -41,6 +41,7 @@ def check(fn_hip, fn_ref, inputs, tol=2e-4, nhwc_in=(), nhwc_out=True, name=""):
             gh = nchw(gh)
         s = max(1e-6, gr.abs().max().item())
         err = (gh.double() - gr).abs().max().item()
+        print(f"   {name}: d/d{k} rel err {err / s:.2e}")
         assert err <= tol * s, f"{name}: d/d{k}: {err:.3e} vs scale {s:.3e}"
 
 

@@ -138,8 +138,8 @@ class CVSR_V8(nn.Module):
         #            (2-4e-4 max-abs: inside the 1e-3 parity bound; default);
         #   "bf16"   plain bf16 MFMA with fp32 accumulation (BASELINE's bf16 configuration, ~6e-3: outside the bound).
         self.precision = "fp16x2"
-        # HIP side streams for the six independent per-neighbour pipelines: 1 = single stream, 0 = auto (6 for one or two
-        # clips, where the launches are small and the streamed sequence gains 7 %: 57.4 -> 61.5 frames/s; 3 otherwise)
+        # HIP side streams for the two independent neighbour groups (frames 0-2 and 4-6): 1 = everything on the caller's
+        # stream, 0 = auto = 2 (one side stream per group)
         self.neighbour_streams = 0
         for key, shape, fan_in, init in _param_spec():
             t = torch.empty(shape)
@@ -301,33 +301,47 @@ class CVSR_V8(nn.Module):
                 x1 = self._conv(ln, w[p + "conv"], pad=1, res1=x1, res2=x2, exact=True)
         return x1
 
-    def _rdab(self, w, res, x, noise):
+    def _rdab(self, w, res, x, noises):
+        """LLongRangAttention (arch.py:2179-2249) on a GROUP of neighbour frames at once: res / x are [G*B,H,W,64] (neighbour
+        major), `noises` one entry per neighbour -- the module's weights are shared by all neighbours, only the noise draw (and
+        with it the mask kernel's launch) is per neighbour."""
         raw = w["raw"]
-        B, H, W, _ = x.shape
+        GB, H, W, _ = x.shape
+        G = len(noises)
+        B = GB // G
         t = self._conv(res, w["RDAB.conv_du_re.0"], act=K.ACT_RELU)
         t = self._conv(t, w["RDAB.conv_du_re.2"], stride=2, pad=2, act=K.ACT_RELU)
         part, n = K.chan_sum_partial(t)
         vmax = K.vec_mlp(part, n, t.shape[1] * t.shape[2], raw["RDAB.conv_du_re2.0.weight"],
                          raw["RDAB.conv_du_re2.0.bias"], 64, K.ACT_RELU)
         xq = self._conv(x, w["RDAB.input_conv"])
-        if isinstance(noise, tuple):      # ("rng", seed, draw, capture): draw the uniforms inside the kernel (default path)
-            _, seed, draw, capture = noise
-            sq, vrow, qwin = K.rdab_prep_rng(xq, vmax, seed, draw, raw["RDAB.directW1_conv.weight"],
-                                             raw["RDAB.directW1_conv.bias"], noise_out=capture)
-        else:
-            sq, vrow, qwin = K.rdab_prep(xq, vmax, noise, raw["RDAB.directW1_conv.weight"], raw["RDAB.directW1_conv.bias"])
-        cat = K.empty_act(B, H, W, 128, x.device)
+        sq, vrow, qwin = (K.empty_act(GB, H, W, 64, x.device) for _ in range(3))
+        for g, noise in enumerate(noises):
+            sl = slice(g * B, (g + 1) * B)
+            outs = (sq[sl], vrow[sl], qwin[sl])
+            if isinstance(noise, tuple):  # ("rng", seed, draw, capture): draw the uniforms inside the kernel (default path)
+                _, seed, draw, capture = noise
+                K.rdab_prep_rng(xq[sl], vmax[sl], seed, draw, raw["RDAB.directW1_conv.weight"], raw["RDAB.directW1_conv.bias"],
+                                noise_out=capture, outs=outs)
+            else:
+                K.rdab_prep(xq[sl], vmax[sl], noise, raw["RDAB.directW1_conv.weight"], raw["RDAB.directW1_conv.bias"], outs=outs)
+        cat = K.empty_act(GB, H, W, 128, x.device)
         rowo = K.seq_attn(sq, vrow, 0)
         qc = K.colconv9(sq, raw["RDAB.directH1_conv.weight"], raw["RDAB.directH1_conv.bias"])
         K.seq_attn(qc, rowo, 1, out=cat[..., 0:64])
         K.seq_attn(qwin, xq[..., 64:128], 2, out=cat[..., 64:128])
         return self._conv(cat, w["RDAB.fuse"], res1=x)
 
-    def _align(self, w, xc, extra, pred, mv, mv_bstride, out):
+    def _align(self, w, xc, extra, pred, mvs, mv_bstride, out):
+        """DualAttAlignment (arch.py:3455-3496) on a group of neighbours: xc / extra / pred / out are [G*B,H,W,64] (xc = the
+        centre frame's features repeated per neighbour), mvs one motion field view per neighbour."""
         raw = w["raw"]
         a = "MV_deform_align."
-        B, H, W, _ = xc.shape
-        warped = K.flow_warp(extra, mv, mv_bstride)
+        GB, H, W, _ = xc.shape
+        B = GB // len(mvs)
+        warped = K.empty_act(GB, H, W, NF, xc.device)
+        for g, mv in enumerate(mvs):
+            K.flow_warp(extra[g * B:(g + 1) * B], mv, mv_bstride, out=warped[g * B:(g + 1) * B])
         kf = self._conv([warped, pred], w[a + "fusion_out.0"], act=K.ACT_RELU)
         gp, ng = K.gram_partial(xc, kf, 16)
         sw, ns = K.chan_sum_partial(warped)
@@ -487,34 +501,36 @@ class CVSR_V8(nn.Module):
         ufs = ufs.contiguous().float()
         rms = rms.contiguous().float()
         noise = gumbel_uniform        # resolved by forward(): injected tensors, or None = draw inside the mask kernel
-        aligned: List[torch.Tensor] = []
-        draw = 0
-        # The six neighbour pipelines are independent of each other: with `neighbour_streams` > 1 they are issued
-        # round-robin on side streams (HIP streams, joined before the temporal fusion), so that their many small
-        # kernels overlap.  Every tensor they produce stays referenced until forward returns.
-        nstr = int(getattr(self, "neighbour_streams", 0)) or (6 if B <= 2 else 3)
+        # The six neighbours share every weight of the compensation + alignment modules, so they are processed as two GROUPS of
+        # three frames (frames 0-2 and 4-6 are contiguous in the frame-major feature stack): each operator runs once on 3*B
+        # images instead of three times on B.  Only what reads a per-neighbour input plane (prior stems, noise draw, motion
+        # field) is launched per neighbour, into slices of the group's tensors.  The two groups are independent: with
+        # `neighbour_streams` > 1 they are issued on two side streams (joined before the temporal fusion).
+        nstr = int(getattr(self, "neighbour_streams", 0)) or 2
         main = torch.cuda.current_stream(x.device)
         side = []
         if nstr > 1:
             cache = self.__dict__.setdefault("_side_streams", {})
-            side = cache.get((x.device, nstr))
+            side = cache.get((x.device, 2))
             if side is None:
-                side = cache[(x.device, nstr)] = [torch.cuda.Stream(x.device) for _ in range(nstr)]
+                side = cache[(x.device, 2)] = [torch.cuda.Stream(x.device) for _ in range(2)]
         for st in side:
             st.wait_stream(main)
         keep = []
-        for i in range(N):
-            if i == ctr:
-                aligned.append(Lf[ctr])
-                continue
-            ctx = torch.cuda.stream(side[draw % nstr]) if side else contextlib.nullcontext()
+        groups = [list(range(0, ctr)), list(range(ctr + 1, N))]
+        xcG = Lf[ctr].repeat(ctr, 1, 1, 1) if ctr > 1 else Lf[ctr]          # the centre features once per neighbour of a group
+        aligned_by_frame = {}
+        for gi, idxs in enumerate(groups):
+            ctx = torch.cuda.stream(side[gi]) if side else contextlib.nullcontext()
             with ctx:
-                aligned.append(self._neighbour(w, raw, Lf, i, ctr, ufs, rms, mvs1, noise, draw, B, H, W, P, N, keep))
+                al = self._neighbour_group(w, raw, Lf, idxs, xcG, ufs, rms, mvs1, noise, gi * ctr, B, H, W, P, N, keep)
             if side:
-                aligned[-1].record_stream(main)      # produced on a side stream, consumed on the caller's
-            draw += 1
+                al.record_stream(main)               # produced on a side stream, consumed on the caller's
+            for n, i in enumerate(idxs):
+                aligned_by_frame[i] = al[n * B:(n + 1) * B]
         for st in side:
             main.wait_stream(st)
+        aligned: List[torch.Tensor] = [Lf[ctr] if i == ctr else aligned_by_frame[i] for i in range(N)]
 
         # 3. temporal fusion, 4. reconstruction trunk, 5. upsampling + skip (arch.py:4463-4481)
         fused = self._conv(aligned, w["tsa_fusion"], act=K.ACT_LRELU)
@@ -533,31 +549,41 @@ class CVSR_V8(nn.Module):
             K.range_probe(out, self._probe[2:4])
         return out, L1.permute(0, 3, 1, 2)
 
-    def _neighbour(self, w, raw, Lf, i, ctr, ufs, rms, mvs1, noise, draw, B, H, W, P, N, keep):
-        """One neighbour frame: prior stems, RDAB compensation, conv_expand_fea_r, MV alignment (arch.py:4443-4460)."""
+    def _neighbour_group(self, w, raw, Lf, idxs, xcG, ufs, rms, mvs1, noise, draw0, B, H, W, P, N, keep):
+        """Neighbour frames `idxs` (consecutive) together: prior stems, RDAB compensation, conv_expand_fea_r, MV alignment
+        (arch.py:4443-4460) on [len(idxs)*B, H, W, 64] tensors, neighbour major."""
         x_dev = Lf.device
-        ufs_prior = K.stem_conv(ufs[:, 0, i], N * P, B, H, W, raw["conv_expand_ufs.weight"],
-                                raw["conv_expand_ufs.bias"])
-        rms_prior, fea_com = K.stem_conv(rms[:, 0, i], N * P, B, H, W, raw["conv_expand_rms.weight"],
-                                         raw["conv_expand_rms.bias"], add=Lf[i])
-        if noise is None:
-            # the reference's default (torch.rand_like per call, arch.py:2169): the draws are generated INSIDE rdab_prep
-            # (Philox4x32-10), the [B,64,H,W] noise tensor never exists; `capture_noise` (tests) asks for a copy
-            cap = None
-            if self.capture_noise is not None:
-                cap = torch.empty((B, NF, H, W), device=x_dev, dtype=torch.float32)
-                self.capture_noise.append(cap)
-            u = ("rng", self._noise_seed, draw, cap)
-        else:
-            u = noise[draw].to(device=x_dev, dtype=torch.float32).contiguous()
-        x_n = self._rdab(w, rms_prior, fea_com, u)
+        G = len(idxs)
+        GB = G * B
+        feaG = Lf[idxs[0]:idxs[0] + G].view(GB, H, W, NF)
+        ufs_prior, rms_prior, fea_com = (K.empty_act(GB, H, W, NF, x_dev) for _ in range(3))
+        noises = []
+        for n, i in enumerate(idxs):
+            sl = slice(n * B, (n + 1) * B)
+            K.stem_conv(ufs[:, 0, i], N * P, B, H, W, raw["conv_expand_ufs.weight"], raw["conv_expand_ufs.bias"], out=ufs_prior[sl])
+            K.stem_conv(rms[:, 0, i], N * P, B, H, W, raw["conv_expand_rms.weight"], raw["conv_expand_rms.bias"], add=Lf[i],
+                        out=rms_prior[sl], out2=fea_com[sl])
+            draw = draw0 + n
+            if noise is None:
+                # the reference's default (torch.rand_like per call, arch.py:2169): the draws are generated INSIDE rdab_prep
+                # (Philox4x32-10), the [B,64,H,W] noise tensor never exists; `capture_noise` (tests) asks for a copy
+                cap = None
+                if self.capture_noise is not None:
+                    cap = torch.empty((B, NF, H, W), device=x_dev, dtype=torch.float32)
+                    self.capture_noise.append(cap)
+                noises.append(("rng", self._noise_seed, draw, cap))
+            else:
+                noises.append(noise[draw].to(device=x_dev, dtype=torch.float32).contiguous())
+        x_n = self._rdab(w, rms_prior, fea_com, noises)
+        fea_i = self._conv([feaG, x_n], w["conv_expand_fea_r"], pad=1)
+        al = K.empty_act(GB, H, W, NF, x_dev)
+        xc = xcG if xcG.shape[0] == GB else xcG[:GB]
+        self._align(w, xc, fea_i, ufs_prior, [mvs1[:, i] for i in idxs], N * 2 * P, al)
         if self.debug_taps is not None:
-            self.debug_taps[f"rdab_{i}"] = x_n
-            self.debug_taps[f"align_{i}"] = al_ref = K.empty_act(B, H, W, NF, x_dev)
-        fea_i = self._conv([Lf[i], x_n], w["conv_expand_fea_r"], pad=1)
-        al = al_ref if self.debug_taps is not None else K.empty_act(B, H, W, NF, x_dev)
-        self._align(w, Lf[ctr], fea_i, ufs_prior, mvs1[:, i], N * 2 * P, al)
-        keep.extend([ufs_prior, rms_prior, fea_com, u, x_n, fea_i])
+            for n, i in enumerate(idxs):
+                self.debug_taps[f"rdab_{i}"] = x_n[n * B:(n + 1) * B]
+                self.debug_taps[f"align_{i}"] = al[n * B:(n + 1) * B]
+        keep.extend([ufs_prior, rms_prior, fea_com, noises, x_n, fea_i, xc])
         return al
 
     @staticmethod

@@ -384,15 +384,24 @@ def swap_outer(x: torch.Tensor, B: int, N: int) -> torch.Tensor:
 
 
 def stem_conv(img: torch.Tensor, img_bstride: int, B: int, H: int, W: int, w: torch.Tensor, bias: torch.Tensor,
-              act: int = ACT_NONE, add: Optional[torch.Tensor] = None):
-    """img: any fp32 device tensor whose element [b][y][x] sits at data_ptr + (b*img_bstride + y*W + x)*4."""
-    out = empty_act(B, H, W, 64, img.device)
-    out2 = None
+              act: int = ACT_NONE, add: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None,
+              out2: Optional[torch.Tensor] = None):
+    """img: any fp32 device tensor whose element [b][y][x] sits at data_ptr + (b*img_bstride + y*W + x)*4.
+    out / out2: optional dense [B,H,W,64] destinations (slices of a larger batch)."""
+    if out is None:
+        out = empty_act(B, H, W, 64, img.device)
+    elif tuple(out.shape) != (B, H, W, 64) or not out.is_contiguous():
+        raise ValueError("stem_conv: out must be a dense [B,H,W,64] tensor")
     lda = ldo2 = 0
     if add is not None:
         _, _, _, _, lda = _chk_act(add, "add")
-        out2 = empty_act(B, H, W, 64, img.device)
+        if out2 is None:
+            out2 = empty_act(B, H, W, 64, img.device)
+        elif tuple(out2.shape) != (B, H, W, 64) or not out2.is_contiguous():
+            raise ValueError("stem_conv: out2 must be a dense [B,H,W,64] tensor")
         ldo2 = 64
+    else:
+        out2 = None
     check(_lib.lib().cdfo_stem_conv(_vp(img), C.c_longlong(img_bstride), _vp(w), _vp(bias), B, H, W, act, _vp(out), 64,
                                     _vp(add), lda, _vp(out2), ldo2, _stream()), "cdfo_stem_conv")
     return (out, out2) if add is not None else out
@@ -483,9 +492,12 @@ def dwconv3x3(x: torch.Tensor, w: torch.Tensor) -> torch.Tensor:
     return out
 
 
-def flow_warp(x: torch.Tensor, mv: torch.Tensor, mv_bstride: int) -> torch.Tensor:
+def flow_warp(x: torch.Tensor, mv: torch.Tensor, mv_bstride: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     B, H, W, Cc, ld = _chk_act(x)
-    out = empty_act(B, H, W, Cc, x.device)
+    if out is None:
+        out = empty_act(B, H, W, Cc, x.device)
+    elif tuple(out.shape) != (B, H, W, Cc) or not out.is_contiguous():
+        raise ValueError("flow_warp: out must be a dense tensor of the input's shape")
     check(_lib.lib().cdfo_flow_warp(_vp(x), ld, _vp(mv), C.c_longlong(mv_bstride), B, H, W, Cc, _vp(out), Cc,
                                     _stream()), "cdfo_flow_warp")
     return out
@@ -682,19 +694,26 @@ def vec_mlp(part: torch.Tensor, n: int, P: int, w1, b1, c1: int, act1: int, w2=N
 
 
 # ----------------------------------------------------------------------------------------------- prior-fusion attention
-def rdab_prep(xq: torch.Tensor, vmax: torch.Tensor, noise: torch.Tensor, wW: torch.Tensor, bW: torch.Tensor):
+def _prep_outs(outs, B, H, W, device):
+    if outs is None:
+        return empty_act(B, H, W, 64, device), empty_act(B, H, W, 64, device), empty_act(B, H, W, 64, device)
+    for t in outs:
+        if tuple(t.shape) != (B, H, W, 64) or not t.is_contiguous() or t.dtype != torch.float32:
+            raise ValueError("rdab_prep: outs must be three dense fp32 [B,H,W,64] tensors")
+    return outs
+
+
+def rdab_prep(xq: torch.Tensor, vmax: torch.Tensor, noise: torch.Tensor, wW: torch.Tensor, bW: torch.Tensor, outs=None):
     B, H, W, Cc, ld = _chk_act(xq)
     assert Cc == 128 and noise.is_contiguous() and tuple(noise.shape) == (B, 64, H, W)
-    sq = empty_act(B, H, W, 64, xq.device)
-    vrow = empty_act(B, H, W, 64, xq.device)
-    qwin = empty_act(B, H, W, 64, xq.device)
+    sq, vrow, qwin = _prep_outs(outs, B, H, W, xq.device)
     check(_lib.lib().cdfo_rdab_prep(_vp(xq), ld, _vp(vmax), _vp(noise), _vp(wW), _vp(bW), B, C.c_longlong(H * W),
                                     _vp(sq), 64, _vp(vrow), 64, _vp(qwin), 64, _stream()), "cdfo_rdab_prep")
     return sq, vrow, qwin
 
 
 def rdab_prep_rng(xq: torch.Tensor, vmax: torch.Tensor, seed: int, draw: int, wW: torch.Tensor, bW: torch.Tensor,
-                  noise_out: Optional[torch.Tensor] = None):
+                  noise_out: Optional[torch.Tensor] = None, outs=None):
     """rdab_prep with the uniform draws of arch.py:2169 generated inside the kernel (Philox4x32-10, key = seed, `draw` =
     index of the call within the forward).  noise_out: optional fp32 [B,64,H,W] tensor that receives the drawn values."""
     B, H, W, Cc, ld = _chk_act(xq)
@@ -702,9 +721,7 @@ def rdab_prep_rng(xq: torch.Tensor, vmax: torch.Tensor, seed: int, draw: int, wW
     if noise_out is not None and (tuple(noise_out.shape) != (B, 64, H, W) or not noise_out.is_contiguous()
                                   or noise_out.dtype != torch.float32):
         raise ValueError("rdab_prep_rng: noise_out must be a contiguous fp32 [B,64,H,W] tensor")
-    sq = empty_act(B, H, W, 64, xq.device)
-    vrow = empty_act(B, H, W, 64, xq.device)
-    qwin = empty_act(B, H, W, 64, xq.device)
+    sq, vrow, qwin = _prep_outs(outs, B, H, W, xq.device)
     check(_lib.lib().cdfo_rdab_prep_rng(_vp(xq), ld, _vp(vmax), C.c_longlong(seed & 0x7FFFFFFFFFFFFFFF), draw, _vp(noise_out),
                                         _vp(wW), _vp(bW), B, C.c_longlong(H * W), _vp(sq), 64, _vp(vrow), 64, _vp(qwin), 64,
                                         _stream()), "cdfo_rdab_prep_rng")

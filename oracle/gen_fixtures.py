@@ -401,7 +401,7 @@ def run_grad_case(ref, name, B, H, W, wseed, iseed):
         if g.numel() <= 4096:
             rec["f:" + k] = g.numpy().copy()
     rec["none"] = np.array(none)
-    path = os.path.join(REPO, "tests", "golden", f"cvsr_v8_{name}.npz")
+    path = os.path.join(REPO, "tests", "golden", f"grad_cvsr_v8_{name[5:]}.npz")
     np.savez_compressed(path, **rec)
     print(f"{name}: loss {loss.item():.6f}, {len(none)} parameters without gradient {none[:4]} -> {path} "
           f"({os.path.getsize(path)/1024:.0f} KiB)")

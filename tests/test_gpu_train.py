@@ -2,7 +2,7 @@
 -- model.train(); optimizer.zero_grad(); sr, _ = model(...); loss = CharbonnierLoss(sr, hr); loss.backward();
 optimizer.step() -- with HIP kernels forward and backward, against
 
-  * the gradients of the REAL reference's training step (tests/golden/cvsr_v8_grad_*.npz): every parameter; the forward
+  * the gradients of the REAL reference's training step (tests/golden/grad_cvsr_v8_*.npz): every parameter; the forward
     `out` <= 1e-5 (exact-fp32 kernels);
   * the CPU oracle's autograd at another size / batch (pinned to the reference by tests/test_oracle_grad_golden.py), in
     float64 as the truth and in float32 as the yardstick.
@@ -25,7 +25,7 @@ import torch
 from test_oracle_grad_golden import golden_errors, oracle_grads
 
 pytestmark = pytest.mark.gpu
-GOLD = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "cvsr_v8_grad_*.npz")))
+GOLD = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "grad_cvsr_v8_*.npz")))
 
 
 def _charbonnier(x, y):
@@ -47,7 +47,7 @@ def _hip_step(wseed, inp, hr, noise):
     return m, out.detach().cpu(), loss.item(), {k: p.grad for k, p in m.named_parameters()}
 
 
-@pytest.mark.parametrize("path", GOLD, ids=lambda p: os.path.basename(p)[8:-4])
+@pytest.mark.parametrize("path", GOLD, ids=lambda p: os.path.basename(p)[13:-4])
 def test_hip_training_step_matches_reference_gradients(path):
     from oracle.cvsr_v8_ref import make_inputs
     g = np.load(path)

@@ -1,5 +1,5 @@
 """Pins the oracle as a GRADIENT oracle: torch autograd through the CPU restatement (oracle/cvsr_v8_ref.py) against the
-gradients of the REAL reference's training step (tests/golden/cvsr_v8_grad_*.npz, produced by oracle/gen_fixtures.py:
+gradients of the REAL reference's training step (tests/golden/grad_cvsr_v8_*.npz, produced by oracle/gen_fixtures.py:
 model.train(); sr, _ = model(...); CharbonnierLoss(sr, hr).backward() -- train_LD_37.py:376-381, opt/loss.py:20-31)."""
 import glob
 import os
@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 import torch
 
-GOLD = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "cvsr_v8_grad_*.npz")))
+GOLD = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "grad_cvsr_v8_*.npz")))
 
 
 def oracle_grads(g, dtype=torch.float32):
@@ -57,7 +57,7 @@ def compare_with_golden(g, grads, rel):
     return rows[0]
 
 
-@pytest.mark.parametrize("path", GOLD, ids=lambda p: os.path.basename(p)[8:-4])
+@pytest.mark.parametrize("path", GOLD, ids=lambda p: os.path.basename(p)[13:-4])
 def test_oracle_autograd_matches_reference_gradients(path):
     g = np.load(path)
     out, loss, grads = oracle_grads(g)

@@ -129,29 +129,45 @@ __global__ __launch_bounds__(256) void rdab_prep_kernel(const float* __restrict_
   }
 }
 
+// directH1_conv (arch.py:2162, 2225): 9 taps along the image rows.  A thread owns one (image, row segment, column, 4-channel
+// group) and slides down its segment with the nine input rows of the current output in registers: every input element is
+// read once per segment (the rows of a segment's 4 + 4 halo twice), coalesced across columns / channel groups.
+constexpr int CC9_SEG = 34;     // output rows per thread
 __global__ __launch_bounds__(256) void colconv9_kernel(const float* __restrict__ in, int ldi,
                                                        const float* __restrict__ wH, const float* __restrict__ bH,
-                                                       int B, int H, int W, float* __restrict__ out, int ldo) {
+                                                       int B, int H, int W, int nseg, float* __restrict__ out, int ldo) {
   float w9[9];
 #pragma unroll
   for (int t = 0; t < 9; ++t) w9[t] = wH[t];
   const float bb = bH[0];
-  const long long total = (long long)B * H * W * 16;
+  const long long total = (long long)B * nseg * W * 16;
   for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total;
        idx += (long long)gridDim.x * blockDim.x) {
     const int cg = idx & 15;
-    const long long p = idx >> 4;
-    const int x = p % W;
-    const int y = (p / W) % H;
-    const long long b = p / ((long long)W * H);
-    f32x4 acc = {bb, bb, bb, bb};
+    long long r = idx >> 4;
+    const int x = (int)(r % W); r /= W;
+    const int seg = (int)(r % nseg);
+    const long long b = r / nseg;
+    const int y0 = seg * CC9_SEG, y1 = min(H, y0 + CC9_SEG);
+    const float* col = in + (b * H * W + x) * ldi + cg * 4;
+    float* ocol = out + (b * H * W + x) * ldo + cg * 4;
+    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+    f32x4 win[9];                                        // win[t] = in[y + t - 4]
 #pragma unroll
-    for (int t = 0; t < 9; ++t) {
-      const int yy = y + t - 4;
-      if (yy < 0 || yy >= H) continue;
-      acc += w9[t] * *reinterpret_cast<const f32x4*>(in + ((b * H + yy) * W + x) * ldi + cg * 4);
+    for (int t = 0; t < 8; ++t) {
+      const int yy = y0 + t - 4;
+      win[t + 1] = (yy >= 0 && yy < H) ? *reinterpret_cast<const f32x4*>(col + (long long)yy * W * ldi) : z;
     }
-    *reinterpret_cast<f32x4*>(out + p * ldo + cg * 4) = acc;
+    for (int y = y0; y < y1; ++y) {
+#pragma unroll
+      for (int t = 0; t < 8; ++t) win[t] = win[t + 1];
+      const int yy = y + 4;
+      win[8] = yy < H ? *reinterpret_cast<const f32x4*>(col + (long long)yy * W * ldi) : z;
+      f32x4 acc = {bb, bb, bb, bb};
+#pragma unroll
+      for (int t = 0; t < 9; ++t) acc += w9[t] * win[t];
+      *reinterpret_cast<f32x4*>(ocol + (long long)y * W * ldo) = acc;
+    }
   }
 }
 
@@ -455,11 +471,12 @@ extern "C" int cdfo_colconv9(const float* in, int ldi, const float* wH, const fl
                              int ldo, void* stream) {
   if (B <= 0 || ldi % 4 || ldo % 4) return CDFO_EINVAL;
   if (!aligned16(in) || !aligned16(out)) return CDFO_EALIGN;
-  long long blocks = ((long long)B * H * W * 16 + 255) / 256;
+  const int nseg = cdiv(H, CC9_SEG);
+  long long blocks = ((long long)B * nseg * W * 16 + 255) / 256;
   if (blocks > 8192) blocks = 8192;
   CdfoProfScope prof(static_cast<hipStream_t>(stream), KID_COLCONV9, 0, 4.0*128*(double)B*H*W);
   hipLaunchKernelGGL(colconv9_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), in, ldi, wH,
-                     bH, B, H, W, out, ldo);
+                     bH, B, H, W, nseg, out, ldo);
   CDFO_LAUNCH_CHECK();
   return 0;
 }

@@ -141,6 +141,7 @@ class CVSR_V8(nn.Module):
         # HIP side streams for the two independent neighbour groups (frames 0-2 and 4-6): 1 = everything on the caller's
         # stream, 0 = auto = 2 (one side stream per group)
         self.neighbour_streams = 0
+        self.neighbour_group = 0        # frames per neighbour group: 0 = auto (3 at >= 3 clips, else 1)
         for key, shape, fan_in, init in _param_spec():
             t = torch.empty(shape)
             if init == "default":
@@ -506,24 +507,30 @@ class CVSR_V8(nn.Module):
         # images instead of three times on B.  Only what reads a per-neighbour input plane (prior stems, noise draw, motion
         # field) is launched per neighbour, into slices of the group's tensors.  The two groups are independent: with
         # `neighbour_streams` > 1 they are issued on two side streams (joined before the temporal fusion).
-        nstr = int(getattr(self, "neighbour_streams", 0)) or 2
+        nstr = int(getattr(self, "neighbour_streams", 0)) or (2 if B >= 3 else 6)
         main = torch.cuda.current_stream(x.device)
         side = []
         if nstr > 1:
             cache = self.__dict__.setdefault("_side_streams", {})
-            side = cache.get((x.device, 2))
+            side = cache.get((x.device, nstr))
             if side is None:
-                side = cache[(x.device, 2)] = [torch.cuda.Stream(x.device) for _ in range(2)]
+                side = cache[(x.device, nstr)] = [torch.cuda.Stream(x.device) for _ in range(nstr)]
         for st in side:
             st.wait_stream(main)
         keep = []
-        groups = [list(range(0, ctr)), list(range(ctr + 1, N))]
-        xcG = Lf[ctr].repeat(ctr, 1, 1, 1) if ctr > 1 else Lf[ctr]          # the centre features once per neighbour of a group
+        # group size: three frames per group at >= 3 clips (large launches, two groups on two streams); one frame per group
+        # (six independent pipelines on up to six streams) for one or two clips, where launches are small and concurrency is
+        # what fills the GPU (the streamed B = 1 sequence: 61 vs 58 frames/s)
+        gsz = int(getattr(self, "neighbour_group", 0)) or (ctr if B >= 3 else 1)
+        groups = [list(range(s, min(s + gsz, e))) for (s0, e) in ((0, ctr), (ctr + 1, N)) for s in range(s0, e, gsz)]
+        xcG = Lf[ctr].repeat(gsz, 1, 1, 1) if gsz > 1 else Lf[ctr]          # the centre features once per neighbour of a group
         aligned_by_frame = {}
+        draw0 = 0
         for gi, idxs in enumerate(groups):
-            ctx = torch.cuda.stream(side[gi]) if side else contextlib.nullcontext()
+            ctx = torch.cuda.stream(side[gi % len(side)]) if side else contextlib.nullcontext()
             with ctx:
-                al = self._neighbour_group(w, raw, Lf, idxs, xcG, ufs, rms, mvs1, noise, gi * ctr, B, H, W, P, N, keep)
+                al = self._neighbour_group(w, raw, Lf, idxs, xcG, ufs, rms, mvs1, noise, draw0, B, H, W, P, N, keep)
+            draw0 += len(idxs)
             if side:
                 al.record_stream(main)               # produced on a side stream, consumed on the caller's
             for n, i in enumerate(idxs):

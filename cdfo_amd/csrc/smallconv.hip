@@ -12,7 +12,7 @@ __global__ __launch_bounds__(256) void small_conv3x3_kernel(const float* __restr
                                                             const float* __restrict__ w,
                                                             const float* __restrict__ bias, int B, int H, int W, int Ho,
                                                             int Wo, int stride, int pad, int act,
-                                                            float* __restrict__ out, int ldo) {
+                                                            float* __restrict__ out, int ldo, _Float16* __restrict__ out_hl) {
   __shared__ __attribute__((aligned(16))) float sw[9 * CIN * COUT];
   for (int i = threadIdx.x; i < 9 * CIN * COUT; i += blockDim.x) {
     const int co = i % COUT, ci = (i / COUT) % CIN, t = i / (COUT * CIN);
@@ -64,7 +64,18 @@ __global__ __launch_bounds__(256) void small_conv3x3_kernel(const float* __restr
     }
 #pragma unroll
     for (int e = 0; e < 4; ++e) acc[e] = act_apply(acc[e], act);
-    *reinterpret_cast<f32x4*>(out + p * ldo + cg * 4) = acc;
+    if (out_hl) {        // fp16 hi | lo planes, chunk-planar [B][2][Ho*Wo][16]: the split-fp16 source of cdfo_conv3x3_ring
+      typedef _Float16 f16x4_t __attribute__((ext_vector_type(4)));
+      f16x4_t hi, lo;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { hi[e] = (_Float16)acc[e]; lo[e] = (_Float16)(acc[e] - (float)hi[e]); }
+      const long long P = (long long)Ho * Wo, pix = p - b * P;
+      _Float16* o16 = out_hl + ((b * 2) * P + pix) * 16 + cg * 4;
+      *reinterpret_cast<f16x4_t*>(o16) = hi;
+      *reinterpret_cast<f16x4_t*>(o16 + P * 16) = lo;
+    } else {
+      *reinterpret_cast<f32x4*>(out + p * ldo + cg * 4) = acc;
+    }
   }
 }
 
@@ -116,11 +127,11 @@ inline int grid_for(long long threads) {
 
 }  // namespace
 
-extern "C" int cdfo_small_conv16(const float* in, int ldi, const float* w, const float* bias, int B, int H, int W,
-                                 int stride, int pad, int out_pad, int transposed, int act, float* out, int ldo,
-                                 void* stream) {
-  if (B <= 0 || ldi % 4 || ldo % 4 || stride < 1) return CDFO_EINVAL;
-  if (!aligned16(in) || !aligned16(out) || (bias && !aligned16(bias))) return CDFO_EALIGN;
+static int small_conv16_launch(const float* in, int ldi, const float* w, const float* bias, int B, int H, int W, int stride,
+                               int pad, int out_pad, int transposed, int act, float* out, int ldo, void* out_hl, void* stream) {
+  if (B <= 0 || ldi % 4 || (!out_hl && ldo % 4) || stride < 1) return CDFO_EINVAL;
+  if (!aligned16(in) || (out && !aligned16(out)) || (out_hl && !aligned16(out_hl)) || (bias && !aligned16(bias))) return CDFO_EALIGN;
+  if (!out && !out_hl) return CDFO_EINVAL;
   int Ho, Wo;
   if (transposed) {
     Ho = (H - 1) * stride - 2 * pad + 3 + out_pad;
@@ -133,14 +144,28 @@ extern "C" int cdfo_small_conv16(const float* in, int ldi, const float* w, const
   const int grid = grid_for((long long)B * Ho * Wo * 4);
   hipStream_t st = static_cast<hipStream_t>(stream);
   CdfoProfScope prof(static_cast<hipStream_t>(stream), KID_SMALL_CONV, 2.0*9*256*(double)B*Ho*Wo, 4.0*16*((double)B*Ho*Wo+(double)B*H*W));
+  _Float16* hl = static_cast<_Float16*>(out_hl);
   if (transposed)
     hipLaunchKernelGGL((small_conv3x3_kernel<16, 16, true>), dim3(grid), dim3(256), 0, st, in, ldi, w, bias, B, H, W, Ho,
-                       Wo, stride, pad, act, out, ldo);
+                       Wo, stride, pad, act, out, ldo, hl);
   else
     hipLaunchKernelGGL((small_conv3x3_kernel<16, 16, false>), dim3(grid), dim3(256), 0, st, in, ldi, w, bias, B, H, W, Ho,
-                       Wo, stride, pad, act, out, ldo);
+                       Wo, stride, pad, act, out, ldo, hl);
   CDFO_LAUNCH_CHECK();
   return 0;
+}
+
+extern "C" int cdfo_small_conv16(const float* in, int ldi, const float* w, const float* bias, int B, int H, int W,
+                                 int stride, int pad, int out_pad, int transposed, int act, float* out, int ldo,
+                                 void* stream) {
+  return small_conv16_launch(in, ldi, w, bias, B, H, W, stride, pad, out_pad, transposed, act, out, ldo, nullptr, stream);
+}
+
+// The same with the result written as fp16 hi | lo planes, chunk-planar [B][2][Ho*Wo][16] (hi = fp16(v), lo = fp16(v - hi)):
+// the split-fp16 source of cdfo_conv3x3_ring (plane_wrap = 2) for the 16 -> 64 convolution that follows it in the prior U-net.
+extern "C" int cdfo_small_conv16_hl(const float* in, int ldi, const float* w, const float* bias, int B, int H, int W,
+                                    int stride, int pad, int out_pad, int transposed, int act, void* out_hl, void* stream) {
+  return small_conv16_launch(in, ldi, w, bias, B, H, W, stride, pad, out_pad, transposed, act, nullptr, 0, out_hl, stream);
 }
 
 extern "C" int cdfo_spatial_gate16(const float* in, int ldi, const float* w, const float* bias, int B, int H, int W,

@@ -239,6 +239,8 @@ class CVSR_V8(nn.Module):
                                                       sd[bp + "down.0.weight"], sd[bp + "down.0.bias"])
         fe = "transformer_feature_extraction.path1."
         w[fe + "conv_hl"] = K.pack_conv_hilo(sd[fe + "conv.weight"], sd[fe + "conv.bias"])
+        w[fe + "side_to_feaoneUDSA.body.11_hl"] = K.pack_conv_hilo(sd[fe + "side_to_feaoneUDSA.body.11.weight"],
+                                                                   sd[fe + "side_to_feaoneUDSA.body.11.bias"])
         w[fe + "qkv_dw"] = K.pack_qkv_dw(sd[fe + "attn.qkv.weight"], sd[fe + "norm1.body.weight"], sd[fe + "norm1.body.bias"])
         pc("upconv1", shuffle2=True)
         pc("upconv2", shuffle2=True)
@@ -270,6 +272,12 @@ class CVSR_V8(nn.Module):
         t = K.small_conv16(t, raw[u + "4.weight"], raw[u + "4.bias"], 2, 2, act=K.ACT_LRELU)
         t = K.spatial_gate16(t, raw[u + "6.spatial.weight"], raw[u + "6.spatial.bias"])
         t = K.small_conv16(t, raw[u + "7.weight"], raw[u + "7.bias"], 2, 2, 0, True, K.ACT_LRELU)
+        if self.precision == "fp16x2":
+            # the last transposed conv writes fp16 hi | lo planes; the 16 -> 64 conv (+ LeakyReLU + residual) then runs as a
+            # split-fp16, fp32-grade product (a_hi*w_hi + a_lo*w_hi + a_hi*w_lo) on the LDS-DMA ring kernel, like the
+            # feature extractor's 64 -> 64 conv: 3 K chunks per tile instead of the tiled kernel's restaging (1.57 -> ~0.6 ms)
+            t = K.small_conv16(t, raw[u + "9.weight"], raw[u + "9.bias"], 2, 2, 1, True, K.ACT_LRELU, out_hl=True)
+            return K.conv_ring(t, w[u + "11_hl"], act=K.ACT_LRELU, res1=res, plane_wrap=2)
         t = K.small_conv16(t, raw[u + "9.weight"], raw[u + "9.bias"], 2, 2, 1, True, K.ACT_LRELU)
         return self._conv(t, w[u + "11"], pad=1, act=K.ACT_LRELU, res1=res, exact=True)
 

@@ -565,13 +565,19 @@ def conv_last(x: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, xc: torch.Te
 
 
 def small_conv16(x: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, stride: int, pad: int, out_pad: int = 0,
-                 transposed: bool = False, act: int = ACT_NONE) -> torch.Tensor:
+                 transposed: bool = False, act: int = ACT_NONE, out_hl: bool = False) -> torch.Tensor:
+    """out_hl: return the result as fp16 hi | lo chunk-planar planes [B, 2, Ho, Wo, 16] (source of conv_ring with plane_wrap=2)."""
     B, H, W, Cc, ld = _chk_act(x)
     assert Cc == 16
     if transposed:
         Ho, Wo = (H - 1) * stride - 2 * pad + 3 + out_pad, (W - 1) * stride - 2 * pad + 3 + out_pad
     else:
         Ho, Wo = (H + 2 * pad - 3) // stride + 1, (W + 2 * pad - 3) // stride + 1
+    if out_hl:
+        hl = torch.empty((B, 2, Ho, Wo, 16), dtype=torch.float16, device=x.device)
+        check(_lib.lib().cdfo_small_conv16_hl(_vp(x), ld, _vp(w), _vp(bias), B, H, W, stride, pad, out_pad, int(transposed), act,
+                                              _vp(hl), _stream()), "cdfo_small_conv16_hl")
+        return hl
     out = empty_act(B, Ho, Wo, 16, x.device)
     check(_lib.lib().cdfo_small_conv16(_vp(x), ld, _vp(w), _vp(bias), B, H, W, stride, pad, out_pad, int(transposed),
                                        act, _vp(out), 16, _stream()), "cdfo_small_conv16")

@@ -161,6 +161,9 @@ int cdfo_conv_last(const float* in, int ldi, const float* w, const float* bias, 
 /* ---- thin 16-channel layers of the prior U-net (smallconv.hip; arch.py:1815-1834, 2719-2730) --------------- */
 int cdfo_small_conv16(const float* in, int ldi, const float* w, const float* bias, int B, int H, int W, int stride,
                       int pad, int out_pad, int transposed, int act, float* out, int ldo, void* stream);
+/* the same, result as fp16 hi | lo planes [B][2][Ho*Wo][16] (chunk-planar): the split-fp16 source of cdfo_conv3x3_ring */
+int cdfo_small_conv16_hl(const float* in, int ldi, const float* w, const float* bias, int B, int H, int W, int stride,
+                         int pad, int out_pad, int transposed, int act, void* out_hl, void* stream);
 int cdfo_spatial_gate16(const float* in, int ldi, const float* w, const float* bias, int B, int H, int W, float* out,
                         int ldo, void* stream);
 

@@ -142,6 +142,11 @@ class CVSR_V8(nn.Module):
         # stream, 0 = auto = 2 (one side stream per group)
         self.neighbour_streams = 0
         self.neighbour_group = 0        # frames per neighbour group: 0 = auto (3 at >= 3 clips, else 1)
+        # fp16x2 mode, the feature extractor's two 3x3 convolutions on the ring kernel: True = activations fp16 hi + lo x
+        # weights fp16 hi + lo (three terms, fp32-grade: L1_fea 1.3e-5 max-abs); False = weights rounded once to fp16 (two
+        # terms): measured 1.7e-3 on the RETURNED feature cache (|L1_fea| up to 7), outside the 1e-3 bound, for 1.3 ms per
+        # step -- so the three-term product stays.  Set before the first forward (it selects the weight packing).
+        self.fe_weight_lo = True
         for key, shape, fan_in, init in _param_spec():
             t = torch.empty(shape)
             if init == "default":
@@ -238,9 +243,10 @@ class CVSR_V8(nn.Module):
                 w[bp + "pro"] = K.pack_block_prologue(sd[bp + "up.0.weight"], sd[bp + "up.0.bias"],
                                                       sd[bp + "down.0.weight"], sd[bp + "down.0.bias"])
         fe = "transformer_feature_extraction.path1."
-        w[fe + "conv_hl"] = K.pack_conv_hilo(sd[fe + "conv.weight"], sd[fe + "conv.bias"])
+        wlo = bool(getattr(self, "fe_weight_lo", True))
+        w[fe + "conv_hl"] = K.pack_conv_hilo(sd[fe + "conv.weight"], sd[fe + "conv.bias"], wlo)
         w[fe + "side_to_feaoneUDSA.body.11_hl"] = K.pack_conv_hilo(sd[fe + "side_to_feaoneUDSA.body.11.weight"],
-                                                                   sd[fe + "side_to_feaoneUDSA.body.11.bias"])
+                                                                   sd[fe + "side_to_feaoneUDSA.body.11.bias"], wlo)
         w[fe + "qkv_dw"] = K.pack_qkv_dw(sd[fe + "attn.qkv.weight"], sd[fe + "norm1.body.weight"], sd[fe + "norm1.body.bias"])
         pc("upconv1", shuffle2=True)
         pc("upconv2", shuffle2=True)

@@ -477,12 +477,14 @@ def layernorm64_hl(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor) -> 
     return out
 
 
-def pack_conv_hilo(weight: torch.Tensor, bias: Optional[torch.Tensor]) -> PackedConv:
+def pack_conv_hilo(weight: torch.Tensor, bias: Optional[torch.Tensor], weight_lo: bool = True) -> PackedConv:
     """3x3 weight for the split-fp16 product on the ring kernel: K-expanded (w_hi | w_hi | w_lo) along the input channels,
-    to be used with a source of hi | lo planes and plane_wrap = 2 * Cin / 16: a_hi*w_hi + a_lo*w_hi + a_hi*w_lo."""
+    to be used with a source of hi | lo planes and plane_wrap = 2 * Cin / 16: a_hi*w_hi + a_lo*w_hi + a_hi*w_lo.
+    weight_lo=False drops the third term (weights rounded once to fp16, activations still hi + lo: the "fp16x2" arithmetic
+    of the tiled kernel): (w_hi | w_hi), a third fewer K chunks."""
     w = weight.detach().float()
     wh = w.half().float()
-    return pack_conv(torch.cat([wh, wh, w - wh], 1).contiguous(), bias)
+    return pack_conv(torch.cat([wh, wh, w - wh] if weight_lo else [wh, wh], 1).contiguous(), bias)
 
 
 def dwconv3x3(x: torch.Tensor, w: torch.Tensor) -> torch.Tensor:

@@ -368,10 +368,8 @@ int ws_launch(const ws_args& a, int grid, hipStream_t st) {
 }
 
 // fp32 pixel-major [B][P][ld] -> fp16 chunk-planar [B][C/16][P][16]
-// (planes_total / plane_off: the result occupies planes [plane_off, plane_off + C/16) of a [B][planes_total][P][16] tensor,
-// so that several sources can be laid side by side as the chunk-planar source of ONE convolution)
 __global__ __launch_bounds__(256) void to_cp16_kernel(const float* __restrict__ in, int ldi, int B, long long P, int C,
-                                                      _Float16* __restrict__ out, int planes_total, int plane_off) {
+                                                      _Float16* __restrict__ out) {
   const int nc = C >> 4;
   const long long total = (long long)B * nc * P * 4;
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
@@ -385,7 +383,7 @@ __global__ __launch_bounds__(256) void to_cp16_kernel(const float* __restrict__ 
     f16x4_t hv;
 #pragma unroll
     for (int k = 0; k < 4; ++k) hv[k] = (_Float16)v[k];
-    *reinterpret_cast<f16x4_t*>(out + (((b * planes_total + plane_off + c) * P + p) * 4 + g) * 4) = hv;
+    *reinterpret_cast<f16x4_t*>(out + i * 4) = hv;
   }
 }
 
@@ -471,19 +469,14 @@ extern "C" int cdfo_conv3x3_c64_ws_res(const void* src_cp16, int B, int H, int W
   return 0;
 }
 
-extern "C" int cdfo_to_cp16_into(const float* in, int ldi, int B, long long P, int C, void* out_cp16, int planes_total, int plane_off,
-                                 void* stream) {
-  if (B <= 0 || P <= 0 || C <= 0 || C % 16 || ldi % 4 || ldi < C || plane_off < 0 || planes_total < plane_off + C / 16) return CDFO_EINVAL;
+extern "C" int cdfo_to_cp16(const float* in, int ldi, int B, long long P, int C, void* out_cp16, void* stream) {
+  if (B <= 0 || P <= 0 || C <= 0 || C % 16 || ldi % 4 || ldi < C) return CDFO_EINVAL;
   if (!aligned16(in) || !aligned16(out_cp16)) return CDFO_EALIGN;
   const long long threads = (long long)B * (C / 16) * P * 4;
   const long long blocks = (threads + 255) / 256;
   CdfoProfScope prof(static_cast<hipStream_t>(stream), KID_LAYOUT, 0, 6.0 * C * (double)B * P);
   hipLaunchKernelGGL(to_cp16_kernel, dim3((unsigned)(blocks > 16384 ? 16384 : blocks)), dim3(256), 0,
-                     static_cast<hipStream_t>(stream), in, ldi, B, P, C, static_cast<_Float16*>(out_cp16), planes_total, plane_off);
+                     static_cast<hipStream_t>(stream), in, ldi, B, P, C, static_cast<_Float16*>(out_cp16));
   CDFO_LAUNCH_CHECK();
   return 0;
-}
-
-extern "C" int cdfo_to_cp16(const float* in, int ldi, int B, long long P, int C, void* out_cp16, void* stream) {
-  return cdfo_to_cp16_into(in, ldi, B, P, C, out_cp16, C / 16, 0, stream);
 }

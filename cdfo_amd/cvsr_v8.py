@@ -421,19 +421,13 @@ class CVSR_V8(nn.Module):
         return (y, None) if want16 else y
 
     def _trunk(self, w, fused):
-        y, y16 = fused, None
+        y = fused
         for g in range(7):
-            r, r16 = y, y16
-            for b in range(3):      # every block hands its successor an fp16 chunk-planar copy of its result
-                r, r16 = self._block(w, f"recon_trunk.body.{g}.body.{b}.", r, r16, want16=True)
-            gc = w[f"recon_trunk.body.{g}.conv"]
-            if r16 is not None and gc.wh is not None:
-                # the group's closing 3x3 conv (+ group skip, + the trunk's skip after the last group) on the residual form of
-                # the weights-stationary kernel, reading the last block's fp16 copy and writing the next group's
-                y16 = torch.empty_like(r16) if g < 6 else None
-                y = K.conv3x3_ws_res(r16, gc, res1=y, res2=fused if g == 6 else None, out2_cp16=y16)
-            else:
-                y, y16 = self._conv(r, gc, pad=1, res1=y, res2=fused if g == 6 else None), None
+            r, r16 = y, None
+            for b in range(3):      # blocks 0 and 1 hand their successor an fp16 chunk-planar copy of the result
+                r, r16 = self._block(w, f"recon_trunk.body.{g}.body.{b}.", r, r16, want16=True) if b < 2 else \
+                    (self._block(w, f"recon_trunk.body.{g}.body.{b}.", r, r16), None)
+            y = self._conv(r, w[f"recon_trunk.body.{g}.conv"], pad=1, res1=y, res2=fused if g == 6 else None)
         return y
 
     # -- forward ---------------------------------------------------------------------------------------------------
@@ -602,12 +596,7 @@ class CVSR_V8(nn.Module):
             else:
                 noises.append(noise[draw].to(device=x_dev, dtype=torch.float32).contiguous())
         x_n = self._rdab(w, rms_prior, fea_com, noises)
-        if self.precision == "fp16x2" and w["conv_expand_fea_r"].wh is not None:
-            # conv_expand_fea_r (3x3, 128 -> 64) on the LDS-DMA ring kernel: its two sources laid side by side as one fp16
-            # chunk-planar tensor (one rounding to fp16, single-pass MFMA like the convolutions inside Block_)
-            fea_i = K.conv_ring(K.cat_cp16([feaG, x_n]), w["conv_expand_fea_r"])
-        else:
-            fea_i = self._conv([feaG, x_n], w["conv_expand_fea_r"], pad=1)
+        fea_i = self._conv([feaG, x_n], w["conv_expand_fea_r"], pad=1)
         al = K.empty_act(GB, H, W, NF, x_dev)
         xc = xcG if xcG.shape[0] == GB else xcG[:GB]
         self._align(w, xc, fea_i, ufs_prior, [mvs1[:, i] for i in idxs], N * 2 * P, al)

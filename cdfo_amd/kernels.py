@@ -226,22 +226,6 @@ def to_cp16(x: torch.Tensor) -> torch.Tensor:
     return out
 
 
-def cat_cp16(srcs: Sequence[torch.Tensor]) -> torch.Tensor:
-    """fp32 pixel-major sources [B,H,W,C_i] -> ONE fp16 chunk-planar tensor [B, sum(C_i)/16, H, W, 16] (their concatenation
-    along the channels, each source rounded once to fp16): the source of a single-pass convolution on conv_ring / conv3x3_ws."""
-    B, H, W, _, _ = _chk_act(srcs[0])
-    planes = sum(s.shape[3] for s in srcs) // 16
-    out = torch.empty((B, planes, H, W, 16), dtype=torch.float16, device=srcs[0].device)
-    off = 0
-    for s in srcs:
-        b_, h_, w_, c_, ld = _chk_act(s)
-        if (b_, h_, w_) != (B, H, W) or c_ % 16:
-            raise ValueError("cat_cp16: sources must share B/H/W and have channel counts that are multiples of 16")
-        check(_lib.lib().cdfo_to_cp16_into(_vp(s), ld, B, C.c_longlong(H * W), c_, _vp(out), planes, off, _stream()), "cdfo_to_cp16_into")
-        off += c_ // 16
-    return out
-
-
 def conv3x3_ws(src: torch.Tensor, pc: PackedConv, *, act: int = ACT_NONE, s2d: bool = False,
                out: Optional[torch.Tensor] = None, dbg: int = 0, clk: Optional[torch.Tensor] = None) -> torch.Tensor:
     """Block_.body[0]-shaped convolution (3x3, 64 input channels, Cout % 64 == 0) on the weights-stationary kernel.

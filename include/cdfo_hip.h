@@ -107,9 +107,6 @@ int cdfo_conv3x3_c64_ws_res(const void* src_cp16, int B, int H, int W, const voi
 int cdfo_conv3x3_ring(const cdfo_conv_args* a, void* stream);
 /* fp32 pixel-major [B][P][ldi] (C channels, C % 16 == 0) -> fp16 chunk-planar [B][C/16][P][16].  */
 int cdfo_to_cp16(const float* in, int ldi, int B, long long P, int C, void* out_cp16, void* stream);
-/* the same into planes [plane_off, plane_off + C/16) of a [B][planes_total][P][16] tensor (sources laid side by side) */
-int cdfo_to_cp16_into(const float* in, int ldi, int B, long long P, int C, void* out_cp16, int planes_total, int plane_off,
-                      void* stream);
 
 /* 1x1 convolution as an HBM-streaming GEMM in split-bf16 (3-pass, fp32-grade) arithmetic; same argument block and
  * epilogue as cdfo_conv_igemm with ks = 1 (fp32 packing of cdfo_pack_conv_weight, per-image weights, fused LayerNorm,

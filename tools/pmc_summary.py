@@ -1,0 +1,46 @@
+"""Developer tool: summarise rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (separate runs) per kernel symbol.
+    python tools/pmc_summary.py <fetch_dir> <write_dir> <out.txt> [--json <out.json> <kernel-substring> <family> <precision>]
+FETCH_SIZE reads 1/2 of the bytes of a 16-B/lane coalesced stream on gfx950 (MI355X_MICROARCH.md, HBM): HBM bytes = 2 * FETCH + WRITE."""
+import csv, glob, json, os, sys
+from collections import defaultdict
+
+
+def collect(d, name):
+    acc = defaultdict(list)
+    for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+        for r in csv.DictReader(open(f)):
+            if r["Counter_Name"] == name:
+                acc[r["Kernel_Name"]].append(float(r["Counter_Value"]))
+    return acc
+
+
+def main():
+    fetch_dir, write_dir, out = sys.argv[1:4]
+    F, Wr = collect(fetch_dir, "FETCH_SIZE"), collect(write_dir, "WRITE_SIZE")
+    rows = []
+    for k in set(F) | set(Wr):
+        f = sum(F.get(k, [0])) / max(1, len(F.get(k, [])))
+        w = sum(Wr.get(k, [0])) / max(1, len(Wr.get(k, [])))
+        n = max(len(F.get(k, [])), len(Wr.get(k, [])))
+        rows.append(((2 * f + w) * n, k, n, f, w))
+    rows.sort(reverse=True)
+    with open(out, "w") as fh:
+        fh.write("# rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (two separate passes, no trace domains): per kernel symbol the launches,\n"
+                 "# mean KiB per launch as reported, HBM bytes per launch = (2 * FETCH + WRITE) * 1024 (gfx950: FETCH_SIZE reads half of a\n"
+                 "# 16-B/lane stream, MI355X_MICROARCH.md), and the total over the run in GiB.\n")
+        fh.write("launches  FETCH_KiB  WRITE_KiB  HBM_MB_per_launch  total_GiB  kernel\n")
+        for tot, k, n, f, w in rows[:40]:
+            fh.write(f"{n:6d} {f:12.1f} {w:12.1f} {(2 * f + w) * 1024 / 1e6:12.1f} {tot * 1024 / 2**30:10.2f}  {k[:150]}\n")
+    if "--json" in sys.argv:
+        i = sys.argv.index("--json")
+        jpath, kern, family, prec = sys.argv[i + 1:i + 5]
+        fk = [v for k, vs in F.items() if kern in k for v in vs]
+        wk = [v for k, vs in Wr.items() if kern in k for v in vs]
+        f, w = sum(fk) / len(fk), sum(wk) / len(wk)
+        json.dump({"kernel": family, "precision": prec, "kernel_symbol_contains": kern, "launches_averaged": [len(fk), len(wk)],
+                   "fetch_kib_raw": f, "write_kib_raw": w, "fetch_correction": 2.0, "hbm_bytes_per_launch": round((2.0 * f + w) * 1024.0),
+                   "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), tools/pmc_summary.py"}, open(jpath, "w"), indent=1)
+
+
+if __name__ == "__main__":
+    main()

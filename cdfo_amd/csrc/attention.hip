@@ -270,18 +270,27 @@ __global__ __launch_bounds__(64) void seq_attn_kernel(const float* __restrict__ 
 typedef _Float16 attn_f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 attn_f16x4 __attribute__((ext_vector_type(4)));
 
-template <int MODE>   // 0: sequence = image row, 1: image column, 2: 8x8 window (64 pixels, row-major inside the window)
-__global__ __launch_bounds__(256) void seq_attn_mfma_kernel(const float* __restrict__ q, int ldq,
-                                                            const float* __restrict__ v, int ldv,
-                                                            float* __restrict__ out, int ldo, int B, int H, int W) {
+// NW waves per workgroup = 32*NW queries of one sequence at most; a stage is 8*NW keys (NW/4 sub-tiles of 32), staged by
+// all NW*64 threads with one 4-key x 4-channel unit each -- the larger the workgroup, the less staging work (loads,
+// fp32 -> fp16 hi/lo splits, LDS writes) per query.  The query tiles of a sequence are spread evenly over its workgroups
+// (tpb tiles each; waves >= tpb only stage).  The kernel is VALU-bound (softmax + splits), not MFMA-bound, hence:
+// scores in the log2 domain (Q is scaled by log2 e once, p = v_exp_f32(s - m) -- one instruction instead of expf's ten),
+// key masking only in a sequence's last sub-tile, and the accumulator rescale skipped while no lane's running maximum moves.
+template <int MODE, int NW>   // MODE 0: sequence = image row, 1: image column, 2: 8x8 window (row-major inside the window)
+__global__ __launch_bounds__(NW * 64) void seq_attn_mfma_kernel(const float* __restrict__ q, int ldq,
+                                                                const float* __restrict__ v, int ldv,
+                                                                float* __restrict__ out, int ldo, int B, int H, int W,
+                                                                int nb, int tpb) {
   constexpr int KROW = 272;                                 // bytes per staged key row: 128 B hi | 128 B lo | 16 B pad
-  __shared__ __attribute__((aligned(16))) unsigned char sK[2][32 * KROW];
-  // V^T: row = channel (128 B: four 16-byte hi slots 2u+h, four lo slots 4+2u+h), slot index XORed with (ch>>1)&7 so
-  // that the 16 channels of a ds_read_b128 lane group hit 16 distinct 16-byte slots
-  __shared__ __attribute__((aligned(16))) unsigned char sV[2][64 * 128];
+  constexpr int NT = NW * 64, SUB = NW / 4, KT = 32 * SUB, KQ = KT / 4;
+  constexpr int K_BYTES = KT * KROW, V_BYTES = SUB * 64 * 128;
+  extern __shared__ __attribute__((aligned(16))) unsigned char attn_smem[];
+  unsigned char* const sK = attn_smem;                      // [2][KT][KROW]
+  // V^T per sub-tile: row = channel (128 B: four 16-byte hi slots 2u+h, four lo slots 4+2u+h), slot index XORed with
+  // (ch>>1)&7 so that the 16 channels of a ds_read_b128 lane group hit 16 distinct 16-byte slots
+  unsigned char* const sV = attn_smem + 2 * K_BYTES;        // [2][SUB][64][128]
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, h = lane >> 5, r = lane & 31;
   const int L = MODE == 0 ? W : (MODE == 1 ? H : 64);
-  const int nb = (L + 127) / 128;
   const int blk = blockIdx.x % nb;
   const long long seq = blockIdx.x / nb;
   long long kbase;
@@ -296,18 +305,19 @@ __global__ __launch_bounds__(256) void seq_attn_mfma_kernel(const float* __restr
   auto pix_of = [&](int i) -> long long {                   // pixel of element i of the sequence
     return MODE == 0 ? kbase + i : (MODE == 1 ? kbase + (long long)i * W : kbase + (long long)(i >> 3) * W + (i & 7));
   };
-  const int q0 = blk * 128 + wave * 32;                     // this wave's first query
-  const bool wave_active = q0 < L;
+  const int q0 = (blk * tpb + wave) * 32;                   // this wave's first query
+  const bool wave_active = wave < tpb && q0 < L;
   int qi = q0 + r;
   const bool q_ok = qi < L;
-  if (!q_ok) qi = L - 1;
+  if (qi >= L) qi = L - 1;
   const long long qpix = pix_of(qi);
 
-  attn_f16x8 qh[4], ql[4];                                  // Q[r][16s + 8h + j], fp16 hi / lo
+  attn_f16x8 qh[4], ql[4];                                  // log2(e) * Q[r][16s + 8h + j], fp16 hi / lo
+  constexpr float LOG2E = 1.4426950408889634f;
 #pragma unroll
   for (int s = 0; s < 4; ++s) {
-    const f32x4 t0 = *reinterpret_cast<const f32x4*>(q + qpix * ldq + 16 * s + 8 * h);
-    const f32x4 t1 = *reinterpret_cast<const f32x4*>(q + qpix * ldq + 16 * s + 8 * h + 4);
+    const f32x4 t0 = *reinterpret_cast<const f32x4*>(q + qpix * ldq + 16 * s + 8 * h) * LOG2E;
+    const f32x4 t1 = *reinterpret_cast<const f32x4*>(q + qpix * ldq + 16 * s + 8 * h + 4) * LOG2E;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       qh[s][e] = (_Float16)t0[e];      ql[s][e] = (_Float16)(t0[e] - (float)qh[s][e]);
@@ -317,35 +327,36 @@ __global__ __launch_bounds__(256) void seq_attn_mfma_kernel(const float* __restr
   f32x16 o0, o1;
 #pragma unroll
   for (int e = 0; e < 16; ++e) { o0[e] = 0.f; o1[e] = 0.f; }
-  float m = -INFINITY, l = 0.f;
+  float m = -INFINITY, l = 0.f;                             // running maximum (log2 domain) and sum of this half-wave's keys
 
-  // staging (4 float4 loads per thread): threads 0-127 take V -- keys 4m..4m+3 x channels 4c..4c+3 each --, threads
-  // 128-255 take K -- keys kk + 8s (s = 0..3) x channels 4c..4c+3
-  const bool st_v = tid < 128;
-  const int sm = (tid >> 4) & 7, sc4 = tid & 15;
+  // staging (4 float4 loads per thread and stage): the first NT/2 threads take V -- keys 4sm..4sm+3 x channels 4c..4c+3
+  // each --, the others K -- keys sm + KQ*s (s = 0..3) x channels 4c..4c+3
+  const bool st_v = tid < NT / 2;
+  const int sj = st_v ? tid : tid - NT / 2, sm = sj >> 4, sc4 = sj & 15;
+  const float* const sbase = (st_v ? v : q) + sc4 * 4;
+  const int sld = st_v ? ldv : ldq;
   f32x4 rs[4];
   auto load_tile = [&](int t0) {
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
-      int key = t0 + (st_v ? 4 * sm + s : sm + 8 * s);
+      int key = t0 + (st_v ? 4 * sm + s : sm + KQ * s);
       key = key < L ? key : L - 1;                          // clamped (masked below), always loaded
-      const long long kp = pix_of(key);
-      rs[s] = *reinterpret_cast<const f32x4*>((st_v ? v + kp * ldv : q + kp * ldq) + sc4 * 4);
+      rs[s] = *reinterpret_cast<const f32x4*>(sbase + pix_of(key) * sld);
     }
   };
   auto write_tile = [&](int buf) {
     if (st_v) {
-      // keys 4m..4m+3 = slots 16u + 8hh + 4g + (0..3) with u = m>>2, hh = m&1, g = (m&3)>>1
-      const int c = 2 * (sm >> 2) + (sm & 1), g = (sm & 3) >> 1;
+      // keys 4m..4m+3 of sub-tile sm>>3 = slots 16u + 8hh + 4g + (0..3) with m = sm&7, u = m>>2, hh = m&1, g = (m&3)>>1
+      const int mm = sm & 7, c = 2 * (mm >> 2) + (mm & 1), g = (mm & 3) >> 1;
+      unsigned char* const vb = sV + buf * V_BYTES + (sm >> 3) * 8192 + g * 8;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const int ch = 4 * sc4 + e, swz = (ch >> 1) & 7;
         attn_f16x4 vh, vl;
 #pragma unroll
         for (int k = 0; k < 4; ++k) { vh[k] = (_Float16)rs[k][e]; vl[k] = (_Float16)(rs[k][e] - (float)vh[k]); }
-        unsigned char* row = &sV[buf][ch * 128 + g * 8];
-        *reinterpret_cast<attn_f16x4*>(row + ((c ^ swz) * 16)) = vh;
-        *reinterpret_cast<attn_f16x4*>(row + (((4 + c) ^ swz) * 16)) = vl;
+        *reinterpret_cast<attn_f16x4*>(vb + ch * 128 + ((c ^ swz) * 16)) = vh;
+        *reinterpret_cast<attn_f16x4*>(vb + ch * 128 + (((4 + c) ^ swz) * 16)) = vl;
       }
     } else {
 #pragma unroll
@@ -353,72 +364,81 @@ __global__ __launch_bounds__(256) void seq_attn_mfma_kernel(const float* __restr
         attn_f16x4 kh, kl;
 #pragma unroll
         for (int e = 0; e < 4; ++e) { kh[e] = (_Float16)rs[s][e]; kl[e] = (_Float16)(rs[s][e] - (float)kh[e]); }
-        unsigned char* row = &sK[buf][(sm + 8 * s) * KROW + sc4 * 8];
+        unsigned char* row = sK + buf * K_BYTES + (sm + KQ * s) * KROW + sc4 * 8;
         *reinterpret_cast<attn_f16x4*>(row) = kh;
         *reinterpret_cast<attn_f16x4*>(row + 128) = kl;
       }
     }
   };
 
-  const int ntiles = (L + 31) / 32;
+  const int nstages = (L + KT - 1) / KT;
   load_tile(0);
   write_tile(0);
   __syncthreads();
-  for (int t = 0; t < ntiles; ++t) {
+  for (int t = 0; t < nstages; ++t) {
     const int buf = t & 1;
-    if (t + 1 < ntiles) load_tile((t + 1) * 32);
+    if (t + 1 < nstages) load_tile((t + 1) * KT);
     if (wave_active) {
-      // ---- S^T = K Q^T
-      f32x16 sacc;
 #pragma unroll
-      for (int e = 0; e < 16; ++e) sacc[e] = 0.f;
+      for (int sub = 0; sub < SUB; ++sub) {
+        const int kv_left = L - (t * KT + sub * 32);        // keys of this sub-tile that exist (>= 32: all)
+        if (kv_left <= 0) break;
+        // ---- S^T = K Q^T (log2 domain)
+        f32x16 sacc;
 #pragma unroll
-      for (int s = 0; s < 4; ++s) {
-        const unsigned char* row = &sK[buf][r * KROW + (16 * s + 8 * h) * 2];
-        const attn_f16x8 kh = *reinterpret_cast<const attn_f16x8*>(row);
-        const attn_f16x8 kl = *reinterpret_cast<const attn_f16x8*>(row + 128);
-        sacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl, qh[s], sacc, 0, 0, 0);
-        sacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, ql[s], sacc, 0, 0, 0);
-        sacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, qh[s], sacc, 0, 0, 0);
-      }
-      // ---- online softmax over this tile's 32 keys (16 here, 16 in the partner half-wave)
-      const int kv_left = L - t * 32;                       // keys beyond L are masked
-      float tmax = -INFINITY;
+        for (int e = 0; e < 16; ++e) sacc[e] = 0.f;
+        const unsigned char* const kb = sK + buf * K_BYTES + (sub * 32 + r) * KROW + 16 * h;
 #pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int key = (e & 3) + 8 * (e >> 2) + 4 * h;
-        if (key >= kv_left) sacc[e] = -INFINITY;
-        tmax = fmaxf(tmax, sacc[e]);
-      }
-      tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
-      const float mn = fmaxf(m, tmax);
-      const float alpha = expf(m - mn);
-      m = mn;
-      float psum = 0.f;
+        for (int s = 0; s < 4; ++s) {
+          const attn_f16x8 kh = *reinterpret_cast<const attn_f16x8*>(kb + 32 * s);
+          const attn_f16x8 kl = *reinterpret_cast<const attn_f16x8*>(kb + 32 * s + 128);
+          sacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl, qh[s], sacc, 0, 0, 0);
+          sacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, ql[s], sacc, 0, 0, 0);
+          sacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, qh[s], sacc, 0, 0, 0);
+        }
+        // ---- online softmax over this sub-tile's 32 keys (16 here, 16 in the partner half-wave)
+        if (kv_left < 32) {                                 // only a sequence's last sub-tile has keys to mask
 #pragma unroll
-      for (int e = 0; e < 16; ++e) { sacc[e] = expf(sacc[e] - mn); psum += sacc[e]; }
-      l = l * alpha + psum;
+          for (int e = 0; e < 16; ++e)
+            if ((e & 3) + 8 * (e >> 2) + 4 * h >= kv_left) sacc[e] = -INFINITY;
+        }
+        float tmax = sacc[0];
 #pragma unroll
-      for (int e = 0; e < 16; ++e) { o0[e] *= alpha; o1[e] *= alpha; }
-      // ---- O^T += V^T P^T
+        for (int e = 1; e < 16; ++e) tmax = fmaxf(tmax, sacc[e]);
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+        const float mn = fmaxf(m, tmax);
+        if (__any(mn > m)) {                                // some lane's running maximum moved: rescale
+          const float alpha = __builtin_amdgcn_exp2f(m - mn);
+          l *= alpha;
 #pragma unroll
-      for (int u = 0; u < 2; ++u) {
-        attn_f16x8 ph, pl;
+          for (int e = 0; e < 16; ++e) { o0[e] *= alpha; o1[e] *= alpha; }
+          m = mn;
+        }
+        float psum = 0.f;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) { ph[j] = (_Float16)sacc[8 * u + j]; pl[j] = (_Float16)(sacc[8 * u + j] - (float)ph[j]); }
+        for (int e = 0; e < 16; ++e) { sacc[e] = __builtin_amdgcn_exp2f(sacc[e] - m); psum += sacc[e]; }
+        l += psum;
+        // ---- O^T += V^T P^T
+        const unsigned char* const vb = sV + buf * V_BYTES + sub * 8192;
 #pragma unroll
-        for (int half = 0; half < 2; ++half) {              // channels 0-31 -> o0, 32-63 -> o1
-          const int ch = 32 * half + r, swz = (ch >> 1) & 7, c = 2 * u + h;
-          const attn_f16x8 vh = *reinterpret_cast<const attn_f16x8*>(&sV[buf][ch * 128 + ((c ^ swz) * 16)]);
-          const attn_f16x8 vl = *reinterpret_cast<const attn_f16x8*>(&sV[buf][ch * 128 + (((4 + c) ^ swz) * 16)]);
-          f32x16& o = half ? o1 : o0;
-          o = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl, ph, o, 0, 0, 0);
-          o = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, pl, o, 0, 0, 0);
-          o = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, ph, o, 0, 0, 0);
+        for (int u = 0; u < 2; ++u) {
+          attn_f16x8 ph, pl;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) { ph[j] = (_Float16)sacc[8 * u + j]; pl[j] = (_Float16)(sacc[8 * u + j] - (float)ph[j]); }
+#pragma unroll
+          for (int half = 0; half < 2; ++half) {            // channels 0-31 -> o0, 32-63 -> o1
+            const int ch = 32 * half + r, swz = (ch >> 1) & 7, c = 2 * u + h;
+            const attn_f16x8 vh = *reinterpret_cast<const attn_f16x8*>(vb + ch * 128 + ((c ^ swz) * 16));
+            const attn_f16x8 vl = *reinterpret_cast<const attn_f16x8*>(vb + ch * 128 + (((4 + c) ^ swz) * 16));
+            f32x16& o = half ? o1 : o0;
+            o = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl, ph, o, 0, 0, 0);
+            o = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, pl, o, 0, 0, 0);
+            o = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, ph, o, 0, 0, 0);
+          }
         }
       }
     }
-    if (t + 1 < ntiles) write_tile(buf ^ 1);
+    if (t + 1 < nstages) write_tile(buf ^ 1);
     __syncthreads();
   }
   if (wave_active) {
@@ -436,6 +456,21 @@ __global__ __launch_bounds__(256) void seq_attn_mfma_kernel(const float* __restr
       }
     }
   }
+}
+
+template <int MODE, int NW>
+int seq_attn_launch(const float* q, int ldq, const float* v, int ldv, float* out, int ldo, int B, int H, int W, hipStream_t st) {
+  static CdfoAttrOnce once;
+  constexpr int SUB = NW / 4, LDSB = 2 * (32 * SUB * 272 + SUB * 64 * 128);
+  const hipError_t e = cdfo_set_max_lds(once, reinterpret_cast<const void*>(&seq_attn_mfma_kernel<MODE, NW>), LDSB);
+  if (e != hipSuccess) return (int)e;
+  const int L = MODE == 0 ? W : (MODE == 1 ? H : 64);
+  const int ntq = cdiv(L, 32), nb = cdiv(ntq, NW), tpb = cdiv(ntq, nb);
+  const long long nseq = MODE == 0 ? (long long)B * H : (MODE == 1 ? (long long)B * W : (long long)B * (H / 8) * (W / 8));
+  if (nseq * nb >= (1ll << 31)) return CDFO_EINVAL;
+  hipLaunchKernelGGL((seq_attn_mfma_kernel<MODE, NW>), dim3((unsigned)(nseq * nb)), dim3(NW * 64), LDSB, st, q, ldq, v, ldv,
+                     out, ldo, B, H, W, nb, tpb);
+  return 0;
 }
 
 }  // namespace
@@ -487,12 +522,15 @@ extern "C" int cdfo_seq_attn(const float* q, int ldq, const float* v, int ldv, f
   if (!aligned16(q) || !aligned16(v) || !aligned16(out)) return CDFO_EALIGN;
   hipStream_t st = static_cast<hipStream_t>(stream);
   CdfoProfScope prof(static_cast<hipStream_t>(stream), (mode%10)==0?KID_ATTN_ROW:((mode%10)==1?KID_ATTN_COL:KID_ATTN_WIN), 4.0*64*(double)B*H*W*((mode%10)==0?W:((mode%10)==1?H:64)), 4.0*192*(double)B*H*W);
-  if (mode == 0) {
-    hipLaunchKernelGGL(seq_attn_mfma_kernel<0>, dim3((unsigned)((long long)B * H * cdiv(W, 128))), dim3(256), 0, st, q,
-                       ldq, v, ldv, out, ldo, B, H, W);
-  } else if (mode == 1) {
-    hipLaunchKernelGGL(seq_attn_mfma_kernel<1>, dim3((unsigned)((long long)B * W * cdiv(H, 128))), dim3(256), 0, st, q,
-                       ldq, v, ldv, out, ldo, B, H, W);
+  if (mode == 0 || mode == 1) {
+    // short sequences fit one 4-wave workgroup; long ones amortise the staging over 8 waves
+    const int L = mode == 0 ? W : H;
+    int rc;
+    if (mode == 0) rc = L <= 128 ? seq_attn_launch<0, 4>(q, ldq, v, ldv, out, ldo, B, H, W, st)
+                                 : seq_attn_launch<0, 8>(q, ldq, v, ldv, out, ldo, B, H, W, st);
+    else rc = L <= 128 ? seq_attn_launch<1, 4>(q, ldq, v, ldv, out, ldo, B, H, W, st)
+                       : seq_attn_launch<1, 8>(q, ldq, v, ldv, out, ldo, B, H, W, st);
+    if (rc) return rc;
   } else if (mode == 10) {   // VALU reference forms of modes 0 / 1 (kept for A/B tests)
     hipLaunchKernelGGL(seq_attn_kernel<0>, dim3((unsigned)((long long)B * H * cdiv(W, 64))), dim3(64), 0, st, q, ldq, v,
                        ldv, out, ldo, B, H, W);
@@ -501,8 +539,8 @@ extern "C" int cdfo_seq_attn(const float* q, int ldq, const float* v, int ldv, f
                        ldv, out, ldo, B, H, W);
   } else if (mode == 2) {
     if ((H & 7) || (W & 7)) return CDFO_EINVAL;
-    hipLaunchKernelGGL(seq_attn_mfma_kernel<2>, dim3((unsigned)((long long)B * (H / 8) * (W / 8))), dim3(256), 0, st, q,
-                       ldq, v, ldv, out, ldo, B, H, W);
+    const int rc = seq_attn_launch<2, 4>(q, ldq, v, ldv, out, ldo, B, H, W, st);
+    if (rc) return rc;
   } else if (mode == 12) {   // VALU reference form of mode 2
     if ((H & 7) || (W & 7)) return CDFO_EINVAL;
     hipLaunchKernelGGL(seq_attn_kernel<2>, dim3((unsigned)((long long)B * (H / 8) * (W / 8))), dim3(64), 0, st, q, ldq, v,

@@ -124,15 +124,20 @@ __global__ __launch_bounds__(256) void dcn_bwd_data_kernel(DcnBwdArgs a) {
 //     of its deformable group with wave-uniform (scalar-loaded) weights: Co * 4 * kh*kw FMAs per pixel, no re-reads;
 //   * with 4 channels per group the thread is the only contributor to grad_offset / grad_mask of (group, tap, pixel):
 //     plain coalesced stores, deterministic;
-//   * grad_input is scattered into an LDS window covering the tile's sampling footprint + a 5-pixel margin (LDS float
-//     atomics -- they are what bounds the kernel: 2.9 ms without the scatter, 13.5 ms with it at the alignment shape);
-//     only samples that leave the window go to global memory one by one.  The window is flushed once, skipping
-//     zeros: ~3.7 k global atomics per workgroup instead of 256 * kh*kw * 16 (a 16 x 32 tile was no faster).
+//   * grad_input is scattered into an LDS window covering the tile's sampling footprint + a 5-pixel margin, as 64-bit
+//     FIXED-POINT integer atomics: ds_add_f32 retires one wave-instruction per ~80 ns per CU on gfx950, ds_add_u64 one per
+//     3-5 ns (tools/probe/lds_atomic_probe.hip) -- the float form was 9.4 of the kernel's 12.3 ms.  The scale is a power
+//     of two chosen per workgroup from max |column gradient x mask| (every contribution is at most that; 2^12 of them
+//     per cell cannot overflow), values keep >= 38 significant bits, and integer sums do not depend on the order of the
+//     adds, so the window -- unlike a float-atomic one -- is bit-reproducible.  Only samples that leave the window go to
+//     global memory one by one.  The window is flushed once, skipping zeros: ~3.7 k global atomics per workgroup instead
+//     of 256 * kh*kw * 16 (a 16 x 32 tile was no faster).
 constexpr int DT_Y = 8, DT_X = 32, DT_MARGIN = 5, DT_MAXT = 9, DT_THREADS = DT_Y * DT_X;
 
 template <bool T9>
 __global__ __launch_bounds__(DT_THREADS) void dcn_bwd_data_tile_kernel(DcnBwdArgs a, int WH, int WW, int tiles_x) {
-  extern __shared__ __attribute__((aligned(16))) float win[];          // [4][WH][WW]
+  extern __shared__ __attribute__((aligned(16))) long long win[];      // [4][WH][WW], fixed point (see above)
+  __shared__ float s_amax[DT_THREADS / 64];
   const int tid = threadIdx.x;
   const int T = T9 ? 9 : a.kh * a.kw, P = a.Ho * a.Wo;
   const int d = blockIdx.y, b = blockIdx.z;
@@ -142,10 +147,8 @@ __global__ __launch_bounds__(DT_THREADS) void dcn_bwd_data_tile_kernel(DcnBwdArg
   const int p = pvalid ? ho * a.Wo + wo : 0;
   const int wy0 = ty0 * a.sh - a.ph - DT_MARGIN, wx0 = tx0 * a.sw - a.pw - DT_MARGIN;
   const int wsize = 4 * WH * WW;
-  if (a.gin) {
-    for (int i = tid; i < wsize; i += DT_THREADS) win[i] = 0.f;
-    __syncthreads();
-  }
+  if (a.gin)
+    for (int i = tid; i < wsize; i += DT_THREADS) win[i] = 0;
   float cg[4][DT_MAXT];
 #pragma unroll
   for (int e = 0; e < 4; ++e)
@@ -164,6 +167,37 @@ __global__ __launch_bounds__(DT_THREADS) void dcn_bwd_data_tile_kernel(DcnBwdArg
           if (T9 || t < T) cg[e][t] = fmaf(wo_[e * T + t], gv, cg[e][t]);
     }
   }
+  // masks of the nine taps (also needed for the fixed-point scale below)
+  float mk[DT_MAXT];
+#pragma unroll
+  for (int t = 0; t < DT_MAXT; ++t)
+    mk[t] = (pvalid && (T9 || t < T) && a.mask) ? a.mask[((long long)(b * a.dg + d) * T + t) * P + p] : 1.f;
+  float fx_scale = 1.f, fx_inv = 1.f;
+  bool fx_ok = true;
+  if (a.gin) {
+    // workgroup maximum of |column gradient x mask| -> power-of-two scale 2^(48 - e), 2^e >= max: a contribution is below
+    // 2^48 in magnitude, 2^12 of them (256 pixels x 9 taps, bilinear weights <= 1) stay inside 63 bits
+    float amax = 0.f;
+#pragma unroll
+    for (int t = 0; t < DT_MAXT; ++t)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float v = fabsf(cg[e][t] * mk[t]);
+        amax = v <= 3.0e38f ? fmaxf(amax, v) : INFINITY;               // NaN / infinity: no fixed point for this workgroup
+      }
+    amax = wave_max(amax);
+    if ((tid & 63) == 0) s_amax[tid >> 6] = amax;
+    __syncthreads();                                                   // (also: the zeroed window is visible)
+    amax = s_amax[0];
+#pragma unroll
+    for (int i = 1; i < DT_THREADS / 64; ++i) amax = fmaxf(amax, s_amax[i]);
+    int ex = 0;
+    if (amax > 0.f && amax < INFINITY) frexpf(amax, &ex);              // amax < 2^ex
+    ex = ex < -60 ? -60 : (ex > 120 ? 120 : ex);
+    fx_scale = ldexpf(1.f, 48 - ex);
+    fx_inv = ldexpf(1.f, ex - 48);
+    fx_ok = amax < INFINITY;       // else every sample takes the float path straight to global memory (NaN / inf propagate)
+  }
 #pragma unroll
   for (int t = 0; t < DT_MAXT; ++t) {
     if (!T9 && t >= T) break;
@@ -173,7 +207,7 @@ __global__ __launch_bounds__(DT_THREADS) void dcn_bwd_data_tile_kernel(DcnBwdArg
     const long long mb = ((long long)(b * a.dg + d) * T + t) * P + p;
     const float h_im = (float)(ho * a.sh - a.ph + ki * a.dh) + a.offset[ob];
     const float w_im = (float)(wo * a.sw - a.pw + kj * a.dw) + a.offset[ob + P];
-    const float m = a.mask ? a.mask[mb] : 1.f;
+    const float m = mk[t];
     float vh = 0.f, vw = 0.f, mv = 0.f;
     if (h_im > -1.f && w_im > -1.f && h_im < (float)a.H && w_im < (float)a.W) {
       const int hl = (int)floorf(h_im), wl = (int)floorf(w_im);
@@ -182,7 +216,7 @@ __global__ __launch_bounds__(DT_THREADS) void dcn_bwd_data_tile_kernel(DcnBwdArg
       const float w1 = hh * hw, w2 = hh * lw, w3 = lh * hw, w4 = lh * lw;
       const int o00 = hl * a.W + wl;
       const int ly = hl - wy0, lx = wl - wx0;                          // window coordinates of the top-left corner
-      const bool inwin = ly >= 0 && ly + 1 < WH && lx >= 0 && lx + 1 < WW;
+      const bool inwin = fx_ok && ly >= 0 && ly + 1 < WH && lx >= 0 && lx + 1 < WW;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const long long pl = ((long long)b * a.C + 4 * d + e) * a.H * a.W;
@@ -196,11 +230,12 @@ __global__ __launch_bounds__(DT_THREADS) void dcn_bwd_data_tile_kernel(DcnBwdArg
         vw = fmaf(hh * (v2 - v1) + lh * (v4 - v3), tg, vw);
         if (a.gin) {
           if (inwin) {
-            float* wp = win + (e * WH + ly) * WW + lx;
-            if (r0 && c0) atomicAdd(wp, w1 * tg);
-            if (r0 && c1) atomicAdd(wp + 1, w2 * tg);
-            if (r1 && c0) atomicAdd(wp + WW, w3 * tg);
-            if (r1 && c1) atomicAdd(wp + WW + 1, w4 * tg);
+            unsigned long long* wp = reinterpret_cast<unsigned long long*>(win) + (e * WH + ly) * WW + lx;
+            const float ts = tg * fx_scale;                            // |ts| < 2^48 (non-finite gradients: see below)
+            if (r0 && c0) atomicAdd(wp, (unsigned long long)(long long)(w1 * ts));
+            if (r0 && c1) atomicAdd(wp + 1, (unsigned long long)(long long)(w2 * ts));
+            if (r1 && c0) atomicAdd(wp + WW, (unsigned long long)(long long)(w3 * ts));
+            if (r1 && c1) atomicAdd(wp + WW + 1, (unsigned long long)(long long)(w4 * ts));
           } else {
             float* gi = a.gin + pl + o00;
             if (r0 && c0) unsafeAtomicAdd(gi, w1 * tg);
@@ -218,8 +253,9 @@ __global__ __launch_bounds__(DT_THREADS) void dcn_bwd_data_tile_kernel(DcnBwdArg
     __syncthreads();
     const int plane = WH * WW;
     for (int i = tid; i < wsize; i += DT_THREADS) {
-      const float v = win[i];
-      if (v == 0.f) continue;
+      const long long vi = win[i];
+      if (vi == 0) continue;
+      const float v = (float)vi * fx_inv;
       const int e = i / plane, r = i - e * plane, ly = r / WW, lx = r - ly * WW;
       const int yy = wy0 + ly, xx = wx0 + lx;
       if (yy >= 0 && yy < a.H && xx >= 0 && xx < a.W)
@@ -434,7 +470,7 @@ extern "C" int cdfo_dcn_backward(const float* in, const float* offset, const flo
     CdfoProfScope prof(st, KID_DCN_BWD, 2.0 * px * Co * (C / groups) * T,
                        4.0 * (px * (Co + 6.0 * deformable_groups * T) + 2.0 * B * C * H * W + (double)Co * (C / groups) * T));
     const int WH = (DT_Y - 1) * sh + (kh - 1) * dh + 2 + 2 * DT_MARGIN, WW = (DT_X - 1) * sw + (kw - 1) * dw + 2 + 2 * DT_MARGIN;
-    const size_t wlds = (size_t)4 * WH * WW * sizeof(float);
+    const size_t wlds = (size_t)4 * WH * WW * sizeof(long long);
     const int tiles_x = cdiv(Wo, DT_X), tiles_y = cdiv(Ho, DT_Y);
     if (groups == 1 && C / deformable_groups == 4 && T <= DT_MAXT && wlds <= 48 * 1024 &&
         (long long)tiles_x * tiles_y < (1ll << 31)) {

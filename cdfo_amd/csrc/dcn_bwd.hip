@@ -28,6 +28,9 @@ struct DcnBwdArgs {
   float* gin; float* goff; float* gmask; float* gw; float* gbias;
   int B, C, H, W, Co, Ho, Wo, kh, kw, sh, sw, ph, pw, dh, dw, groups, dg;
   float scale;
+  const _Float16* gt;       // GW form: grad_output per 8 x 32 tile as fp16 [B][tile][hi|lo][64 o][256 pixels] (dcn_bwd_gprep_kernel)
+  const float* gt_inv;      //          and the power of two that undoes each tile's scaling
+  float* col;               //          masked column values [B][dg][tile][4 * 9][256 pixels] written by the data kernel
 };
 
 struct Sample {             // bilinear footprint of one sample position (cu:466-496, 498-567)
@@ -132,21 +135,84 @@ __global__ __launch_bounds__(256) void dcn_bwd_data_kernel(DcnBwdArgs a) {
 //     adds, so the window -- unlike a float-atomic one -- is bit-reproducible.  Only samples that leave the window go to
 //     global memory one by one.  The window is flushed once, skipping zeros: ~3.7 k global atomics per workgroup instead
 //     of 256 * kh*kw * 16 (a 16 x 32 tile was no faster).
+//   * GW form (grad_weight requested, Co <= 64, workspace given): the sampled, masked column values the thread has in
+//     hand anyway are stored ([image][group][tile][4 * kh*kw][256 pixels] fp32, 256 contiguous bytes per wave-instruction),
+//     and dcn_bwd_gw_kernel contracts them with grad_output on the matrix cores -- the weight-gradient kernel's own
+//     sampling pass (5.9 ms at the alignment shape) disappears.  (Contracting inside this kernel -- column image in LDS,
+//     sums in registers over a run of tiles -- was tried: 213 VGPRs and 66 KB of LDS took this latency-bound kernel from
+//     12 to 8 waves per CU and it ran 3x slower than the two kernels do together.)
 constexpr int DT_Y = 8, DT_X = 32, DT_MARGIN = 5, DT_MAXT = 9, DT_THREADS = DT_Y * DT_X;
+constexpr int DT_COLROWS = 4 * DT_MAXT;                          // (e, t) rows of the column image
 
-template <bool T9>
-__global__ __launch_bounds__(DT_THREADS) void dcn_bwd_data_tile_kernel(DcnBwdArgs a, int WH, int WW, int tiles_x) {
+typedef _Float16 dcnb_f16x8 __attribute__((ext_vector_type(8)));
+
+// power of two s with amax * s in [2^13, 2^14): the scaled values sit well inside fp16's range, hi + lo keep 22 bits
+__device__ __forceinline__ float dcnb_pow2_scale(float amax, float& inv) {
+  int ex = 0;
+  if (amax > 0.f && amax < INFINITY) frexpf(amax, &ex);          // amax = m * 2^ex, m in [0.5, 1)
+  ex = ex < -100 ? -100 : (ex > 100 ? 100 : ex);
+  inv = ldexpf(1.f, ex - 14);
+  return ldexpf(1.f, 14 - ex);
+}
+
+__device__ __forceinline__ void dcnb_split8(const f32x4& v0, const f32x4& v1, float sc, dcnb_f16x8& hi, dcnb_f16x8& lo) {
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const float x0 = v0[j] * sc, x1 = v1[j] * sc;
+    hi[j] = (_Float16)x0;     lo[j] = (_Float16)(x0 - (float)hi[j]);
+    hi[4 + j] = (_Float16)x1; lo[4 + j] = (_Float16)(x1 - (float)hi[4 + j]);
+  }
+}
+
+// grad_output -> per-tile transposed, scaled, split copy for the GW form: grid (tiles, B), one thread per pixel of the
+// 8 x 32 tile (row-major index = the thread index = the pixel index the consumer uses), Co <= 64 (absent channels: zeros).
+__global__ __launch_bounds__(DT_THREADS) void dcn_bwd_gprep_kernel(const float* __restrict__ gout, _Float16* __restrict__ gt,
+                                                                  float* __restrict__ gt_inv, int Co, int Ho, int Wo,
+                                                                  int tiles_x, int ntiles) {
+  __shared__ float s_max[DT_THREADS / 64];
+  const int tid = threadIdx.x, tile = blockIdx.x, b = blockIdx.y, P = Ho * Wo;
+  const int ho = (tile / tiles_x) * DT_Y + (tid >> 5), wo = (tile % tiles_x) * DT_X + (tid & 31);
+  const bool pvalid = ho < Ho && wo < Wo;
+  const float* gp = gout + (long long)b * Co * P + (pvalid ? ho * Wo + wo : 0);
+  float g[64];
+  float amax = 0.f;
+#pragma unroll
+  for (int o = 0; o < 64; ++o) {
+    g[o] = (pvalid && o < Co) ? gp[(long long)o * P] : 0.f;
+    amax = fmaxf(amax, fabsf(g[o]));
+  }
+  amax = wave_max(amax);
+  if ((tid & 63) == 0) s_max[tid >> 6] = amax;
+  __syncthreads();
+  amax = fmaxf(fmaxf(s_max[0], s_max[1]), fmaxf(s_max[2], s_max[3]));
+  float inv;
+  const float sc = dcnb_pow2_scale(amax, inv);
+  if (tid == 0) gt_inv[(long long)b * ntiles + tile] = inv;
+  _Float16* base = gt + ((long long)b * ntiles + tile) * (2 * 64 * DT_THREADS) + tid;
+#pragma unroll
+  for (int o = 0; o < 64; ++o) {
+    const float x = g[o] * sc;
+    const _Float16 hi = (_Float16)x;
+    base[o * DT_THREADS] = hi;
+    base[(64 + o) * DT_THREADS] = (_Float16)(x - (float)hi);
+  }
+}
+
+template <bool T9, bool GW>
+__global__ __launch_bounds__(DT_THREADS) void dcn_bwd_data_tile_kernel(DcnBwdArgs a, int WH, int WW, int tiles_x, int ntiles) {
   extern __shared__ __attribute__((aligned(16))) long long win[];      // [4][WH][WW], fixed point (see above)
   __shared__ float s_amax[DT_THREADS / 64];
   const int tid = threadIdx.x;
   const int T = T9 ? 9 : a.kh * a.kw, P = a.Ho * a.Wo;
-  const int d = blockIdx.y, b = blockIdx.z;
-  const int ty0 = (blockIdx.x / tiles_x) * DT_Y, tx0 = (blockIdx.x % tiles_x) * DT_X;
+  const int d = blockIdx.y, b = blockIdx.z, tile = blockIdx.x;
+  const int ty0 = (tile / tiles_x) * DT_Y, tx0 = (tile % tiles_x) * DT_X;
   const int ho = ty0 + (tid >> 5), wo = tx0 + (tid & 31);
   const bool pvalid = ho < a.Ho && wo < a.Wo;
   const int p = pvalid ? ho * a.Wo + wo : 0;
   const int wy0 = ty0 * a.sh - a.ph - DT_MARGIN, wx0 = tx0 * a.sw - a.pw - DT_MARGIN;
   const int wsize = 4 * WH * WW;
+  // GW: this (image, group, tile)'s column image [4 * 9][256 pixels] in the workspace; thread = pixel = column index
+  float* const colp = GW ? a.col + (((long long)b * a.dg + d) * ntiles + tile) * (DT_COLROWS * DT_THREADS) + tid : nullptr;
   if (a.gin)
     for (int i = tid; i < wsize; i += DT_THREADS) win[i] = 0;
   float cg[4][DT_MAXT];
@@ -200,54 +266,66 @@ __global__ __launch_bounds__(DT_THREADS) void dcn_bwd_data_tile_kernel(DcnBwdArg
   }
 #pragma unroll
   for (int t = 0; t < DT_MAXT; ++t) {
-    if (!T9 && t >= T) break;
-    if (!pvalid) continue;
-    const int ki = t / a.kw, kj = t - ki * a.kw;
-    const long long ob = ((long long)(b * a.dg + d) * T + t) * 2 * P + p;
-    const long long mb = ((long long)(b * a.dg + d) * T + t) * P + p;
-    const float h_im = (float)(ho * a.sh - a.ph + ki * a.dh) + a.offset[ob];
-    const float w_im = (float)(wo * a.sw - a.pw + kj * a.dw) + a.offset[ob + P];
-    const float m = mk[t];
-    float vh = 0.f, vw = 0.f, mv = 0.f;
-    if (h_im > -1.f && w_im > -1.f && h_im < (float)a.H && w_im < (float)a.W) {
-      const int hl = (int)floorf(h_im), wl = (int)floorf(w_im);
-      const float lh = h_im - (float)hl, lw = w_im - (float)wl, hh = 1.f - lh, hw = 1.f - lw;
-      const bool r0 = hl >= 0, r1 = hl + 1 <= a.H - 1, c0 = wl >= 0, c1 = wl + 1 <= a.W - 1;
-      const float w1 = hh * hw, w2 = hh * lw, w3 = lh * hw, w4 = lh * lw;
-      const int o00 = hl * a.W + wl;
-      const int ly = hl - wy0, lx = wl - wx0;                          // window coordinates of the top-left corner
-      const bool inwin = fx_ok && ly >= 0 && ly + 1 < WH && lx >= 0 && lx + 1 < WW;
+    if (!T9 && t >= T) {                                               // (GW: absent taps are zero rows of the image)
+      if (GW)
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const long long pl = ((long long)b * a.C + 4 * d + e) * a.H * a.W;
-        const float* im = a.in + pl;
-        const float v1 = (r0 && c0) ? im[o00] : 0.f, v2 = (r0 && c1) ? im[o00 + 1] : 0.f;
-        const float v3 = (r1 && c0) ? im[o00 + a.W] : 0.f, v4 = (r1 && c1) ? im[o00 + a.W + 1] : 0.f;
-        const float cgv = cg[e][t];
-        mv = fmaf(cgv, w1 * v1 + w2 * v2 + w3 * v3 + w4 * v4, mv);
-        const float tg = cgv * m;
-        vh = fmaf(hw * (v3 - v1) + lw * (v4 - v2), tg, vh);
-        vw = fmaf(hh * (v2 - v1) + lh * (v4 - v3), tg, vw);
-        if (a.gin) {
-          if (inwin) {
-            unsigned long long* wp = reinterpret_cast<unsigned long long*>(win) + (e * WH + ly) * WW + lx;
-            const float ts = tg * fx_scale;                            // |ts| < 2^48 (non-finite gradients: see below)
-            if (r0 && c0) atomicAdd(wp, (unsigned long long)(long long)(w1 * ts));
-            if (r0 && c1) atomicAdd(wp + 1, (unsigned long long)(long long)(w2 * ts));
-            if (r1 && c0) atomicAdd(wp + WW, (unsigned long long)(long long)(w3 * ts));
-            if (r1 && c1) atomicAdd(wp + WW + 1, (unsigned long long)(long long)(w4 * ts));
-          } else {
-            float* gi = a.gin + pl + o00;
-            if (r0 && c0) unsafeAtomicAdd(gi, w1 * tg);
-            if (r0 && c1) unsafeAtomicAdd(gi + 1, w2 * tg);
-            if (r1 && c0) unsafeAtomicAdd(gi + a.W, w3 * tg);
-            if (r1 && c1) unsafeAtomicAdd(gi + a.W + 1, w4 * tg);
+        for (int e = 0; e < 4; ++e) colp[(e * DT_MAXT + t) * DT_THREADS] = 0.f;
+      continue;
+    }
+    float colv[4] = {0.f, 0.f, 0.f, 0.f};
+    if (pvalid) {
+      const int ki = t / a.kw, kj = t - ki * a.kw;
+      const long long ob = ((long long)(b * a.dg + d) * T + t) * 2 * P + p;
+      const long long mb = ((long long)(b * a.dg + d) * T + t) * P + p;
+      const float h_im = (float)(ho * a.sh - a.ph + ki * a.dh) + a.offset[ob];
+      const float w_im = (float)(wo * a.sw - a.pw + kj * a.dw) + a.offset[ob + P];
+      const float m = mk[t];
+      float vh = 0.f, vw = 0.f, mv = 0.f;
+      if (h_im > -1.f && w_im > -1.f && h_im < (float)a.H && w_im < (float)a.W) {
+        const int hl = (int)floorf(h_im), wl = (int)floorf(w_im);
+        const float lh = h_im - (float)hl, lw = w_im - (float)wl, hh = 1.f - lh, hw = 1.f - lw;
+        const bool r0 = hl >= 0, r1 = hl + 1 <= a.H - 1, c0 = wl >= 0, c1 = wl + 1 <= a.W - 1;
+        const float w1 = hh * hw, w2 = hh * lw, w3 = lh * hw, w4 = lh * lw;
+        const int o00 = hl * a.W + wl;
+        const int ly = hl - wy0, lx = wl - wx0;                        // window coordinates of the top-left corner
+        const bool inwin = fx_ok && ly >= 0 && ly + 1 < WH && lx >= 0 && lx + 1 < WW;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const long long pl = ((long long)b * a.C + 4 * d + e) * a.H * a.W;
+          const float* im = a.in + pl;
+          const float v1 = (r0 && c0) ? im[o00] : 0.f, v2 = (r0 && c1) ? im[o00 + 1] : 0.f;
+          const float v3 = (r1 && c0) ? im[o00 + a.W] : 0.f, v4 = (r1 && c1) ? im[o00 + a.W + 1] : 0.f;
+          const float cgv = cg[e][t];
+          const float sv = w1 * v1 + w2 * v2 + w3 * v3 + w4 * v4;
+          colv[e] = sv * m;
+          mv = fmaf(cgv, sv, mv);
+          const float tg = cgv * m;
+          vh = fmaf(hw * (v3 - v1) + lw * (v4 - v2), tg, vh);
+          vw = fmaf(hh * (v2 - v1) + lh * (v4 - v3), tg, vw);
+          if (a.gin) {
+            if (inwin) {
+              unsigned long long* wp = reinterpret_cast<unsigned long long*>(win) + (e * WH + ly) * WW + lx;
+              const float ts = tg * fx_scale;                          // |ts| < 2^48
+              if (r0 && c0) atomicAdd(wp, (unsigned long long)(long long)(w1 * ts));
+              if (r0 && c1) atomicAdd(wp + 1, (unsigned long long)(long long)(w2 * ts));
+              if (r1 && c0) atomicAdd(wp + WW, (unsigned long long)(long long)(w3 * ts));
+              if (r1 && c1) atomicAdd(wp + WW + 1, (unsigned long long)(long long)(w4 * ts));
+            } else {
+              float* gi = a.gin + pl + o00;
+              if (r0 && c0) unsafeAtomicAdd(gi, w1 * tg);
+              if (r0 && c1) unsafeAtomicAdd(gi + 1, w2 * tg);
+              if (r1 && c0) unsafeAtomicAdd(gi + a.W, w3 * tg);
+              if (r1 && c1) unsafeAtomicAdd(gi + a.W + 1, w4 * tg);
+            }
           }
         }
       }
+      if (a.goff) { a.goff[ob] = vh; a.goff[ob + P] = vw; }
+      if (a.gmask) a.gmask[mb] = mv;
     }
-    if (a.goff) { a.goff[ob] = vh; a.goff[ob + P] = vw; }
-    if (a.gmask) a.gmask[mb] = mv;
+    if (GW)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) colp[(e * DT_MAXT + t) * DT_THREADS] = colv[e];     // 256 contiguous bytes per wave
   }
   if (a.gin) {
     __syncthreads();
@@ -256,11 +334,103 @@ __global__ __launch_bounds__(DT_THREADS) void dcn_bwd_data_tile_kernel(DcnBwdArg
       const long long vi = win[i];
       if (vi == 0) continue;
       const float v = (float)vi * fx_inv;
-      const int e = i / plane, r = i - e * plane, ly = r / WW, lx = r - ly * WW;
+      const int e = i / plane, rr = i - e * plane, ly = rr / WW, lx = rr - ly * WW;
       const int yy = wy0 + ly, xx = wx0 + lx;
       if (yy >= 0 && yy < a.H && xx >= 0 && xx < a.W)
         unsafeAtomicAdd(a.gin + (((long long)b * a.C + 4 * d + e) * a.H + yy) * a.W + xx, v);
     }
+  }
+}
+
+// ---- GW form, second half: gw[o][4d + e][t] += scale * sum over pixels of gout[o][p] col[(e,t)][p] on the matrix cores.
+// Workgroup = one deformable group x a run of tiles of one image; wave w takes pixels 64w .. 64w+63 of every tile (K = 4 steps
+// of 16).  A fragment (lane = output channel, 8 consecutive pixels) = one 16-byte load per fp16 half from the transposed
+// copy; B fragment (lane = (e,t) row, the same 8 pixels) = two 16-byte loads of fp32 column values, scaled by the wave's
+// power of two for this tile (max over its 36 x 64 values) and split hi + lo.  The running sums stay in registers, in units
+// of the current tile's scales (a change multiplies them by a power of two: exact); at the end the four waves are added in
+// a fixed order through LDS and leave as Co * 4 * kh*kw global atomics per workgroup.
+__global__ __launch_bounds__(DT_THREADS) void dcn_bwd_gw_kernel(DcnBwdArgs a, int ntiles, int tpw) {
+  __shared__ float red[4 * 64 * DT_COLROWS];                           // [wave][o][(e,t)]: 36,864 bytes
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, r = lane & 31;
+  const int d = blockIdx.y, b = blockIdx.z, T = a.kh * a.kw;
+  f32x16 gacc[2][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int q = 0; q < 16; ++q) gacc[i >> 1][i & 1][q] = 0.f;
+  float unit = 1.f;
+  for (int ti = 0; ti < tpw; ++ti) {
+    const int tile = blockIdx.x * tpw + ti;
+    if (tile >= ntiles) break;
+    const _Float16* gtile = a.gt + ((long long)b * ntiles + tile) * (2 * 64 * DT_THREADS) + 64 * wave;
+    const float* ctile = a.col + (((long long)b * a.dg + d) * ntiles + tile) * (DT_COLROWS * DT_THREADS) + 64 * wave;
+    // this lane's column values of the tile: rows r and 32 + r (the latter only for r < 4), 4 k-steps x 8 pixels
+    f32x4 cv[2][4][2];
+    float cmax = 0.f;
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int et = 32 * nt + r;
+        f32x4 v0 = {0.f, 0.f, 0.f, 0.f}, v1 = {0.f, 0.f, 0.f, 0.f};
+        if (et < DT_COLROWS) {
+          v0 = *reinterpret_cast<const f32x4*>(ctile + et * DT_THREADS + 16 * k + 8 * h);
+          v1 = *reinterpret_cast<const f32x4*>(ctile + et * DT_THREADS + 16 * k + 8 * h + 4);
+        }
+        cv[nt][k][0] = v0; cv[nt][k][1] = v1;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) cmax = fmaxf(cmax, fmaxf(fabsf(v0[j]), fabsf(v1[j])));
+      }
+    float cinv;
+    const float csc = dcnb_pow2_scale(wave_max(cmax), cinv);
+    const float un = a.gt_inv[(long long)b * ntiles + tile] * cinv;
+    if (un != unit) {
+      const float f = unit / un;
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) gacc[i >> 1][i & 1][q] *= f;
+      unit = un;
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int l0 = 16 * k + 8 * h;
+      dcnb_f16x8 ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt) {
+        ah[mt] = *reinterpret_cast<const dcnb_f16x8*>(gtile + (32 * mt + r) * DT_THREADS + l0);
+        al[mt] = *reinterpret_cast<const dcnb_f16x8*>(gtile + (64 + 32 * mt + r) * DT_THREADS + l0);
+      }
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) dcnb_split8(cv[nt][k][0], cv[nt][k][1], csc, bh[nt], bl[nt]);
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+          gacc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[mt], bh[nt], gacc[mt][nt], 0, 0, 0);
+          gacc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mt], bl[nt], gacc[mt][nt], 0, 0, 0);
+          gacc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mt], bh[nt], gacc[mt][nt], 0, 0, 0);
+        }
+    }
+  }
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+      const int et = 32 * nt + r;
+      if (et < DT_COLROWS)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+          const int o = 32 * mt + (q & 3) + 8 * (q >> 2) + 4 * h;
+          red[(wave * 64 + o) * DT_COLROWS + et] = gacc[mt][nt][q] * unit;
+        }
+    }
+  __syncthreads();
+  for (int i = tid; i < 64 * DT_COLROWS; i += DT_THREADS) {
+    const int o = i / DT_COLROWS, et = i - o * DT_COLROWS, e = et / DT_MAXT, t = et - e * DT_MAXT;
+    if (o >= a.Co || t >= T) continue;
+    const float v = (red[i] + red[64 * DT_COLROWS + i]) + (red[2 * 64 * DT_COLROWS + i] + red[3 * 64 * DT_COLROWS + i]);
+    unsafeAtomicAdd(a.gw + ((long long)o * a.C + 4 * d + e) * T + t, a.scale * v);
   }
 }
 
@@ -445,11 +615,45 @@ __global__ __launch_bounds__(256) void dcn_bwd_bias_kernel(const float* __restri
 
 }  // namespace
 
+static long long dcnb_gt_bytes(long long nt) { return nt * (2 * 64 * DT_THREADS) * (long long)sizeof(_Float16); }
+static long long dcnb_inv_bytes(long long nt) { return ((nt * 4 + 255) / 256) * 256; }
+
+// Workspace of cdfo_dcn_backward_ws: room for the per-tile transposed fp16 copy of grad_output (+ one float per tile) and
+// the column values (4 * 9 floats per pixel and deformable group) when the fused weight-gradient form applies (groups == 1, C/dg == 4, kh*kw <= 9, Co <= 64), else 0.  -1 on bad shapes.
+extern "C" long long cdfo_dcn_backward_workspace_bytes(int B, int C, int H, int W, int Co, int kh, int kw, int sh, int sw,
+                                                       int ph, int pw, int dh, int dw, int groups, int deformable_groups) {
+  if (B <= 0 || C <= 0 || Co <= 0 || kh <= 0 || kw <= 0 || sh <= 0 || sw <= 0 || dh <= 0 || dw <= 0 || groups <= 0 ||
+      deformable_groups <= 0 || C % groups || Co % groups || C % deformable_groups)
+    return -1;
+  const int Ho = (H + 2 * ph - (dh * (kh - 1) + 1)) / sh + 1, Wo = (W + 2 * pw - (dw * (kw - 1) + 1)) / sw + 1;
+  if (Ho <= 0 || Wo <= 0) return -1;
+  if (groups != 1 || C / deformable_groups != 4 || kh * kw > DT_MAXT || Co > 64) return 0;
+  const long long nt = (long long)B * cdiv(Wo, DT_X) * cdiv(Ho, DT_Y);
+  return dcnb_gt_bytes(nt) + dcnb_inv_bytes(nt) + nt * deformable_groups * (DT_COLROWS * DT_THREADS) * (long long)sizeof(float);
+}
+
+extern "C" int cdfo_dcn_backward_ws(const float* in, const float* offset, const float* mask, const float* weight,
+                                    const float* grad_out, float* grad_in, float* grad_offset, float* grad_mask,
+                                    float* grad_weight, float* grad_bias, int B, int C, int H, int W, int Co, int kh, int kw,
+                                    int sh, int sw, int ph, int pw, int dh, int dw, int groups, int deformable_groups,
+                                    float scale, void* workspace, long long workspace_bytes, void* stream);
+
 extern "C" int cdfo_dcn_backward(const float* in, const float* offset, const float* mask, const float* weight,
                                  const float* grad_out, float* grad_in, float* grad_offset, float* grad_mask,
                                  float* grad_weight, float* grad_bias, int B, int C, int H, int W, int Co, int kh, int kw,
                                  int sh, int sw, int ph, int pw, int dh, int dw, int groups, int deformable_groups,
                                  float scale, void* stream) {
+  return cdfo_dcn_backward_ws(in, offset, mask, weight, grad_out, grad_in, grad_offset, grad_mask, grad_weight, grad_bias, B, C,
+                              H, W, Co, kh, kw, sh, sw, ph, pw, dh, dw, groups, deformable_groups, scale, nullptr, 0, stream);
+}
+
+// The same with a workspace (cdfo_dcn_backward_workspace_bytes, 16-byte aligned; NULL / too small: the weight gradient
+// runs as its own kernel with a second sampling pass -- same results up to summation order, slower).
+extern "C" int cdfo_dcn_backward_ws(const float* in, const float* offset, const float* mask, const float* weight,
+                                    const float* grad_out, float* grad_in, float* grad_offset, float* grad_mask,
+                                    float* grad_weight, float* grad_bias, int B, int C, int H, int W, int Co, int kh, int kw,
+                                    int sh, int sw, int ph, int pw, int dh, int dw, int groups, int deformable_groups,
+                                    float scale, void* workspace, long long workspace_bytes, void* stream) {
   if (B <= 0 || C <= 0 || Co <= 0 || kh <= 0 || kw <= 0 || sh <= 0 || sw <= 0 || dh <= 0 || dw <= 0 || groups <= 0 ||
       deformable_groups <= 0)
     return CDFO_EINVAL;
@@ -463,26 +667,56 @@ extern "C" int cdfo_dcn_backward(const float* in, const float* offset, const flo
   if (T > (WPAIRS * 256) / WOB) return CDFO_EINVAL;
   if ((long long)deformable_groups * T > 65535 || B > 65535 || C > 65535) return CDFO_EINVAL;
   DcnBwdArgs a{in, offset, mask, weight, grad_out, grad_in, grad_offset, grad_mask, grad_weight, grad_bias,
-               B, C, H, W, Co, Ho, Wo, kh, kw, sh, sw, ph, pw, dh, dw, groups, deformable_groups, scale};
+               B, C, H, W, Co, Ho, Wo, kh, kw, sh, sw, ph, pw, dh, dw, groups, deformable_groups, scale, nullptr, nullptr, nullptr};
   hipStream_t st = static_cast<hipStream_t>(stream);
   const double px = (double)B * P;
+  bool gw_done = false;
   if (grad_in || grad_offset || grad_mask) {
     CdfoProfScope prof(st, KID_DCN_BWD, 2.0 * px * Co * (C / groups) * T,
                        4.0 * (px * (Co + 6.0 * deformable_groups * T) + 2.0 * B * C * H * W + (double)Co * (C / groups) * T));
     const int WH = (DT_Y - 1) * sh + (kh - 1) * dh + 2 + 2 * DT_MARGIN, WW = (DT_X - 1) * sw + (kw - 1) * dw + 2 + 2 * DT_MARGIN;
     const size_t wlds = (size_t)4 * WH * WW * sizeof(long long);
     const int tiles_x = cdiv(Wo, DT_X), tiles_y = cdiv(Ho, DT_Y);
+    // GW form: the data kernel also stores its column values, dcn_bwd_gw_kernel contracts them with grad_output
+    const long long ws_need = cdfo_dcn_backward_workspace_bytes(B, C, H, W, Co, kh, kw, sh, sw, ph, pw, dh, dw, groups,
+                                                                deformable_groups);
+    const bool fuse_gw = grad_weight != nullptr && Co <= 64 && ws_need > 0 && workspace != nullptr &&
+                         workspace_bytes >= ws_need && aligned16(workspace);
     if (groups == 1 && C / deformable_groups == 4 && T <= DT_MAXT && wlds <= 48 * 1024 &&
         (long long)tiles_x * tiles_y < (1ll << 31)) {
-      dim3 grid(tiles_x * tiles_y, deformable_groups, B);
-      if (T == 9) hipLaunchKernelGGL(dcn_bwd_data_tile_kernel<true>, grid, dim3(DT_THREADS), wlds, st, a, WH, WW, tiles_x);
-      else hipLaunchKernelGGL(dcn_bwd_data_tile_kernel<false>, grid, dim3(DT_THREADS), wlds, st, a, WH, WW, tiles_x);
+      const int ntiles = tiles_x * tiles_y;
+      if (fuse_gw) {
+        const long long nt = (long long)B * ntiles;
+        char* wsp = static_cast<char*>(workspace);
+        _Float16* gt = reinterpret_cast<_Float16*>(wsp);
+        float* gt_inv = reinterpret_cast<float*>(wsp + dcnb_gt_bytes(nt));
+        a.col = reinterpret_cast<float*>(wsp + dcnb_gt_bytes(nt) + dcnb_inv_bytes(nt));
+        hipLaunchKernelGGL(dcn_bwd_gprep_kernel, dim3(ntiles, B), dim3(DT_THREADS), 0, st, grad_out, gt, gt_inv, Co, Ho, Wo,
+                           tiles_x, ntiles);
+        a.gt = gt; a.gt_inv = gt_inv;
+      }
+      dim3 grid(ntiles, deformable_groups, B);
+      if (T == 9) {
+        if (fuse_gw) hipLaunchKernelGGL((dcn_bwd_data_tile_kernel<true, true>), grid, dim3(DT_THREADS), wlds, st, a, WH, WW, tiles_x, ntiles);
+        else hipLaunchKernelGGL((dcn_bwd_data_tile_kernel<true, false>), grid, dim3(DT_THREADS), wlds, st, a, WH, WW, tiles_x, ntiles);
+      } else {
+        if (fuse_gw) hipLaunchKernelGGL((dcn_bwd_data_tile_kernel<false, true>), grid, dim3(DT_THREADS), wlds, st, a, WH, WW, tiles_x, ntiles);
+        else hipLaunchKernelGGL((dcn_bwd_data_tile_kernel<false, false>), grid, dim3(DT_THREADS), wlds, st, a, WH, WW, tiles_x, ntiles);
+      }
+      if (fuse_gw) {
+        CDFO_LAUNCH_CHECK();
+        // a workgroup walks a run of tiles and keeps the sums in registers (one set of atomics per run)
+        int tpw = 16;
+        while (tpw > 1 && (long long)cdiv(ntiles, tpw) * deformable_groups * B < 4096) tpw >>= 1;
+        hipLaunchKernelGGL(dcn_bwd_gw_kernel, dim3(cdiv(ntiles, tpw), deformable_groups, B), dim3(DT_THREADS), 0, st, a, ntiles, tpw);
+        gw_done = true;
+      }
     } else {
       hipLaunchKernelGGL(dcn_bwd_data_kernel, dim3(cdiv(P, 256), deformable_groups * T, B), dim3(256), 0, st, a);
     }
     CDFO_LAUNCH_CHECK();
   }
-  if (grad_weight) {
+  if (grad_weight && !gw_done) {
     const long long total = (long long)B * P;
     // enough workgroups to fill 256 CUs a few times over, each walking a whole number of 64-position chunks
     const int zb = cdiv(Co / groups, WOB);

@@ -229,7 +229,9 @@ extern "C" long long cdfo_dcn_workspace_bytes_dt(int dtype, int backward, int B,
   Dims d;
   if (!dims_of(B, C, H, W, Co, kh, kw, sh, sw, ph, pw, dh, dw, groups, deformable_groups, d)) return -1;
   if (dtype == CDFO_DTYPE_F64) return 0;
-  long long fast = backward ? 0 : cdfo_dcn_workspace_bytes(B, C, H, W, Co, kh, kw, groups, deformable_groups);
+  long long fast = backward ? cdfo_dcn_backward_workspace_bytes(B, C, H, W, Co, kh, kw, sh, sw, ph, pw, dh, dw, groups, deformable_groups)
+                            : cdfo_dcn_workspace_bytes(B, C, H, W, Co, kh, kw, groups, deformable_groups);
+  if (fast < 0) return -1;
   if (!backward && fast < d.n_in * 4) fast = d.n_in * 4;             // the general kernel's group-planar copy
   if (dtype == CDFO_DTYPE_F32) return fast;
   if (dtype != CDFO_DTYPE_F16) return -1;
@@ -302,11 +304,11 @@ extern "C" int cdfo_dcn_backward_dt(int dtype, const void* in, const void* offse
   if (!dims_of(B, C, H, W, Co, kh, kw, sh, sw, ph, pw, dh, dw, groups, deformable_groups, d)) return CDFO_EINVAL;
   if (!in || !offset || !weight || !grad_out || (grad_mask && !mask)) return CDFO_EINVAL;
   if (dtype == CDFO_DTYPE_F32)
-    return cdfo_dcn_backward(static_cast<const float*>(in), static_cast<const float*>(offset), static_cast<const float*>(mask),
-                             static_cast<const float*>(weight), static_cast<const float*>(grad_out), static_cast<float*>(grad_in),
-                             static_cast<float*>(grad_offset), static_cast<float*>(grad_mask), static_cast<float*>(grad_weight),
-                             static_cast<float*>(grad_bias), B, C, H, W, Co, kh, kw, sh, sw, ph, pw, dh, dw, groups,
-                             deformable_groups, scale, stream);
+    return cdfo_dcn_backward_ws(static_cast<const float*>(in), static_cast<const float*>(offset), static_cast<const float*>(mask),
+                                static_cast<const float*>(weight), static_cast<const float*>(grad_out), static_cast<float*>(grad_in),
+                                static_cast<float*>(grad_offset), static_cast<float*>(grad_mask), static_cast<float*>(grad_weight),
+                                static_cast<float*>(grad_bias), B, C, H, W, Co, kh, kw, sh, sw, ph, pw, dh, dw, groups,
+                                deformable_groups, scale, workspace, workspace_bytes, stream);
   if (dtype == CDFO_DTYPE_F64) {
     TArgs a{};
     a.in = static_cast<const double*>(in); a.offset = static_cast<const double*>(offset);
@@ -348,10 +350,10 @@ extern "C" int cdfo_dcn_backward_dt(int dtype, const void* in, const void* offse
   if (grad_weight && hipMemsetAsync(g_w, 0, d.n_w * 4, st) != hipSuccess) return CDFO_EINVAL;
   if (grad_bias && hipMemsetAsync(g_b, 0, (size_t)Co * 4, st) != hipSuccess) return CDFO_EINVAL;
   CDFO_LAUNCH_CHECK();
-  const int rc = cdfo_dcn_backward(f_in, f_off, mask ? f_mask : nullptr, f_w, f_go, grad_in ? g_in : nullptr,
-                                   grad_offset ? g_off : nullptr, grad_mask ? g_mask : nullptr, grad_weight ? g_w : nullptr,
-                                   grad_bias ? g_b : nullptr, B, C, H, W, Co, kh, kw, sh, sw, ph, pw, dh, dw, groups,
-                                   deformable_groups, scale, stream);
+  const int rc = cdfo_dcn_backward_ws(f_in, f_off, mask ? f_mask : nullptr, f_w, f_go, grad_in ? g_in : nullptr,
+                                      grad_offset ? g_off : nullptr, grad_mask ? g_mask : nullptr, grad_weight ? g_w : nullptr,
+                                      grad_bias ? g_b : nullptr, B, C, H, W, Co, kh, kw, sh, sw, ph, pw, dh, dw, groups,
+                                      deformable_groups, scale, ws, workspace_bytes - (ws - static_cast<char*>(workspace)), stream);
   if (rc) return rc;
   if (grad_in) cast_launch<float, h, true>(g_in, static_cast<h*>(grad_in), d.n_in, st);
   if (grad_offset) cast_launch<float, h, false>(g_off, static_cast<h*>(grad_offset), d.n_off, st);

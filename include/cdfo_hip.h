@@ -256,13 +256,25 @@ int cdfo_dcn_backward(const float* in, const float* offset, const float* mask, c
                       const float* grad_out, float* grad_in, float* grad_offset, float* grad_mask, float* grad_weight,
                       float* grad_bias, int B, int C, int H, int W, int Co, int kh, int kw, int sh, int sw, int ph,
                       int pw, int dh, int dw, int groups, int deformable_groups, float scale, void* stream);
+/* The same with a workspace of cdfo_dcn_backward_workspace_bytes(...) bytes (16-byte aligned; non-zero for groups == 1,
+ * C/dg == 4, kh*kw <= 9, Co <= 64 -- the alignment module's shape; -1 on bad shapes): the weight gradient is then
+ * contracted on the matrix cores inside the data-gradient kernel (grad_output x the column values it samples anyway)
+ * instead of by a second sampling pass.  NULL / too small a workspace = cdfo_dcn_backward.  */
+long long cdfo_dcn_backward_workspace_bytes(int B, int C, int H, int W, int Co, int kh, int kw, int sh, int sw, int ph,
+                                            int pw, int dh, int dw, int groups, int deformable_groups);
+int cdfo_dcn_backward_ws(const float* in, const float* offset, const float* mask, const float* weight,
+                         const float* grad_out, float* grad_in, float* grad_offset, float* grad_mask, float* grad_weight,
+                         float* grad_bias, int B, int C, int H, int W, int Co, int kh, int kw, int sh, int sw, int ph,
+                         int pw, int dh, int dw, int groups, int deformable_groups, float scale, void* workspace,
+                         long long workspace_bytes, void* stream);
 
 /* ---- the operator's other dtypes (dcn_typed.hip) --------------------------------------------------------------
  * The reference instantiates its kernels for float, double and half (AT_DISPATCH_FLOATING_TYPES_AND_HALF,
  * ops/dcn/src/deform_conv_cuda_kernel.cu:258,352,450,780,812,845).  Same tensors and conventions as cdfo_dcn_forward /
  * cdfo_dcn_backward with elements of `dtype` (CDFO_DTYPE_*): F32 forwards to those; F16 = fp16 tensors, fp32 arithmetic
  * (operands widened into `workspace`, the fp32 kernels run, results narrowed once; accumulating gradients are added to the
- * fp16 tensors); F64 = fp64 VALU kernels, fp64 atomics (correctness-first).  `workspace` must hold
+ * fp16 tensors); F64 = fp64 VALU kernels, fp64 atomics (correctness-first).  F32 / F16 backward: the workspace also carries
+ * what cdfo_dcn_backward_ws wants.  `workspace` must hold
  * cdfo_dcn_workspace_bytes_dt(...) bytes, 16-byte aligned (`backward` = 0 / 1; F64 needs none; returns -1 on bad shapes). */
 long long cdfo_dcn_workspace_bytes_dt(int dtype, int backward, int B, int C, int H, int W, int Co, int kh, int kw, int sh,
                                       int sw, int ph, int pw, int dh, int dw, int groups, int deformable_groups);

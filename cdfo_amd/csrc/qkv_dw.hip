@@ -134,21 +134,28 @@ __global__ __launch_bounds__(QD_THREADS) void qkv_dw_kernel(qd_args a) {
         f32x16 acc;
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[e] = 0.f;
-        const int n = nb < 2 ? nt * 64 + nb * 32 + r : 128 + nt * 32 + r;   // blocks 0, 1: [32 q | 32 k] of the same heads
+        // transposed product (rows = output channels, columns = pixels): a lane's accumulator registers are 4 x 4
+        // consecutive channels of ITS pixel (halo column r), so the y tile is written with four 16-byte stores per lane
+        // and the inside-the-image test is one per lane
+        const int n0 = nb < 2 ? nt * 64 + nb * 32 : 128 + nt * 32;            // blocks 0, 1: [32 q | 32 k] of the same heads
+        const int n = n0 + r;
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
           const qd_bf16x8 wh = *reinterpret_cast<const qd_bf16x8*>(smem + ((s * 2 + h) * 192 + n) * 16);
           const qd_bf16x8 wl = *reinterpret_cast<const qd_bf16x8*>(smem + QD_W_BYTES / 2 + ((s * 2 + h) * 192 + n) * 16);
-          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[s], wh, acc, 0, 0, 0);
-          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[s], wl, acc, 0, 0, 0);
-          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[s], wh, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, al[s], acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl, ah[s], acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, ah[s], acc, 0, 0, 0);
         }
-        const float bn = sBias[n];
+        const int gxr = ox0 - 1 + r;
+        const bool in = row_in && gxr >= 0 && gxr < W;
+        float* yrow = sY + (wave * 32 + r) * QD_YP + nt * 32 + 4 * h;
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-          const int hx = (e & 3) + 8 * (e >> 2) + 4 * h, gx = ox0 - 1 + hx;
-          const bool in = row_in && gx >= 0 && gx < W;
-          sY[(wave * 32 + hx) * QD_YP + nt * 32 + r] = in ? acc[e] + bn : 0.f;
+        for (int j = 0; j < 4; ++j) {                                      // channels n0 + 8j + 4h .. + 3
+          const f32x4 bv = *reinterpret_cast<const f32x4*>(sBias + n0 + 8 * j + 4 * h);
+          f32x4 v = {acc[4 * j] + bv[0], acc[4 * j + 1] + bv[1], acc[4 * j + 2] + bv[2], acc[4 * j + 3] + bv[3]};
+          if (!in) v = f32x4{0.f, 0.f, 0.f, 0.f};
+          *reinterpret_cast<f32x4*>(yrow + 8 * j) = v;
         }
       }
       __syncthreads();

@@ -24,6 +24,7 @@ constexpr int BP_LDS = BP_BIAS_OFF + 128 * 4;             // 102,912 bytes
 
 typedef __bf16 bp_bf16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 bp_f16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 bp_f16x8 __attribute__((ext_vector_type(8)));
 
 struct bp_args {
   const float* x; int ldx;
@@ -32,6 +33,7 @@ struct bp_args {
   const float* bias;            // [128]
   _Float16* u16;                // [B][4][2H][2W][16]
   _Float16* d16;                // [B][4][H/2][W/2][16]
+  _Float16* x16;                // optional [B][4][H][W][16]: fp16 chunk-planar copy of x itself (the 1x branch's source)
 };
 
 __global__ __launch_bounds__(BP_THREADS) void block_pro_kernel(bp_args a) {
@@ -80,6 +82,20 @@ __global__ __launch_bounds__(BP_THREADS) void block_pro_kernel(bp_args a) {
         ah[s][j] = (__bf16)v;
         al[s][j] = (__bf16)(v - (float)ah[s][j]);
       }
+    if (a.x16) {
+      // the tile's own pixels (halo rows 1-6, columns 1-30) also leave as the fp16 chunk-planar copy of x: this lane holds
+      // channels 8h .. 8h+7 of each 16-channel chunk s = one 16-byte store per chunk
+      const int gy = oy0 - 1 + wave, gx = ox0 - 1 + r;
+      if (wave >= 1 && wave <= BP_TR && r >= 1 && r <= BP_TC && gy < H && gx < W) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          bp_f16x8 hv;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) hv[j] = (_Float16)xr[2 * s + (j >> 2)][j & 3];
+          *reinterpret_cast<bp_f16x8*>(a.x16 + ((((long long)b * 4 + s) * H + gy) * W + gx) * 16 + 8 * h) = hv;
+        }
+      }
+    }
     const int tn = t + gridDim.x;
     if (tn < ntiles) load_x(tn);
 
@@ -160,10 +176,10 @@ __global__ __launch_bounds__(BP_THREADS) void block_pro_kernel(bp_args a) {
 }  // namespace
 
 extern "C" int cdfo_block_prologue(const float* x, int ldx, int B, int H, int W, const void* w_bf16, const float* bias128,
-                                   void* u16, void* d16, void* stream) {
+                                   void* u16, void* d16, void* x16, void* stream) {
   if (B <= 0 || H <= 0 || W <= 0 || (H & 1) || (W & 1) || ldx % 4 || ldx < 64) return CDFO_EINVAL;
   if ((long long)B * H * W * 4 >= (1ll << 31)) return CDFO_EINVAL;
-  if (!aligned16(x) || !aligned16(w_bf16) || !aligned16(u16) || !aligned16(d16) || !bias128) return CDFO_EALIGN;
+  if (!aligned16(x) || !aligned16(w_bf16) || !aligned16(u16) || !aligned16(d16) || !aligned16(x16) || !bias128) return CDFO_EALIGN;
   hipStream_t st = static_cast<hipStream_t>(stream);
   static CdfoAttrOnce once;
   const hipError_t e = cdfo_set_max_lds(once, reinterpret_cast<const void*>(block_pro_kernel), BP_LDS);
@@ -175,7 +191,7 @@ extern "C" int cdfo_block_prologue(const float* x, int ldx, int B, int H, int W,
   bp_args a;
   a.x = x; a.ldx = ldx; a.B = B; a.H = H; a.W = W;
   a.w = static_cast<const unsigned short*>(w_bf16); a.bias = bias128;
-  a.u16 = static_cast<_Float16*>(u16); a.d16 = static_cast<_Float16*>(d16);
+  a.u16 = static_cast<_Float16*>(u16); a.d16 = static_cast<_Float16*>(d16); a.x16 = static_cast<_Float16*>(x16);
   const double px = (double)B * H * W;
   CdfoProfScope prof(st, KID_RESAMPLE, 2.0 * px * 128 * 64, px * (4.0 * 64 + 2.0 * 64 * 4 + 2.0 * 16));
   hipLaunchKernelGGL(block_pro_kernel, dim3(grid), dim3(BP_THREADS), BP_LDS, st, a);

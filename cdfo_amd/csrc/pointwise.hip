@@ -319,7 +319,9 @@ __global__ __launch_bounds__(256) void up2_cp16_kernel(const float* __restrict__
 // out = x * gate[b][c]   (CALayer, arch.py:2041-2043)
 __global__ __launch_bounds__(256) void scale_channels_kernel(const float* __restrict__ in, int ldi,
                                                              const float* __restrict__ gate, int B, long long P, int C,
-                                                             float* __restrict__ out, int ldo) {
+                                                             float* __restrict__ out, int ldo,
+                                                             _Float16* __restrict__ out16) {
+  typedef _Float16 sc_f16x4 __attribute__((ext_vector_type(4)));
   const int cgs = C >> 2;
   const long long total = (long long)B * P * cgs;
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
@@ -328,7 +330,14 @@ __global__ __launch_bounds__(256) void scale_channels_kernel(const float* __rest
     const long long p = i / cgs;
     const long long b = p / P;
     const f32x4 g = *reinterpret_cast<const f32x4*>(gate + b * C + cg * 4);
-    *reinterpret_cast<f32x4*>(out + p * ldo + cg * 4) = *reinterpret_cast<const f32x4*>(in + p * ldi + cg * 4) * g;
+    const f32x4 v = *reinterpret_cast<const f32x4*>(in + p * ldi + cg * 4) * g;
+    *reinterpret_cast<f32x4*>(out + p * ldo + cg * 4) = v;
+    if (out16) {          // fp16 chunk-planar copy [B][C/16][P][16] (the source layout of cdfo_conv3x3_c64_ws)
+      sc_f16x4 hv;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) hv[k] = (_Float16)v[k];
+      *reinterpret_cast<sc_f16x4*>(out16 + ((b * (C >> 4) + (cg >> 2)) * P + (p - b * P)) * 16 + (cg & 3) * 4) = hv;
+    }
   }
 }
 
@@ -533,12 +542,12 @@ extern "C" int cdfo_resample2(const float* in, int ldi, int B, int H, int W, int
 }
 
 extern "C" int cdfo_scale_channels(const float* in, int ldi, const float* gate, int B, long long P, int C, float* out,
-                                   int ldo, void* stream) {
-  if (B <= 0 || C % 4 || ldi % 4 || ldo % 4) return CDFO_EINVAL;
-  if (!aligned16(in) || !aligned16(out) || !aligned16(gate)) return CDFO_EALIGN;
+                                   int ldo, void* out_cp16, void* stream) {
+  if (B <= 0 || C % 4 || ldi % 4 || ldo % 4 || (out_cp16 && C % 16)) return CDFO_EINVAL;
+  if (!aligned16(in) || !aligned16(out) || !aligned16(gate) || !aligned16(out_cp16)) return CDFO_EALIGN;
   CdfoProfScope prof(static_cast<hipStream_t>(stream), KID_SCALE, 0, 8.0*C*(double)B*P);
   hipLaunchKernelGGL(scale_channels_kernel, dim3(grid_for((long long)B * P * (C / 4))), dim3(256), 0,
-                     static_cast<hipStream_t>(stream), in, ldi, gate, B, P, C, out, ldo);
+                     static_cast<hipStream_t>(stream), in, ldi, gate, B, P, C, out, ldo, static_cast<_Float16*>(out_cp16));
   CDFO_LAUNCH_CHECK();
   return 0;
 }

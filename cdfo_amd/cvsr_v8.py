@@ -369,13 +369,16 @@ class CVSR_V8(nn.Module):
         gate = K.vec_mlp(part, n, H * W, raw[a + "CALayer.conv_du.0.weight"], raw[a + "CALayer.conv_du.0.bias"], 64,
                          K.ACT_RELU, raw[a + "CALayer.conv_du.2.weight"], raw[a + "CALayer.conv_du.2.bias"], 64,
                          K.ACT_SIGMOID)
-        o = K.scale_channels(o, gate)
         rb = [w[a + n] for n in ("ResidualBlock.conv1", "ResidualBlock.conv2", "ResidualBlock1.conv1", "ResidualBlock1.conv2")]
-        if self.precision == "fp16x2" and H % 2 == 0 and all(c.wh is not None for c in rb):
+        fast16 = self.precision == "fp16x2" and H % 2 == 0 and all(c.wh is not None for c in rb)
+        if fast16:
+            o, o16 = K.scale_channels(o, gate, want_cp16=True)
+        else:
+            o = K.scale_channels(o, gate)
+        if fast16:
             # the two ResidualBlock_noBN (arch.py:261-262) on the Block_ kernels: conv1 + ReLU weights-stationary (fp16
             # chunk-planar in and out), conv2 + residual on its residual form (fp32 pixel-major out); single-pass fp16 MFMA like the
             # convolutions inside Block_ (no measurable change of the forward's error: 2.80e-4 with and without)
-            o16 = K.to_cp16(o)
             n16 = torch.empty_like(o16)
             o = K.conv3x3_ws_res(K.conv3x3_ws(o16, rb[0], act=K.ACT_RELU), rb[1], res1=o, out2_cp16=n16)
             return K.conv3x3_ws_res(K.conv3x3_ws(n16, rb[2], act=K.ACT_RELU), rb[3], res1=o, res2=xc, out=out)
@@ -398,9 +401,11 @@ class CVSR_V8(nn.Module):
             # kernel; the 64- and 256-channel tensors between them are fp16 chunk-planar [B,C/16,H,W,16].  Same
             # arithmetic as the single-pass fp16 mode of the tiled kernel: fp16 operands, fp32 accumulation
             c1 = lambda src, **kw: K.conv3x3_ws(src, b0, act=K.ACT_LRELU, **kw)
+            # sources of the x2 and x1/2 branches (and, for a group's first block, of the 1x branch), one read of x
             if x16 is None:
-                x16 = K.to_cp16(x)
-            u16, d16 = K.block_prologue(x, w[p + "pro"])      # sources of the x2 and x1/2 branches, one read of x
+                u16, d16, x16 = K.block_prologue(x, w[p + "pro"], want_x16=True)
+            else:
+                u16, d16 = K.block_prologue(x, w[p + "pro"])
             out = K.conv_ring(c1(x16), b2, res1=x)
             d = K.conv_ring(c1(d16), b2)
             t = c1(u16, s2d=True)

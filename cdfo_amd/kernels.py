@@ -425,15 +425,17 @@ def pack_block_prologue(w_up: torch.Tensor, b_up: torch.Tensor, w_dn: torch.Tens
     return torch.cat([pack(hi), pack(lo)]).contiguous(), torch.cat([b_up.detach().float(), b_dn.detach().float()]).contiguous()
 
 
-def block_prologue(x: torch.Tensor, packed):
-    """(u16, d16): fp16 chunk-planar bilinear_x2(up.0(x)) [B,4,2H,2W,16] and down.0(mean2x2(x)) [B,4,H/2,W/2,16]."""
+def block_prologue(x: torch.Tensor, packed, want_x16: bool = False):
+    """(u16, d16): fp16 chunk-planar bilinear_x2(up.0(x)) [B,4,2H,2W,16] and down.0(mean2x2(x)) [B,4,H/2,W/2,16];
+    want_x16: also (third) the fp16 chunk-planar copy [B,4,H,W,16] of x itself, from the same read of x."""
     B, H, W, Cc, ld = _chk_act(x)
     assert Cc == 64 and H % 2 == 0 and W % 2 == 0
     u16 = torch.empty((B, 4, 2 * H, 2 * W, 16), dtype=torch.float16, device=x.device)
     d16 = torch.empty((B, 4, H // 2, W // 2, 16), dtype=torch.float16, device=x.device)
+    x16 = torch.empty((B, 4, H, W, 16), dtype=torch.float16, device=x.device) if want_x16 else None
     check(_lib.lib().cdfo_block_prologue(_vp(x), ld, B, H, W, _vp(packed[0]), _vp(packed[1]), _vp(u16), _vp(d16),
-                                         _stream()), "cdfo_block_prologue")
-    return u16, d16
+                                         _vp(x16), _stream()), "cdfo_block_prologue")
+    return (u16, d16, x16) if want_x16 else (u16, d16)
 
 
 def pack_qkv_dw(w_qkv: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor):
@@ -526,12 +528,14 @@ def resample2(x: torch.Tensor, up: bool, out: Optional[torch.Tensor] = None, acc
     return out
 
 
-def scale_channels(x: torch.Tensor, gate: torch.Tensor) -> torch.Tensor:
+def scale_channels(x: torch.Tensor, gate: torch.Tensor, want_cp16: bool = False):
+    """x * gate[b][c]; want_cp16: also the fp16 chunk-planar copy [B,C/16,H,W,16] of the result (returns a pair)."""
     B, H, W, Cc, ld = _chk_act(x)
     out = empty_act(B, H, W, Cc, x.device)
-    check(_lib.lib().cdfo_scale_channels(_vp(x), ld, _vp(gate), B, C.c_longlong(H * W), Cc, _vp(out), Cc, _stream()),
-          "cdfo_scale_channels")
-    return out
+    o16 = torch.empty((B, Cc // 16, H, W, 16), dtype=torch.float16, device=x.device) if want_cp16 else None
+    check(_lib.lib().cdfo_scale_channels(_vp(x), ld, _vp(gate), B, C.c_longlong(H * W), Cc, _vp(out), Cc, _vp(o16),
+                                         _stream()), "cdfo_scale_channels")
+    return (out, o16) if want_cp16 else out
 
 
 def upconv_last(x: torch.Tensor, pc: PackedConv, w_last: torch.Tensor, b_last: torch.Tensor, xc: torch.Tensor,

@@ -151,9 +151,10 @@ int cdfo_flow_warp(const float* in, int ldi, const float* mv, long long mv_bstri
  * 2 = `out` is an fp16 chunk-planar tensor [B][C/16][2H][2W][16] (ldo ignored), the source of cdfo_conv3x3_c64_ws. */
 int cdfo_resample2(const float* in, int ldi, int B, int H, int W, int C, float* out, int ldo, int up, int accumulate,
                    int out_f16, void* stream);
-/* out = in * gate[b][c] (CALayer, arch.py:2041-2043). */
+/* out = in * gate[b][c] (CALayer, arch.py:2041-2043); out_cp16 (optional, C % 16 == 0): the same values as the fp16
+ * chunk-planar tensor [B][C/16][P][16] that cdfo_conv3x3_c64_ws reads. */
 int cdfo_scale_channels(const float* in, int ldi, const float* gate, int B, long long P, int C, float* out, int ldo,
-                        void* stream);
+                        void* out_cp16, void* stream);
 /* conv_last 3x3 64->1 (+bias) + bilinear x4 of the centre LR frame (arch.py:4476-4480); out = [B][Hh][Wh]. */
 int cdfo_conv_last(const float* in, int ldi, const float* w, const float* bias, const float* xc, long long xc_bstride,
                    int B, int Hh, int Wh, float* out, void* stream);
@@ -204,9 +205,10 @@ int cdfo_metric_partials(const float* a, const float* b, int N, int H, int W, in
 /* Block_ prologue (arch.py:378-406): from one read of the block input x [B][H][W][64] (H, W even) the fp16 chunk-planar
  * sources of its two resampled branches: u16 [B][4][2H][2W][16] = bilinear_x2(up.0(x)) and d16 [B][4][H/2][W/2][16] =
  * down.0(mean2x2(x)).  w_bf16: split-bf16 1x1 weights [hi|lo][4][2][128][8], rows 0-63 = up.0, 64-127 = down.0,
- * element (s,h,n,j) = W[n][16s+8h+j]; bias128 = [up.0 bias | down.0 bias].  */
+ * element (s,h,n,j) = W[n][16s+8h+j]; bias128 = [up.0 bias | down.0 bias].  x16 (optional): also the fp16 chunk-planar
+ * copy [B][4][H][W][16] of x itself, the source of the block's own-resolution branch.  */
 int cdfo_block_prologue(const float* x, int ldx, int B, int H, int W, const void* w_bf16, const float* bias128, void* u16,
-                        void* d16, void* stream);
+                        void* d16, void* x16, void* stream);
 /* MDTA front end in one pass (arch.py:1169-1198 LayerNorm, :1551-1552 qkv + qkv_dwconv): out[B][H][W][192] =
  * depthwise3x3(conv1x1(LayerNorm64(x))).  w_bf16: split-bf16 weights [hi|lo][4][2][192][8], element (s,h,n,j) =
  * W[n][16s+8h+j] * gamma[16s+8h+j]; bias[192] = W @ beta (may be NULL); dw_w: raw [192][1][3][3] taps.

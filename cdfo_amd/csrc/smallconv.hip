@@ -125,6 +125,62 @@ inline int grid_for(long long threads) {
   return (int)(blocks < 1 ? 1 : (blocks > 8192 ? 8192 : blocks));
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// First layer of the prior U-net in the feature extractor's first round, straight from the one-channel prior image:
+//     t = lrelu( body.0( conv_second(pms) ) )      (arch.py:4420 conv_second -- no activation -- then 1819-1820 body.0)
+// Both are 3x3 zero-padded convolutions with nothing but their biases in between, and conv_second's 64-channel result
+// feeds only this layer in round 0 (arch.py:1463-1468), so it never needs to exist: for every tap t of body.0 whose
+// position p + t lies inside the image (outside it body.0 sees its zero padding, not conv_second's bias),
+//     out[o](p) = b0[o] + sum_t [p + t inside] * ( bt[t][o] + sum_u wc[t][u][o] * pms(p + t + u) ),
+//     wc[t][u][o] = sum_c W0[o][c][t] W2[c][u],   bt[t][o] = sum_c W0[o][c][t] b2[c]     (composed on the host in fp64)
+// -- exact at the borders, 81 x 16 multiply-adds per pixel instead of a 64-channel tensor written and read back.
+// thread = (pixel, 4 output channels).
+__global__ __launch_bounds__(256) void udsa_head_kernel(const float* __restrict__ img, long long bstride,
+                                                        const float* __restrict__ wc, const float* __restrict__ bt,
+                                                        const float* __restrict__ b0, int B, int H, int W,
+                                                        float* __restrict__ out, int ldo) {
+  __shared__ __attribute__((aligned(16))) float sw[81 * 16 + 9 * 16 + 16];
+  for (int i = threadIdx.x; i < 81 * 16; i += blockDim.x) sw[i] = wc[i];
+  for (int i = threadIdx.x; i < 9 * 16; i += blockDim.x) sw[81 * 16 + i] = bt[i];
+  for (int i = threadIdx.x; i < 16; i += blockDim.x) sw[81 * 16 + 9 * 16 + i] = b0[i];
+  __syncthreads();
+  const long long total = (long long)B * H * W * 4;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int cg = (int)(i & 3);
+    const long long p = i >> 2;
+    const int x = (int)(p % W), y = (int)((p / W) % H);
+    const long long b = p / ((long long)W * H);
+    const float* im = img + b * bstride;
+    float win[5][5];
+#pragma unroll
+    for (int dy = 0; dy < 5; ++dy)
+#pragma unroll
+      for (int dx = 0; dx < 5; ++dx) {
+        const int yy = y + dy - 2, xx = x + dx - 2;
+        win[dy][dx] = (yy >= 0 && yy < H && xx >= 0 && xx < W) ? im[(long long)yy * W + xx] : 0.f;
+      }
+    f32x4 acc = *reinterpret_cast<const f32x4*>(sw + 81 * 16 + 9 * 16 + cg * 4);
+#pragma unroll
+    for (int ty = 0; ty < 3; ++ty)
+#pragma unroll
+      for (int tx = 0; tx < 3; ++tx) {
+        const int yy = y + ty - 1, xx = x + tx - 1;
+        if (yy < 0 || yy >= H || xx < 0 || xx >= W) continue;
+        const int t = ty * 3 + tx;
+        f32x4 a = *reinterpret_cast<const f32x4*>(sw + 81 * 16 + t * 16 + cg * 4);
+#pragma unroll
+        for (int uy = 0; uy < 3; ++uy)
+#pragma unroll
+          for (int ux = 0; ux < 3; ++ux)
+            a += *reinterpret_cast<const f32x4*>(sw + (t * 9 + uy * 3 + ux) * 16 + cg * 4) * win[ty + uy][tx + ux];
+        acc += a;
+      }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) acc[k] = acc[k] > 0.f ? acc[k] : 0.1f * acc[k];
+    *reinterpret_cast<f32x4*>(out + p * ldo + cg * 4) = acc;
+  }
+}
+
 }  // namespace
 
 static int small_conv16_launch(const float* in, int ldi, const float* w, const float* bias, int B, int H, int W, int stride,
@@ -175,6 +231,21 @@ extern "C" int cdfo_spatial_gate16(const float* in, int ldi, const float* w, con
   CdfoProfScope prof(static_cast<hipStream_t>(stream), KID_SPATIAL_GATE, 0, 4.0*32*(double)B*H*W);
   hipLaunchKernelGGL(spatial_gate16_kernel, dim3(grid_for((long long)B * H * W)), dim3(256), 0,
                      static_cast<hipStream_t>(stream), in, ldi, w, bias, B, H, W, out, ldo);
+  CDFO_LAUNCH_CHECK();
+  return 0;
+}
+
+// lrelu(body.0(conv_second(img))) of the prior U-net's first round from the one-channel image (see udsa_head_kernel).
+// img element [b][y][x] at img + b*img_bstride + y*W + x; wc [9][9][16], bt [9][16], b0 [16]; out [B][H][W][16], pitch ldo.
+extern "C" int cdfo_udsa_head(const float* img, long long img_bstride, const float* wc, const float* bt, const float* b0, int B,
+                              int H, int W, float* out, int ldo, void* stream) {
+  if (B <= 0 || H <= 0 || W <= 0 || ldo % 4 || ldo < 16 || !img || !wc || !bt || !b0) return CDFO_EINVAL;
+  if (!aligned16(out)) return CDFO_EALIGN;
+  const long long total = (long long)B * H * W * 4;
+  long long blocks = (total + 255) / 256;
+  if (blocks > 16384) blocks = 16384;
+  hipLaunchKernelGGL(udsa_head_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), img, img_bstride, wc,
+                     bt, b0, B, H, W, out, ldo);
   CDFO_LAUNCH_CHECK();
   return 0;
 }

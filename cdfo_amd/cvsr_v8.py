@@ -248,6 +248,8 @@ class CVSR_V8(nn.Module):
         w[fe + "side_to_feaoneUDSA.body.11_hl"] = K.pack_conv_hilo(sd[fe + "side_to_feaoneUDSA.body.11.weight"],
                                                                    sd[fe + "side_to_feaoneUDSA.body.11.bias"], wlo)
         w[fe + "qkv_dw"] = K.pack_qkv_dw(sd[fe + "attn.qkv.weight"], sd[fe + "norm1.body.weight"], sd[fe + "norm1.body.bias"])
+        w["udsa_head"] = K.pack_udsa_head(sd[fe + "side_to_feaoneUDSA.body.0.weight"], sd[fe + "side_to_feaoneUDSA.body.0.bias"],
+                                          sd["conv_second.weight"], sd["conv_second.bias"])
         pc("upconv1", shuffle2=True)
         pc("upconv2", shuffle2=True)
         w["raw"] = {k: v.contiguous() for k, v in sd.items()}
@@ -270,10 +272,11 @@ class CVSR_V8(nn.Module):
         return K.conv(*args, prec=prec, **kw)
 
     # -- building blocks ------------------------------------------------------------------------------------------
-    def _udsa(self, w, x2, res):
+    def _udsa(self, w, x2, res, head=None):
+        """head: body.0's activated output when it was computed elsewhere (round 0: straight from the prior image)."""
         raw = w["raw"]
         u = "transformer_feature_extraction.path1.side_to_feaoneUDSA.body."
-        t = self._conv(x2, w[u + "0"], pad=1, act=K.ACT_LRELU, exact=True)
+        t = head if head is not None else self._conv(x2, w[u + "0"], pad=1, act=K.ACT_LRELU, exact=True)
         t = K.small_conv16(t, raw[u + "2.weight"], raw[u + "2.bias"], 2, 2, act=K.ACT_LRELU)
         t = K.small_conv16(t, raw[u + "4.weight"], raw[u + "4.bias"], 2, 2, act=K.ACT_LRELU)
         t = K.spatial_gate16(t, raw[u + "6.spatial.weight"], raw[u + "6.spatial.bias"])
@@ -287,13 +290,20 @@ class CVSR_V8(nn.Module):
         t = K.small_conv16(t, raw[u + "9.weight"], raw[u + "9.bias"], 2, 2, 1, True, K.ACT_LRELU)
         return self._conv(t, w[u + "11"], pad=1, act=K.ACT_LRELU, res1=res, exact=True)
 
-    def _feature_extraction(self, w, x1, x2):
+    def _feature_extraction(self, w, x1, prior, P, Bn):
+        """x1: conv_first features [Bn,H,W,64]; prior: the one-channel prior images (element [b][y][x] at b*P + y*W + x).
+        conv_second(prior) feeds only the prior U-net's first layer of round 0 and has no activation (arch.py:4420,
+        1463-1468): the two convolutions are composed (K.udsa_head), the 64-channel tensor between them never exists."""
         raw = w["raw"]
         p = "transformer_feature_extraction.path1."
+        x2 = None
         for rnd in range(3):
             # (the prior U-net is independent of the MDTA chain below, but issuing it on a side stream made the
             # forward 18 % slower: both chains are made of full-GPU launches that only get in each other's way)
-            x2 = self._udsa(w, x2, x1 if rnd == 0 else x2)
+            if rnd == 0:
+                x2 = self._udsa(w, None, x1, head=K.udsa_head(prior, P, Bn, self.H, self.W, w["udsa_head"]))
+            else:
+                x2 = self._udsa(w, x2, x2)
             if self.precision == "f32":
                 qkv = self._conv(x1, w[p + "attn.qkv"], ln=(raw[p + "norm1.body.weight"], raw[p + "norm1.body.bias"]))
                 qkv = K.dwconv3x3(qkv, raw[p + "attn.qkv_dwconv.weight"])
@@ -501,13 +511,11 @@ class CVSR_V8(nn.Module):
         # 1. feature extraction (arch.py:4416-4427)
         if pre_L1_fea is None:
             f = K.stem_conv(x, P, B * N, H, W, raw["conv_first.weight"], raw["conv_first.bias"], K.ACT_LRELU)
-            s = K.stem_conv(pms, P, B * N, H, W, raw["conv_second.weight"], raw["conv_second.bias"])
-            L1 = self._feature_extraction(w, f, s)                       # [B*7,H,W,64], clip-major
+            L1 = self._feature_extraction(w, f, pms, P, B * N)           # [B*7,H,W,64], clip-major
         else:
             last_x, last_p = x[:, -1].contiguous(), pms[:, -1].contiguous()
             f = K.stem_conv(last_x, P, B, H, W, raw["conv_first.weight"], raw["conv_first.bias"], K.ACT_LRELU)
-            s = K.stem_conv(last_p, P, B, H, W, raw["conv_second.weight"], raw["conv_second.bias"])
-            new = self._feature_extraction(w, f, s)                      # [B,H,W,64]
+            new = self._feature_extraction(w, f, last_p, P, B)           # [B,H,W,64]
             pre = self._as_pixel_major(pre_L1_fea, B * N, H, W)
             L1 = torch.empty_like(pre)
             L1v, prev = L1.view(B, N, H, W, NF), pre.view(B, N, H, W, NF)

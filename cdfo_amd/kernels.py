@@ -407,6 +407,24 @@ def stem_conv(img: torch.Tensor, img_bstride: int, B: int, H: int, W: int, w: to
     return (out, out2) if add is not None else out
 
 
+def pack_udsa_head(w0: torch.Tensor, b0: torch.Tensor, w2: torch.Tensor, b2: torch.Tensor):
+    """Composition of conv_second (1 -> 64, 3x3, w2 / b2) and the prior U-net's body.0 (64 -> 16, 3x3, w0 / b0) for
+    cdfo_udsa_head: (wc [9,9,16], bt [9,16], b0 [16]), summed over the 64 channels in float64."""
+    W0 = w0.detach().double().reshape(16, 64, 9)
+    W2 = w2.detach().double().reshape(64, 9)
+    wc = torch.einsum("oct,cu->tuo", W0, W2).float().contiguous()
+    bt = torch.einsum("oct,c->to", W0, b2.detach().double()).float().contiguous()
+    return wc, bt, b0.detach().float().contiguous()
+
+
+def udsa_head(img: torch.Tensor, img_bstride: int, B: int, H: int, W: int, packed) -> torch.Tensor:
+    """lrelu(body.0(conv_second(img))) -> [B,H,W,16]; img as in stem_conv."""
+    out = empty_act(B, H, W, 16, img.device)
+    check(_lib.lib().cdfo_udsa_head(_vp(img), C.c_longlong(img_bstride), _vp(packed[0]), _vp(packed[1]), _vp(packed[2]), B, H, W,
+                                    _vp(out), 16, _stream()), "cdfo_udsa_head")
+    return out
+
+
 def layernorm64(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor) -> torch.Tensor:
     B, H, W, Cc, ld = _chk_act(x)
     assert Cc == 64

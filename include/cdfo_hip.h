@@ -165,6 +165,13 @@ int cdfo_small_conv16(const float* in, int ldi, const float* w, const float* bia
 /* the same, result as fp16 hi | lo planes [B][2][Ho*Wo][16] (chunk-planar): the split-fp16 source of cdfo_conv3x3_ring */
 int cdfo_small_conv16_hl(const float* in, int ldi, const float* w, const float* bias, int B, int H, int W, int stride,
                          int pad, int out_pad, int transposed, int act, void* out_hl, void* stream);
+/* lrelu(body.0(conv_second(img))): the prior U-net's first layer in the feature extractor's first round (arch.py:4420,
+ * 1463-1468, 1819-1820) straight from the one-channel prior image -- conv_second's 64-channel result feeds only this
+ * layer there and has no activation, so the two 3x3 convolutions are composed (exactly, borders included: a tap of body.0
+ * outside the image sees zero, not conv_second's bias).  wc[t][u][o] = sum_c W0[o][c][t] W2[c][u] ([9][9][16]),
+ * bt[t][o] = sum_c W0[o][c][t] b2[c] ([9][16]), b0 = body.0's bias.  img element [b][y][x] at img + b*img_bstride + y*W + x. */
+int cdfo_udsa_head(const float* img, long long img_bstride, const float* wc, const float* bt, const float* b0, int B, int H,
+                   int W, float* out, int ldo, void* stream);
 int cdfo_spatial_gate16(const float* in, int ldi, const float* w, const float* bias, int B, int H, int W, float* out,
                         int ldo, void* stream);
 

@@ -522,3 +522,21 @@ def test_conv1x1_stream_many_tiles_across_images(srcs, Cout, nres, per_image):
     out2 = K.conv([_nhwc(t).cuda() for t in xs], pc, act=K.ACT_RELU, res1=dev_r[0], res2=dev_r[1], prec=K.PREC_BF16X3)
     torch.cuda.synchronize()
     assert torch.equal(out, out2)             # no atomics, fixed summation order
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,H,W", [(2, 8, 8), (3, 17, 29), (1, 64, 96)])
+def test_udsa_head_is_body0_of_conv_second(B, H, W):
+    """cdfo_udsa_head composes conv_second (1 -> 64) with the prior U-net's body.0 (64 -> 16, LeakyReLU 0.1), borders
+    included (arch.py:4420, 1819-1820): compared with the two torch convolutions in float64."""
+    import torch.nn.functional as F
+    from cdfo_amd import kernels as K
+    g = torch.Generator().manual_seed(B * 100 + H)
+    img = torch.randn(B, 1, H, W, generator=g)
+    w2, b2 = torch.randn(64, 1, 3, 3, generator=g) / 3, torch.randn(64, generator=g) * 0.3
+    w0, b0 = torch.randn(16, 64, 3, 3, generator=g) / 24, torch.randn(16, generator=g) * 0.3
+    ref = F.leaky_relu(F.conv2d(F.conv2d(img.double(), w2.double(), b2.double(), padding=1), w0.double(), b0.double(), padding=1), 0.1)
+    packed = K.pack_udsa_head(w0.cuda(), b0.cuda(), w2.cuda(), b2.cuda())
+    out = K.udsa_head(img.cuda().contiguous(), H * W, B, H, W, packed)
+    err = (out.permute(0, 3, 1, 2).double().cpu() - ref).abs().max().item()
+    assert err <= 2e-5 * max(1.0, ref.abs().max().item()), err

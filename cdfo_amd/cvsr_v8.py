@@ -240,6 +240,10 @@ class CVSR_V8(nn.Module):
                 fused = K.pack_conv(wf, wdn @ b2 + bdn)
                 fused.tap_mask = tap_mask
                 w[bp + "down_fused"] = fused
+                # the half-resolution branch ends in up.0(body.2(.)) before its bilinear x2: a 1x1 after a 3x3 convolution,
+                # both linear -> one 3x3 convolution (one launch and one round trip of the 64-channel tensor less per block)
+                wup, bup = sd[bp + "up.0.weight"][:, :, 0, 0], sd[bp + "up.0.bias"]
+                w[bp + "body.2_up"] = K.pack_conv(torch.einsum("po,ocyx->pcyx", wup, w3).contiguous(), wup @ b2 + bup)
                 w[bp + "pro"] = K.pack_block_prologue(sd[bp + "up.0.weight"], sd[bp + "up.0.bias"],
                                                       sd[bp + "down.0.weight"], sd[bp + "down.0.bias"])
         fe = "transformer_feature_extraction.path1."
@@ -417,11 +421,11 @@ class CVSR_V8(nn.Module):
             else:
                 u16, d16 = K.block_prologue(x, w[p + "pro"])
             out = K.conv_ring(c1(x16), b2, res1=x)
-            d = K.conv_ring(c1(d16), b2)
+            d = K.conv_ring(c1(d16), w[p + "body.2_up"])      # = up.0(body.2(.)) of the x1/2 branch
             t = c1(u16, s2d=True)
             y16 = torch.empty_like(x16) if want16 else None
-            # the x1/2 branch (up.0 of d, bilinear x2) is added by the last convolution's epilogue
-            y = K.conv_ring(t, w[p + "down_fused"], res1=out, res_up2=self._conv(d, up), out2_cp16=y16)
+            # the x1/2 branch (bilinear x2 of d) is added by the last convolution's epilogue
+            y = K.conv_ring(t, w[p + "down_fused"], res1=out, res_up2=d, out2_cp16=y16)
             return (y, y16) if want16 else y
         out = self._conv(self._conv(x, b0, pad=1, act=K.ACT_LRELU, out_f16=t16, inner=True), b2, pad=1, res1=x)
         # half-resolution branch

@@ -376,9 +376,25 @@ def dcn_forward_line(device, H, W, B, iters=10):
             traffic = tj["hbm_bytes_per_launch"] + tj["prepass_hbm_bytes_per_launch"]
         except Exception:
             traffic = None
+    # the operator's backward at the same shape (all five gradients, as tools/bench_dcn.py --backward)
+    from cdfo_amd import deform_conv_cuda as ext
+    go = torch.randn(B, Co, H, W, device=device, generator=g)
+    gi, gw, gb, goff, gm = (torch.zeros_like(t) for t in (x, w, b, off, msk))
+    e = torch.empty(0, device=device)
+    bwd = lambda: ext.modulated_deform_conv_cuda_backward(x, w, b, e, off, msk, e, gi, gw, gb, goff, gm, go, 3, 3, 1, 1, 1, 1,  # noqa: E731
+                                                          1, 1, 1, dg, True)
+    for _ in range(2):
+        bwd()
+    e0.record()
+    for _ in range(iters):
+        bwd()
+    e1.record()
+    torch.cuda.synchronize()
+    ms_b = e0.elapsed_time(e1) / iters
     return {"workload": f"DCNv2 forward C=Co=64 dg=16 3x3, {B}x{H}x{W}, MV-like offsets", "ms_per_launch": round(ms, 4),
             "roofline": {"bound": "hbm", "achieved": round(ach, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(ach / 8000.0, 4),
-                         "algorithmic_bytes_per_launch": nbytes, "traffic": traffic}}
+                         "algorithmic_bytes_per_launch": nbytes, "traffic": traffic},
+            "backward_ms_per_launch": round(ms_b, 4)}
 
 
 def _host_cores():

@@ -55,8 +55,9 @@ __device__ __forceinline__ float c1_row16_sum(float v) {  // sum over the 16 lan
 // NCB: number of 64-wide output-channel blocks (1..4).
 // TAPS (CDFO_STORE_TAPS9, upconv2 of arch.py:4474-4476 only): instead of the pixel-shuffled 64-channel HR feature map,
 // store for every HR pixel the nine per-tap channel sums t_k = sum_c w_last[c][k] * act(y)[c] of the 3x3 conv_last that
-// follows: 36 bytes per HR pixel instead of 256 (the 4.3 GB HR map is never written nor read back).  The 16 lanes that
-// hold one HR pixel's 64 channels are one DPP row.
+// follows: 36 bytes per HR pixel instead of 256 (the 4.3 GB HR map is never written nor read back).  The sums are a second
+// matrix product in the epilogue (round 2; as sixteen-lane DPP reductions they were 1 150 vector instructions per lane and
+// output block and made the launch 2.06 ms long).
 template <int NCB, bool TAPS = false>
 __global__ __launch_bounds__(256, 2) void conv1x1_bf16x3_kernel(cdfo_conv_args a) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[A_BYTES + W_BYTES];
@@ -150,12 +151,19 @@ __global__ __launch_bounds__(256, 2) void conv1x1_bf16x3_kernel(cdfo_conv_args a
   const int c4 = lane & 15, pr = lane >> 4;                  // 16 float4 columns, 4 pixel rows per wave-instruction
   const bool plain = a.store_mode == CDFO_STORE_PLAIN;
   const int cq = a.Cout >> 2;
-  f32x4 wl9[TAPS ? 9 : 1];                                   // conv_last taps of this lane's 4 channels (a.res2 = [64][9])
+  // TAPS: the nine tap sums are a second matrix product, taps[k][pixel] = sum_c w_last[c][k] * act(y)[pixel][c] -- A = w_last^T
+  // (row = tap, zero rows 9..31), split fp16 hi | lo once per lane: lane (r = tap, h) holds channels 16 s + 8 h .. + 7
+  typedef _Float16 c1_f16x8 __attribute__((ext_vector_type(8)));
+  c1_f16x8 twh[TAPS ? 4 : 1], twl[TAPS ? 4 : 1];
   if (TAPS) {
 #pragma unroll
-    for (int k = 0; k < 9; ++k)
+    for (int s4 = 0; s4 < 4; ++s4)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) wl9[k][j] = a.res2[(c4 * 4 + j) * 9 + k];
+      for (int j = 0; j < 8; ++j) {
+        const float wv = r < 9 ? a.res2[(16 * s4 + 8 * h + j) * 9 + r] : 0.f;      // a.res2 = conv_last.weight as [64][9]
+        twh[s4][j] = (_Float16)wv;
+        twl[s4][j] = (_Float16)(wv - (float)twh[s4][j]);
+      }
   }
 #pragma unroll
   for (int cb = 0; cb < NCB; ++cb) {
@@ -166,6 +174,62 @@ __global__ __launch_bounds__(256, 2) void conv1x1_bf16x3_kernel(cdfo_conv_args a
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (TAPS) {
+      // block cb = sub-pixel (dy, dx) = (cb >> 1, cb & 1) of the pixel-shuffled map.  B = act(y + bias) of this wave's 32
+      // pixels (lane (r = pixel, h): channels 16 s + 8 h .. + 7 from the transposed tile), scaled per PIXEL by a power of two
+      // into fp16's range (a column of the product may carry its own scale) and split hi | lo: hi*hi + lo*hi + hi*lo.
+      f32x4 y[4][2];
+      float amax = 0.f;
+#pragma unroll
+      for (int s4 = 0; s4 < 4; ++s4)
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          const int ch = 16 * s4 + 8 * h + 4 * q;
+          f32x4 t = *reinterpret_cast<const f32x4*>(wl + r * EPI_RS + ch);
+          if (a.bias) t += *reinterpret_cast<const f32x4*>(a.bias + cb * 64 + ch);
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            t[k] = fmaxf(t[k], 0.f) + slope * fminf(t[k], 0.f);
+            amax = fmaxf(amax, fabsf(t[k]));
+          }
+          y[s4][q] = t;
+        }
+      amax = fmaxf(amax, __shfl_xor(amax, 32, 64));            // the pixel's other 32 channels sit in lane ^ 32
+      int ex = 0;
+      if (amax > 0.f && amax < INFINITY) frexpf(amax, &ex);
+      ex = ex < -100 ? -100 : (ex > 100 ? 100 : ex);
+      const float sc = ldexpf(1.f, 14 - ex), inv = ldexpf(1.f, ex - 14);
+      f32x16 tacc;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) tacc[e] = 0.f;
+#pragma unroll
+      for (int s4 = 0; s4 < 4; ++s4) {
+        c1_f16x8 yh, yl;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float v = y[s4][j >> 2][j & 3] * sc;
+          yh[j] = (_Float16)v;
+          yl[j] = (_Float16)(v - (float)yh[j]);
+        }
+        tacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(twl[s4], yh, tacc, 0, 0, 0);
+        tacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(twh[s4], yl, tacc, 0, 0, 0);
+        tacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(twh[s4], yh, tacc, 0, 0, 0);
+      }
+      // lane (pixel r, h): registers 0..3 = taps 4 h .. 4 h + 3, register 4 = tap 8 (h = 0)
+      const long long pin = p0 + wave * 32 + r;
+      if (pin < P) {
+        const int oy = (int)(pin / a.W), ox = (int)(pin - (long long)oy * a.W);
+        const long long opix = ((long long)b * 2 * a.H + 2 * oy + (cb >> 1)) * (2 * a.W) + 2 * ox + (cb & 1);
+        float* op = a.out + opix * a.ldo;
+        const f32x4 t4 = {tacc[0] * inv, tacc[1] * inv, tacc[2] * inv, tacc[3] * inv};
+        if ((a.ldo & 3) == 0) *reinterpret_cast<f32x4*>(op + 4 * h) = t4;
+        else { op[4 * h] = t4[0]; op[4 * h + 1] = t4[1]; op[4 * h + 2] = t4[2]; op[4 * h + 3] = t4[3]; }
+        if (h == 0) op[8] = tacc[4] * inv;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      continue;
+    }
     const int n = cb * 64 + c4 * 4;
     const bool nok = n < a.Cout;
     f32x4 bias = {0.f, 0.f, 0.f, 0.f};
@@ -179,19 +243,6 @@ __global__ __launch_bounds__(256, 2) void conv1x1_bf16x3_kernel(cdfo_conv_args a
       const long long pin = p0 + wave * 32 + i;               // pixel inside the image
       if (!nok || pin >= P) continue;
       const long long pix = (long long)b * P + pin;
-      if (TAPS) {        // block cb = sub-pixel (dy, dx) = (cb >> 1, cb & 1); lane c4 < 9 stores tap sum c4
-        float mine = 0.f;
-#pragma unroll
-        for (int k = 0; k < 9; ++k) {
-          const f32x4 pr4 = t * wl9[k];
-          const float sk = c1_row16_sum((pr4[0] + pr4[1]) + (pr4[2] + pr4[3]));
-          mine = c4 == k ? sk : mine;
-        }
-        const int oy = (int)(pin / a.W), ox = (int)(pin - (long long)oy * a.W);
-        const long long opix = ((long long)b * 2 * a.H + 2 * oy + (cb >> 1)) * (2 * a.W) + 2 * ox + (cb & 1);
-        if (c4 < 9) a.out[opix * a.ldo + c4] = mine;
-        continue;
-      }
       if (plain) {
         if (a.res1) t += *reinterpret_cast<const f32x4*>(a.res1 + pix * a.ldr1 + n);
         if (a.res2) t += *reinterpret_cast<const f32x4*>(a.res2 + pix * a.ldr2 + n);

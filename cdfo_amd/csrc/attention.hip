@@ -8,6 +8,7 @@
 //   seq_attn    : softmax(Q Q^T) V over a row, a column or an 8x8 window, one query per lane, keys streamed through
 //                 wave-uniform (scalar) loads, online softmax in registers.
 #include "common.h"
+#include <cstdlib>
 
 namespace {
 
@@ -523,13 +524,20 @@ extern "C" int cdfo_seq_attn(const float* q, int ldq, const float* v, int ldv, f
   hipStream_t st = static_cast<hipStream_t>(stream);
   CdfoProfScope prof(static_cast<hipStream_t>(stream), (mode%10)==0?KID_ATTN_ROW:((mode%10)==1?KID_ATTN_COL:KID_ATTN_WIN), 4.0*64*(double)B*H*W*((mode%10)==0?W:((mode%10)==1?H:64)), 4.0*192*(double)B*H*W);
   if (mode == 0 || mode == 1) {
-    // short sequences fit one 4-wave workgroup; long ones amortise the staging over 8 waves
+    // 8-wave workgroups amortise the staging over twice the queries, but only if the sequence's 32-query tiles fill them:
+    // 272 keys = 9 tiles = 2 x 8 waves at 56 % or 3 x 4 waves at 75 % (column attention at 24 x 272 x 480: 1.61 vs 1.35 ms;
+    // row attention, 480 keys: 1.67 ms with 8 waves, 1.86 with 4).  The strided key rows of the column form are NOT what
+    // it waits for: the same products over transposed tensors (contiguous rows of 272 keys) took 1.50 ms.
     const int L = mode == 0 ? W : H;
+    const int ntq = cdiv(L, 32);
+    static const int force_nw = getenv("CDFO_ATTN_NW") ? atoi(getenv("CDFO_ATTN_NW")) : 0;     // developer switch (4 / 8)
+    const bool wide = force_nw ? force_nw == 8
+                               : L > 128 && (double)ntq / (cdiv(ntq, 8) * 8) >= (double)ntq / (cdiv(ntq, 4) * 4) - 0.1;
     int rc;
-    if (mode == 0) rc = L <= 128 ? seq_attn_launch<0, 4>(q, ldq, v, ldv, out, ldo, B, H, W, st)
-                                 : seq_attn_launch<0, 8>(q, ldq, v, ldv, out, ldo, B, H, W, st);
-    else rc = L <= 128 ? seq_attn_launch<1, 4>(q, ldq, v, ldv, out, ldo, B, H, W, st)
-                       : seq_attn_launch<1, 8>(q, ldq, v, ldv, out, ldo, B, H, W, st);
+    if (mode == 0) rc = !wide ? seq_attn_launch<0, 4>(q, ldq, v, ldv, out, ldo, B, H, W, st)
+                              : seq_attn_launch<0, 8>(q, ldq, v, ldv, out, ldo, B, H, W, st);
+    else rc = !wide ? seq_attn_launch<1, 4>(q, ldq, v, ldv, out, ldo, B, H, W, st)
+                    : seq_attn_launch<1, 8>(q, ldq, v, ldv, out, ldo, B, H, W, st);
     if (rc) return rc;
   } else if (mode == 10) {   // VALU reference forms of modes 0 / 1 (kept for A/B tests)
     hipLaunchKernelGGL(seq_attn_kernel<0>, dim3((unsigned)((long long)B * H * cdiv(W, 64))), dim3(64), 0, st, q, ldq, v,

@@ -54,6 +54,56 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(const float* __restrict_
   }
 }
 
+// Two 3x3 convolutions 1 -> 64 of the SAME single-channel plane in one pass:
+//     outA = conv(img; wA, bA) + add            (fea_com = fea_i + conv_expand_rms(rms), arch.py:4446-4449)
+//     outB = actB(conv(img; wB, bB))            (relu(conv_du_re.0(conv_expand_rms(rms))): the 1x1 conv_du_re.0 of
+//                                                LLongRangAttention, arch.py:2148-2152 / 2200, composed with
+//                                                conv_expand_rms on the host -- a 1x1 after a 3x3, nothing in between)
+// so that `rms_prior` itself (read only by those two consumers) is never written.
+__global__ __launch_bounds__(256) void stem_conv2_kernel(const float* __restrict__ img, long long img_bstride,
+                                                         const float* __restrict__ wA, const float* __restrict__ bA,
+                                                         const float* __restrict__ add, int lda, float* __restrict__ outA,
+                                                         int ldoA, const float* __restrict__ wB,
+                                                         const float* __restrict__ bB, int actB, float* __restrict__ outB,
+                                                         int ldoB, int B, int H, int W) {
+  const int cg = threadIdx.x & 15;  // channel group: couts 4cg..4cg+3
+  float wa[9][4], wb[9][4], ba[4], bb[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    ba[j] = bA ? bA[cg * 4 + j] : 0.f;
+    bb[j] = bB ? bB[cg * 4 + j] : 0.f;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) { wa[t][j] = wA[(cg * 4 + j) * 9 + t]; wb[t][j] = wB[(cg * 4 + j) * 9 + t]; }
+  }
+  const long long npix = (long long)B * H * W;
+  for (long long p = (blockIdx.x * (long long)blockDim.x + threadIdx.x) >> 4; p < npix;
+       p += ((long long)gridDim.x * blockDim.x) >> 4) {
+    const int x = p % W;
+    const int y = (p / W) % H;
+    const int b = p / ((long long)W * H);
+    const float* ip = img + b * img_bstride;
+    float v[9];
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+      for (int dx = 0; dx < 3; ++dx) {
+        const int yy = y + dy - 1, xx = x + dx - 1;
+        v[dy * 3 + dx] = (yy >= 0 && yy < H && xx >= 0 && xx < W) ? ip[(long long)yy * W + xx] : 0.f;
+      }
+    f32x4 oa, ob;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float sa = ba[j], sb = bb[j];
+#pragma unroll
+      for (int t = 0; t < 9; ++t) { sa += v[t] * wa[t][j]; sb += v[t] * wb[t][j]; }
+      oa[j] = sa;
+      ob[j] = act_apply(sb, actB);
+    }
+    *reinterpret_cast<f32x4*>(outA + p * ldoA + cg * 4) = oa + *reinterpret_cast<const f32x4*>(add + p * lda + cg * 4);
+    *reinterpret_cast<f32x4*>(outB + p * ldoB + cg * 4) = ob;
+  }
+}
+
 // ------------------------------------------------------------------------------------------------------------
 // per-pixel LayerNorm over 64 channels, biased variance, eps 1e-5 (arch.py:1169-1185)
 __global__ __launch_bounds__(256) void layernorm64_kernel(const float* __restrict__ in, int ldi,
@@ -474,6 +524,19 @@ extern "C" int cdfo_stem_conv(const float* img, long long img_bstride, const flo
   hipLaunchKernelGGL(stem_conv_kernel, dim3(grid_for((long long)B * H * W * 16)), dim3(256), 0,
                      static_cast<hipStream_t>(stream), img, img_bstride, w, bias, B, H, W, act, out, ldo, add, lda, out2,
                      ldo2);
+  CDFO_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int cdfo_stem_conv2(const float* img, long long img_bstride, const float* wA, const float* bA, const float* add,
+                               int lda, float* outA, int ldoA, const float* wB, const float* bB, int actB, float* outB,
+                               int ldoB, int B, int H, int W, void* stream) {
+  if (B <= 0 || H <= 0 || W <= 0 || !img || !wA || !wB || !add || lda % 4 || ldoA % 4 || ldoB % 4) return CDFO_EINVAL;
+  if (!aligned16(outA) || !aligned16(outB) || !aligned16(add)) return CDFO_EALIGN;
+  CdfoProfScope prof(static_cast<hipStream_t>(stream), KID_STEM, 2.0*2*9*64*(double)B*H*W, 4.0*(double)B*H*W*(1+192));
+  hipLaunchKernelGGL(stem_conv2_kernel, dim3(grid_for((long long)B * H * W * 16)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), img, img_bstride, wA, bA, add, lda, outA, ldoA, wB, bB, actB, outB,
+                     ldoB, B, H, W);
   CDFO_LAUNCH_CHECK();
   return 0;
 }

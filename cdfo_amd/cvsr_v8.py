@@ -252,6 +252,12 @@ class CVSR_V8(nn.Module):
         w[fe + "side_to_feaoneUDSA.body.11_hl"] = K.pack_conv_hilo(sd[fe + "side_to_feaoneUDSA.body.11.weight"],
                                                                    sd[fe + "side_to_feaoneUDSA.body.11.bias"], wlo)
         w[fe + "qkv_dw"] = K.pack_qkv_dw(sd[fe + "attn.qkv.weight"], sd[fe + "norm1.body.weight"], sd[fe + "norm1.body.bias"])
+        # conv_du_re.0 (1x1) of the compensation module composed with conv_expand_rms (3x3 on the one-channel residual map): a
+        # second 1 -> 64 stencil for the stem kernel, so that `rms_prior` is never materialised (arch.py:2200, 4446-4449)
+        w1 = sd["RDAB.conv_du_re.0.weight"].double()[:, :, 0, 0]
+        wr, br = sd["conv_expand_rms.weight"].double(), sd["conv_expand_rms.bias"].double()
+        w["rms_du0"] = (torch.einsum("oc,ckyx->okyx", w1, wr).float().contiguous(),
+                        (w1 @ br + sd["RDAB.conv_du_re.0.bias"].double()).float().contiguous())
         w["udsa_head"] = K.pack_udsa_head(sd[fe + "side_to_feaoneUDSA.body.0.weight"], sd[fe + "side_to_feaoneUDSA.body.0.bias"],
                                           sd["conv_second.weight"], sd["conv_second.bias"])
         pc("upconv1", shuffle2=True)
@@ -330,16 +336,16 @@ class CVSR_V8(nn.Module):
                 x1 = self._conv(ln, w[p + "conv"], pad=1, res1=x1, res2=x2, exact=True)
         return x1
 
-    def _rdab(self, w, res, x, noises):
-        """LLongRangAttention (arch.py:2179-2249) on a GROUP of neighbour frames at once: res / x are [G*B,H,W,64] (neighbour
-        major), `noises` one entry per neighbour -- the module's weights are shared by all neighbours, only the noise draw (and
-        with it the mask kernel's launch) is per neighbour."""
+    def _rdab(self, w, du0, x, noises):
+        """LLongRangAttention (arch.py:2179-2249) on a GROUP of neighbour frames at once: du0 / x are [G*B,H,W,64] (neighbour
+        major; du0 = relu(conv_du_re.0(res)) of the module's residual-map input, computed by the stem kernel), `noises` one
+        entry per neighbour -- the module's weights are shared by all neighbours, only the noise draw (and with it the mask
+        kernel's launch) is per neighbour."""
         raw = w["raw"]
         GB, H, W, _ = x.shape
         G = len(noises)
         B = GB // G
-        t = self._conv(res, w["RDAB.conv_du_re.0"], act=K.ACT_RELU)
-        t = self._conv(t, w["RDAB.conv_du_re.2"], stride=2, pad=2, act=K.ACT_RELU)
+        t = self._conv(du0, w["RDAB.conv_du_re.2"], stride=2, pad=2, act=K.ACT_RELU)
         part, n = K.chan_sum_partial(t)
         vmax = K.vec_mlp(part, n, t.shape[1] * t.shape[2], raw["RDAB.conv_du_re2.0.weight"],
                          raw["RDAB.conv_du_re2.0.bias"], 64, K.ACT_RELU)
@@ -594,13 +600,14 @@ class CVSR_V8(nn.Module):
         G = len(idxs)
         GB = G * B
         feaG = Lf[idxs[0]:idxs[0] + G].view(GB, H, W, NF)
-        ufs_prior, rms_prior, fea_com = (K.empty_act(GB, H, W, NF, x_dev) for _ in range(3))
+        ufs_prior, du0, fea_com = (K.empty_act(GB, H, W, NF, x_dev) for _ in range(3))
         noises = []
         for n, i in enumerate(idxs):
             sl = slice(n * B, (n + 1) * B)
             K.stem_conv(ufs[:, 0, i], N * P, B, H, W, raw["conv_expand_ufs.weight"], raw["conv_expand_ufs.bias"], out=ufs_prior[sl])
-            K.stem_conv(rms[:, 0, i], N * P, B, H, W, raw["conv_expand_rms.weight"], raw["conv_expand_rms.bias"], add=Lf[i],
-                        out=rms_prior[sl], out2=fea_com[sl])
+            # fea_com = fea_i + rms_prior and du0 = relu(conv_du_re.0(rms_prior)) from the residual map itself
+            K.stem_conv2(rms[:, 0, i], N * P, B, H, W, raw["conv_expand_rms.weight"], raw["conv_expand_rms.bias"], Lf[i],
+                         fea_com[sl], w["rms_du0"][0], w["rms_du0"][1], K.ACT_RELU, du0[sl])
             draw = draw0 + n
             if noise is None:
                 # the reference's default (torch.rand_like per call, arch.py:2169): the draws are generated INSIDE rdab_prep
@@ -612,7 +619,7 @@ class CVSR_V8(nn.Module):
                 noises.append(("rng", self._noise_seed, draw, cap))
             else:
                 noises.append(noise[draw].to(device=x_dev, dtype=torch.float32).contiguous())
-        x_n = self._rdab(w, rms_prior, fea_com, noises)
+        x_n = self._rdab(w, du0, fea_com, noises)
         fea_i = self._conv([feaG, x_n], w["conv_expand_fea_r"], pad=1)
         al = K.empty_act(GB, H, W, NF, x_dev)
         xc = xcG if xcG.shape[0] == GB else xcG[:GB]
@@ -621,7 +628,7 @@ class CVSR_V8(nn.Module):
             for n, i in enumerate(idxs):
                 self.debug_taps[f"rdab_{i}"] = x_n[n * B:(n + 1) * B]
                 self.debug_taps[f"align_{i}"] = al[n * B:(n + 1) * B]
-        keep.extend([ufs_prior, rms_prior, fea_com, noises, x_n, fea_i, xc])
+        keep.extend([ufs_prior, du0, fea_com, noises, x_n, fea_i, xc])
         return al
 
     @staticmethod

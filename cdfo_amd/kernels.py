@@ -407,6 +407,17 @@ def stem_conv(img: torch.Tensor, img_bstride: int, B: int, H: int, W: int, w: to
     return (out, out2) if add is not None else out
 
 
+def stem_conv2(img: torch.Tensor, img_bstride: int, B: int, H: int, W: int, wA: torch.Tensor, bA: torch.Tensor,
+               add: torch.Tensor, outA: torch.Tensor, wB: torch.Tensor, bB: torch.Tensor, actB: int, outB: torch.Tensor):
+    """outA = conv3x3(img; wA, bA) + add, outB = actB(conv3x3(img; wB, bB)); img as in stem_conv, outA / outB dense [B,H,W,64]."""
+    _, _, _, _, lda = _chk_act(add, "add")
+    for o in (outA, outB):
+        if tuple(o.shape) != (B, H, W, 64) or not o.is_contiguous():
+            raise ValueError("stem_conv2: outputs must be dense [B,H,W,64] tensors")
+    check(_lib.lib().cdfo_stem_conv2(_vp(img), C.c_longlong(img_bstride), _vp(wA), _vp(bA), _vp(add), lda, _vp(outA), 64,
+                                     _vp(wB), _vp(bB), actB, _vp(outB), 64, B, H, W, _stream()), "cdfo_stem_conv2")
+
+
 def pack_udsa_head(w0: torch.Tensor, b0: torch.Tensor, w2: torch.Tensor, b2: torch.Tensor):
     """Composition of conv_second (1 -> 64, 3x3, w2 / b2) and the prior U-net's body.0 (64 -> 16, 3x3, w0 / b0) for
     cdfo_udsa_head: (wc [9,9,16], bt [9,16], b0 [16]), summed over the 64 channels in float64."""

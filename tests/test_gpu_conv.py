@@ -540,3 +540,21 @@ def test_udsa_head_is_body0_of_conv_second(B, H, W):
     out = K.udsa_head(img.cuda().contiguous(), H * W, B, H, W, packed)
     err = (out.permute(0, 3, 1, 2).double().cpu() - ref).abs().max().item()
     assert err <= 2e-5 * max(1.0, ref.abs().max().item()), err
+
+
+@pytest.mark.gpu
+def test_stem_conv2_is_two_stencils_of_one_plane():
+    """cdfo_stem_conv2: outA = conv(img; wA, bA) + add, outB = relu(conv(img; wB, bB)) (arch.py:4446-4449, 2200)."""
+    from cdfo_amd import kernels as K
+    g = torch.Generator().manual_seed(11)
+    B, H, W = 3, 17, 29
+    img = torch.randn(B, 1, H, W, generator=g)
+    wA, bA = torch.randn(64, 1, 3, 3, generator=g) / 3, torch.randn(64, generator=g)
+    wB, bB = torch.randn(64, 1, 3, 3, generator=g) / 3, torch.randn(64, generator=g)
+    add = torch.randn(B, H, W, 64, generator=g)
+    outA, outB = torch.empty(B, H, W, 64, device="cuda"), torch.empty(B, H, W, 64, device="cuda")
+    K.stem_conv2(img.cuda().contiguous(), H * W, B, H, W, wA.cuda(), bA.cuda(), add.cuda(), outA, wB.cuda(), bB.cuda(), K.ACT_RELU, outB)
+    refA = F.conv2d(img, wA, bA, padding=1).permute(0, 2, 3, 1) + add
+    refB = F.relu(F.conv2d(img, wB, bB, padding=1)).permute(0, 2, 3, 1)
+    assert (outA.cpu() - refA).abs().max().item() <= 1e-5
+    assert (outB.cpu() - refB).abs().max().item() <= 1e-5

@@ -409,3 +409,71 @@ def test_dcn_fast_path_full_size_matches_exact_kernel_and_is_reproducible():
     assert torch.equal(fast[0], fast[1]) and torch.equal(fast[0], fast[2])
     err = (fast[0] - exact).abs().max().item()
     assert err <= 2e-5 * max(1.0, exact.abs().max().item()), err
+
+
+@pytest.mark.parametrize("scale", [1e-12, 1.0, 1e12])
+def test_dcn_backward_tiled_forms_hold_their_accuracy_at_any_magnitude(scale):
+    """The alignment-shape backward scatters grad_input as 64-bit fixed point (scale chosen per workgroup) and contracts the
+    weight gradient as split fp16 (scaled per tile / wave): both must keep fp32-grade RELATIVE accuracy whatever the
+    magnitude of grad_output is (the backward is linear in it)."""
+    from cdfo_amd import deform_conv_cuda as ext
+    from oracle.dcn_modules_ref import dcn_backward_ref
+    B, C, Co, H, W, k, s, p, d, g, dg = 2, 16, 24, 19, 37, 3, 1, 1, 1, 1, 4
+    x, w, b, off, msk, go = _bwd_inputs(B, C, Co, H, W, k, s, p, d, g, dg, 4242)
+    ref = dcn_backward_ref(x, off, msk, w, go, s, p, d, g, dg)
+    t = lambda a: torch.from_numpy(a).cuda()  # noqa: E731
+    e = torch.empty(0, device="cuda")
+    gi, gw, gb, goff, gm = (torch.zeros_like(t(a)) for a in (x, w, b, off, msk))
+    ext.modulated_deform_conv_cuda_backward(t(x), t(w), t(b), e, t(off), t(msk), e, gi, gw, gb, goff, gm, t(go) * scale, k, k, s, s,
+                                            p, p, d, d, g, dg, True)
+    torch.cuda.synchronize()
+    for got, name in ((gi, "grad_input"), (gw, "grad_weight"), (gb, "grad_bias"), (goff, "grad_offset"), (gm, "grad_mask")):
+        _close(got.double().cpu().numpy() / scale, ref[name])
+
+
+def test_dcn_backward_tiled_form_propagates_non_finite_gradients():
+    """A NaN in grad_output reaches grad_input (the fixed-point window is bypassed for that workgroup) instead of vanishing."""
+    from cdfo_amd import deform_conv_cuda as ext
+    B, C, Co, H, W, k, s, p, d, g, dg = 1, 8, 8, 16, 32, 3, 1, 1, 1, 1, 2
+    x, w, b, off, msk, go = _bwd_inputs(B, C, Co, H, W, k, s, p, d, g, dg, 7)
+    off *= 0.1
+    go[0, 3, 5, 7] = np.nan
+    t = lambda a: torch.from_numpy(a).cuda()  # noqa: E731
+    e = torch.empty(0, device="cuda")
+    gi, gw, gb, goff, gm = (torch.zeros_like(t(a)) for a in (x, w, b, off, msk))
+    ext.modulated_deform_conv_cuda_backward(t(x), t(w), t(b), e, t(off), t(msk), e, gi, gw, gb, goff, gm, t(go), k, k, s, s, p, p,
+                                            d, d, g, dg, True)
+    torch.cuda.synchronize()
+    assert torch.isnan(gi).any() and torch.isnan(gw).any()
+    assert torch.isfinite(gi).any()          # the NaN stays local: pixels far from (5, 7) are untouched
+
+
+def test_dcn_backward_with_and_without_workspace_agree():
+    """cdfo_dcn_backward_ws (matrix-core weight gradient from the data kernel's columns) against cdfo_dcn_backward (second
+    sampling pass) through the C-ABI."""
+    import ctypes as C
+    from cdfo_amd import _lib
+    L = _lib.lib()
+    B, Cc, Co, H, W, k, dg = 2, 32, 64, 24, 40, 3, 8
+    x, w, b, off, msk, go = _bwd_inputs(B, Cc, Co, H, W, k, 1, 1, 1, 1, dg, 99)
+    t = lambda a: torch.from_numpy(a).cuda()  # noqa: E731
+    tx, tw, toff, tm, tgo = t(x), t(w), t(off), t(msk), t(go)
+    p = lambda z: C.c_void_p(z.data_ptr())  # noqa: E731
+    res = []
+    for use_ws in (False, True):
+        gi, gw, gb, goff, gm = (torch.zeros_like(z) for z in (tx, tw, t(b), toff, tm))
+        st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        if use_ws:
+            n = L.cdfo_dcn_backward_workspace_bytes(B, Cc, H, W, Co, k, k, 1, 1, 1, 1, 1, 1, 1, dg)
+            assert n > 0
+            ws = torch.empty(n, dtype=torch.uint8, device="cuda")
+            rc = L.cdfo_dcn_backward_ws(p(tx), p(toff), p(tm), p(tw), p(tgo), p(gi), p(goff), p(gm), p(gw), p(gb), B, Cc, H, W, Co, k, k,
+                                        1, 1, 1, 1, 1, 1, 1, dg, C.c_float(1.0), p(ws), C.c_longlong(n), st)
+        else:
+            rc = L.cdfo_dcn_backward(p(tx), p(toff), p(tm), p(tw), p(tgo), p(gi), p(goff), p(gm), p(gw), p(gb), B, Cc, H, W, Co, k, k,
+                                     1, 1, 1, 1, 1, 1, 1, dg, C.c_float(1.0), st)
+        assert rc == 0
+        torch.cuda.synchronize()
+        res.append([z.cpu().numpy() for z in (gi, gw, gb, goff, gm)])
+    for a0, a1 in zip(*res):
+        _close(a1, a0, 2e-5)

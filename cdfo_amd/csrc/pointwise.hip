@@ -65,7 +65,7 @@ __global__ __launch_bounds__(256) void stem_conv2_kernel(const float* __restrict
                                                          const float* __restrict__ add, int lda, float* __restrict__ outA,
                                                          int ldoA, const float* __restrict__ wB,
                                                          const float* __restrict__ bB, int actB, float* __restrict__ outB,
-                                                         int ldoB, int B, int H, int W) {
+                                                         int ldoB, int B, int H, int W, int s2dB) {
   const int cg = threadIdx.x & 15;  // channel group: couts 4cg..4cg+3
   float wa[9][4], wb[9][4], ba[4], bb[4];
 #pragma unroll
@@ -100,7 +100,15 @@ __global__ __launch_bounds__(256) void stem_conv2_kernel(const float* __restrict
       ob[j] = act_apply(sb, actB);
     }
     *reinterpret_cast<f32x4*>(outA + p * ldoA + cg * 4) = oa + *reinterpret_cast<const f32x4*>(add + p * lda + cg * 4);
-    *reinterpret_cast<f32x4*>(outB + p * ldoB + cg * 4) = ob;
+    if (s2dB) {
+      // space-to-depth form [B][H/2 + 1][W/2 + 1][4 * 64] (channel = (y & 1, x & 1) phase * 64 + c; the extra last row and
+      // column are the caller's zero padding): the 3x3 stride-2 pad-2 convolution that follows (conv_du_re.2) is then a
+      // stride-1 convolution with a 2x2 tap window over it
+      const long long q = ((long long)b * ((H >> 1) + 1) + (y >> 1)) * ((W >> 1) + 1) + (x >> 1);
+      *reinterpret_cast<f32x4*>(outB + q * ldoB + ((y & 1) * 2 + (x & 1)) * 64 + cg * 4) = ob;
+    } else {
+      *reinterpret_cast<f32x4*>(outB + p * ldoB + cg * 4) = ob;
+    }
   }
 }
 
@@ -530,13 +538,14 @@ extern "C" int cdfo_stem_conv(const float* img, long long img_bstride, const flo
 
 extern "C" int cdfo_stem_conv2(const float* img, long long img_bstride, const float* wA, const float* bA, const float* add,
                                int lda, float* outA, int ldoA, const float* wB, const float* bB, int actB, float* outB,
-                               int ldoB, int B, int H, int W, void* stream) {
+                               int ldoB, int s2dB, int B, int H, int W, void* stream) {
   if (B <= 0 || H <= 0 || W <= 0 || !img || !wA || !wB || !add || lda % 4 || ldoA % 4 || ldoB % 4) return CDFO_EINVAL;
+  if (s2dB && ((H & 1) || (W & 1) || ldoB < 256)) return CDFO_EINVAL;
   if (!aligned16(outA) || !aligned16(outB) || !aligned16(add)) return CDFO_EALIGN;
   CdfoProfScope prof(static_cast<hipStream_t>(stream), KID_STEM, 2.0*2*9*64*(double)B*H*W, 4.0*(double)B*H*W*(1+192));
   hipLaunchKernelGGL(stem_conv2_kernel, dim3(grid_for((long long)B * H * W * 16)), dim3(256), 0,
                      static_cast<hipStream_t>(stream), img, img_bstride, wA, bA, add, lda, outA, ldoA, wB, bB, actB, outB,
-                     ldoB, B, H, W);
+                     ldoB, B, H, W, s2dB);
   CDFO_LAUNCH_CHECK();
   return 0;
 }

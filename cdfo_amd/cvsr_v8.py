@@ -258,6 +258,26 @@ class CVSR_V8(nn.Module):
         wr, br = sd["conv_expand_rms.weight"].double(), sd["conv_expand_rms.bias"].double()
         w["rms_du0"] = (torch.einsum("oc,ckyx->okyx", w1, wr).float().contiguous(),
                         (w1 @ br + sd["RDAB.conv_du_re.0.bias"].double()).float().contiguous())
+        # conv_du_re.2 (3x3, stride 2, pad 2) over the space-to-depth form of its input [H/2+1, W/2+1, 4*64] (written that way by
+        # the stem kernel): output (i, j) reads input rows 2i-2+dy = s2d row i-1 phase dy (dy = 0, 1) or s2d row i phase 0
+        # (dy = 2) -- a stride-1 pad-1 convolution with weights on the taps (-1, 0) x (-1, 0) only, which the 16-bit MFMA kernel
+        # runs with a per-chunk tap mask (the exact-fp32 strided kernel it replaces: 0.91 ms per launch)
+        w2 = sd["RDAB.conv_du_re.2.weight"]
+        ws2d = w2.new_zeros(64, 4, 64, 3, 3)
+        masks = []
+        for a_ in range(2):
+            for b_ in range(2):
+                m = 0
+                for ty in range(2):
+                    for tx in range(2):
+                        dy, dx = 2 * ty + a_, 2 * tx + b_
+                        if dy <= 2 and dx <= 2:
+                            ws2d[:, a_ * 2 + b_, :, ty, tx] = w2[:, :, dy, dx]
+                            m |= 1 << (ty * 3 + tx)
+                masks += [m] * 4
+        pc2 = K.pack_conv(ws2d.view(64, 256, 3, 3).contiguous(), sd["RDAB.conv_du_re.2.bias"])
+        pc2.tap_mask = torch.tensor(masks, dtype=torch.int32, device=w2.device)
+        w["RDAB.conv_du_re.2_s2d"] = pc2
         w["udsa_head"] = K.pack_udsa_head(sd[fe + "side_to_feaoneUDSA.body.0.weight"], sd[fe + "side_to_feaoneUDSA.body.0.bias"],
                                           sd["conv_second.weight"], sd["conv_second.bias"])
         pc("upconv1", shuffle2=True)
@@ -338,14 +358,15 @@ class CVSR_V8(nn.Module):
 
     def _rdab(self, w, du0, x, noises):
         """LLongRangAttention (arch.py:2179-2249) on a GROUP of neighbour frames at once: du0 / x are [G*B,H,W,64] (neighbour
-        major; du0 = relu(conv_du_re.0(res)) of the module's residual-map input, computed by the stem kernel), `noises` one
+        major; du0 = relu(conv_du_re.0(res)) of the module's residual-map input in space-to-depth form, computed by the stem
+        kernel), `noises` one
         entry per neighbour -- the module's weights are shared by all neighbours, only the noise draw (and with it the mask
         kernel's launch) is per neighbour."""
         raw = w["raw"]
         GB, H, W, _ = x.shape
         G = len(noises)
         B = GB // G
-        t = self._conv(du0, w["RDAB.conv_du_re.2"], stride=2, pad=2, act=K.ACT_RELU)
+        t = self._conv(du0, w["RDAB.conv_du_re.2_s2d"], pad=1, act=K.ACT_RELU, exact=True)     # [GB, H/2+1, W/2+1, 64]
         part, n = K.chan_sum_partial(t)
         vmax = K.vec_mlp(part, n, t.shape[1] * t.shape[2], raw["RDAB.conv_du_re2.0.weight"],
                          raw["RDAB.conv_du_re2.0.bias"], 64, K.ACT_RELU)
@@ -600,14 +621,17 @@ class CVSR_V8(nn.Module):
         G = len(idxs)
         GB = G * B
         feaG = Lf[idxs[0]:idxs[0] + G].view(GB, H, W, NF)
-        ufs_prior, du0, fea_com = (K.empty_act(GB, H, W, NF, x_dev) for _ in range(3))
+        ufs_prior, fea_com = (K.empty_act(GB, H, W, NF, x_dev) for _ in range(2))
+        du0 = K.empty_act(GB, H // 2 + 1, W // 2 + 1, 4 * NF, x_dev)       # space-to-depth, + one zero row / column
+        du0[:, H // 2].zero_()
+        du0[:, :, W // 2].zero_()
         noises = []
         for n, i in enumerate(idxs):
             sl = slice(n * B, (n + 1) * B)
             K.stem_conv(ufs[:, 0, i], N * P, B, H, W, raw["conv_expand_ufs.weight"], raw["conv_expand_ufs.bias"], out=ufs_prior[sl])
             # fea_com = fea_i + rms_prior and du0 = relu(conv_du_re.0(rms_prior)) from the residual map itself
             K.stem_conv2(rms[:, 0, i], N * P, B, H, W, raw["conv_expand_rms.weight"], raw["conv_expand_rms.bias"], Lf[i],
-                         fea_com[sl], w["rms_du0"][0], w["rms_du0"][1], K.ACT_RELU, du0[sl])
+                         fea_com[sl], w["rms_du0"][0], w["rms_du0"][1], K.ACT_RELU, du0[sl], s2dB=True)
             draw = draw0 + n
             if noise is None:
                 # the reference's default (torch.rand_like per call, arch.py:2169): the draws are generated INSIDE rdab_prep

@@ -408,14 +408,17 @@ def stem_conv(img: torch.Tensor, img_bstride: int, B: int, H: int, W: int, w: to
 
 
 def stem_conv2(img: torch.Tensor, img_bstride: int, B: int, H: int, W: int, wA: torch.Tensor, bA: torch.Tensor,
-               add: torch.Tensor, outA: torch.Tensor, wB: torch.Tensor, bB: torch.Tensor, actB: int, outB: torch.Tensor):
-    """outA = conv3x3(img; wA, bA) + add, outB = actB(conv3x3(img; wB, bB)); img as in stem_conv, outA / outB dense [B,H,W,64]."""
+               add: torch.Tensor, outA: torch.Tensor, wB: torch.Tensor, bB: torch.Tensor, actB: int, outB: torch.Tensor,
+               s2dB: bool = False):
+    """outA = conv3x3(img; wA, bA) + add, outB = actB(conv3x3(img; wB, bB)); img as in stem_conv, outA dense [B,H,W,64]; outB
+    dense [B,H,W,64], or with s2dB a dense [B,H/2+1,W/2+1,256] space-to-depth tensor whose last row / column the caller zeroes."""
     _, _, _, _, lda = _chk_act(add, "add")
-    for o in (outA, outB):
-        if tuple(o.shape) != (B, H, W, 64) or not o.is_contiguous():
-            raise ValueError("stem_conv2: outputs must be dense [B,H,W,64] tensors")
+    shapeB = (B, H // 2 + 1, W // 2 + 1, 256) if s2dB else (B, H, W, 64)
+    if tuple(outA.shape) != (B, H, W, 64) or not outA.is_contiguous() or tuple(outB.shape) != shapeB or not outB.is_contiguous():
+        raise ValueError("stem_conv2: outputs must be dense tensors of the documented shapes")
     check(_lib.lib().cdfo_stem_conv2(_vp(img), C.c_longlong(img_bstride), _vp(wA), _vp(bA), _vp(add), lda, _vp(outA), 64,
-                                     _vp(wB), _vp(bB), actB, _vp(outB), 64, B, H, W, _stream()), "cdfo_stem_conv2")
+                                     _vp(wB), _vp(bB), actB, _vp(outB), shapeB[3], int(s2dB), B, H, W, _stream()),
+          "cdfo_stem_conv2")
 
 
 def pack_udsa_head(w0: torch.Tensor, b0: torch.Tensor, w2: torch.Tensor, b2: torch.Tensor):

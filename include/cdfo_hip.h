@@ -135,10 +135,12 @@ int cdfo_stem_conv(const float* img, long long img_bstride, const float* w, cons
                    int act, float* out, int ldo, const float* add, int lda, float* out2, int ldo2, void* stream);
 /* two 1 -> 64 3x3 convolutions of the same plane in one pass: outA = conv(img; wA, bA) + add, outB = actB(conv(img; wB, bB))
  * (fea_com = fea_i + conv_expand_rms(rms), arch.py:4446-4449, and relu(conv_du_re.0(conv_expand_rms(rms))), arch.py:2148-2152,
- * 2200, with the 1x1 conv_du_re.0 composed into wB / bB by the caller: `rms_prior` is never written). */
+ * 2200, with the 1x1 conv_du_re.0 composed into wB / bB by the caller: `rms_prior` is never written).  s2dB != 0: outB in
+ * space-to-depth form [B][H/2 + 1][W/2 + 1][4 * 64] (phase-major channels; last row / column = the caller's zeros), over which
+ * the stride-2 conv_du_re.2 is a stride-1 convolution with a 2x2 tap window. */
 int cdfo_stem_conv2(const float* img, long long img_bstride, const float* wA, const float* bA, const float* add, int lda,
-                    float* outA, int ldoA, const float* wB, const float* bB, int actB, float* outB, int ldoB, int B, int H, int W,
-                    void* stream);
+                    float* outA, int ldoA, const float* wB, const float* bB, int actB, float* outB, int ldoB, int s2dB, int B,
+                    int H, int W, void* stream);
 /* per-pixel LayerNorm over 64 channels (arch.py:1169-1198). */
 int cdfo_layernorm64(const float* in, int ldi, const float* gamma, const float* beta, long long npix, float* out,
                      int ldo, void* stream);

@@ -17,10 +17,14 @@ namespace {
 constexpr int BP_THREADS = 512;
 constexpr int BP_TR = 6, BP_TC = 30;
 constexpr int BP_W_BYTES = 2 * 4 * 2 * 128 * 16;          // [hi|lo][k-step][k-half][128 cout: up.0 | down.0][8 bf16] = 32,768
-constexpr int BP_YP = 68;
-constexpr int BP_Y_BYTES = 8 * 32 * BP_YP * 4;            // 69,632
+// the resampling tile holds 32 channels at a time (four passes: up.0 | down.0 x two halves): 32 KB, so that TWO workgroups
+// fit a CU (65.5 KB each) and one's resampling / store phase overlaps the other's MFMA phase -- with one 103 KB workgroup per
+// CU the phases ran back to back at half the HBM rate.  Pitch 32 floats: a pixel's 8 channel quads are 128 contiguous bytes,
+// consecutive pixels alternate between the two halves of the 64 banks = conflict-free ds_read_b128
+constexpr int BP_YP = 32;
+constexpr int BP_Y_BYTES = 8 * 32 * BP_YP * 4;            // 32,768
 constexpr int BP_BIAS_OFF = BP_W_BYTES + BP_Y_BYTES;
-constexpr int BP_LDS = BP_BIAS_OFF + 128 * 4;             // 102,912 bytes
+constexpr int BP_LDS = BP_BIAS_OFF + 128 * 4;             // 66,048 bytes
 
 typedef __bf16 bp_bf16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 bp_f16x4 __attribute__((ext_vector_type(4)));
@@ -36,7 +40,7 @@ struct bp_args {
   _Float16* x16;                // optional [B][4][H][W][16]: fp16 chunk-planar copy of x itself (the 1x branch's source)
 };
 
-__global__ __launch_bounds__(BP_THREADS) void block_pro_kernel(bp_args a) {
+__global__ __launch_bounds__(BP_THREADS, 4) void block_pro_kernel(bp_args a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   float* sY = reinterpret_cast<float*>(smem + BP_W_BYTES);
   float* sBias = reinterpret_cast<float*>(smem + BP_BIAS_OFF);
@@ -100,9 +104,9 @@ __global__ __launch_bounds__(BP_THREADS) void block_pro_kernel(bp_args a) {
     if (tn < ntiles) load_x(tn);
 
 #pragma unroll 1
-    for (int nb = 0; nb < 2; ++nb) {        // 0: y = up.0(x) -> bilinear x2;  1: z = down.0(x) -> 2x2 mean
-#pragma unroll
-      for (int nt = 0; nt < 2; ++nt) {
+    for (int pass = 0; pass < 4; ++pass) {  // (nb, nt): nb 0: y = up.0(x) -> bilinear x2;  1: z = down.0(x) -> 2x2 mean; nt: 32-channel half
+      const int nb = pass >> 1, nt = pass & 1;
+      {
         f32x16 acc;
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[e] = 0.f;
@@ -118,16 +122,17 @@ __global__ __launch_bounds__(BP_THREADS) void block_pro_kernel(bp_args a) {
         const float bn = sBias[n];
 #pragma unroll
         for (int e = 0; e < 16; ++e)
-          sY[(wave * 32 + (e & 3) + 8 * (e >> 2) + 4 * h) * BP_YP + nt * 32 + r] = acc[e] + bn;
+          sY[(wave * 32 + (e & 3) + 8 * (e >> 2) + 4 * h) * BP_YP + r] = acc[e] + bn;
       }
       __syncthreads();
       if (nb == 0) {
-        // bilinear x2: thread = 4 channels (q) of the 2x2 output block (2Q-1..2Q, 2P-1..2P) fed by source rows Q-1..Q,
-        // columns P-1..P (halo-local rows qq..qq+1, columns pp..pp+1; the clamped replicas are already in the tile).
-        // 7 x 31 blocks cover the tile's 12 x 60 outputs (+ the shared edge with the neighbouring tiles, written by
+        // bilinear x2: thread = 4 channels (quad q of this half) of the 2x2 output block (2Q-1..2Q, 2P-1..2P) fed by source
+        // rows Q-1..Q, columns P-1..P (halo-local rows qq..qq+1, columns pp..pp+1; the clamped replicas are already in the
+        // tile).  7 x 31 blocks cover the tile's 12 x 60 outputs (+ the shared edge with the neighbouring tiles, written by
         // whichever tile owns the output pixel).
-        for (int i = tid; i < 7 * 31 * 16; i += BP_THREADS) {
-          const int q = i & 15, pp = (i >> 4) % 31, qq = (i >> 4) / 31;
+        for (int i = tid; i < 7 * 31 * 8; i += BP_THREADS) {
+          const int q = i & 7, pp = (i >> 3) % 31, qq = (i >> 3) / 31;
+          const int cq = nt * 8 + q;                      // channel quad of the 64
           const f32x4 vaa = *reinterpret_cast<const f32x4*>(sY + (qq * 32 + pp) * BP_YP + q * 4);
           const f32x4 vab = *reinterpret_cast<const f32x4*>(sY + (qq * 32 + pp + 1) * BP_YP + q * 4);
           const f32x4 vba = *reinterpret_cast<const f32x4*>(sY + ((qq + 1) * 32 + pp) * BP_YP + q * 4);
@@ -148,14 +153,15 @@ __global__ __launch_bounds__(BP_THREADS) void block_pro_kernel(bp_args a) {
               bp_f16x4 hv;
 #pragma unroll
               for (int k = 0; k < 4; ++k) hv[k] = (_Float16)v[k];
-              *reinterpret_cast<bp_f16x4*>(a.u16 + ((((long long)b * 4 + (q >> 2)) * Ho + Y) * Wo + X) * 16 + (q & 3) * 4) = hv;
+              *reinterpret_cast<bp_f16x4*>(a.u16 + ((((long long)b * 4 + (cq >> 2)) * Ho + Y) * Wo + X) * 16 + (cq & 3) * 4) = hv;
             }
           }
         }
       } else {
         // 2x2 mean: 3 x 15 half-resolution pixels per tile (tile origin is even in both directions)
-        for (int i = tid; i < 3 * 15 * 16; i += BP_THREADS) {
-          const int q = i & 15, px = (i >> 4) % 15, py = (i >> 4) / 15;
+        for (int i = tid; i < 3 * 15 * 8; i += BP_THREADS) {
+          const int q = i & 7, px = (i >> 3) % 15, py = (i >> 3) / 15;
+          const int cq = nt * 8 + q;
           const int yd = (oy0 >> 1) + py, xd = (ox0 >> 1) + px;
           if (yd >= Hd || xd >= Wd) continue;
           const float* p0 = sY + ((1 + 2 * py) * 32 + 1 + 2 * px) * BP_YP + q * 4;      // halo offset 1
@@ -165,7 +171,7 @@ __global__ __launch_bounds__(BP_THREADS) void block_pro_kernel(bp_args a) {
           bp_f16x4 hv;
 #pragma unroll
           for (int k = 0; k < 4; ++k) hv[k] = (_Float16)v[k];
-          *reinterpret_cast<bp_f16x4*>(a.d16 + ((((long long)b * 4 + (q >> 2)) * Hd + yd) * Wd + xd) * 16 + (q & 3) * 4) = hv;
+          *reinterpret_cast<bp_f16x4*>(a.d16 + ((((long long)b * 4 + (cq >> 2)) * Hd + yd) * Wd + xd) * 16 + (cq & 3) * 4) = hv;
         }
       }
       __syncthreads();
@@ -187,7 +193,7 @@ extern "C" int cdfo_block_prologue(const float* x, int ldx, int B, int H, int W,
   const int cus = cdfo_num_cus();
   if (cus <= 0) return CDFO_EINVAL;
   const long long ntiles = (long long)B * cdiv(H, BP_TR) * cdiv(W, BP_TC);
-  const int grid = (int)(ntiles < cus ? ntiles : cus);
+  const int grid = (int)(ntiles < 2 * cus ? ntiles : 2 * cus);      // two workgroups per CU (LDS 2 x 65.5 KB, 120 VGPRs)
   bp_args a;
   a.x = x; a.ldx = ldx; a.B = B; a.H = H; a.W = W;
   a.w = static_cast<const unsigned short*>(w_bf16); a.bias = bias128;

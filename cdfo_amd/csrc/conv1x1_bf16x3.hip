@@ -263,12 +263,19 @@ __global__ __launch_bounds__(256, 2) void conv1x1_bf16x3_kernel(cdfo_conv_args a
 
 // conv1x1_stream.hip: the persistent LDS-DMA streaming form (plain store, CoutP <= 128, weights + rings within LDS)
 int cdfo_conv1x1_stream_try(const cdfo_conv_args& a, hipStream_t st);
+extern "C" int cdfo_layernorm64_cp16hl(const float* in, int ldi, const float* gamma, const float* beta, int B, long long P,
+                                       void* out, void* stream);
 
 extern "C" int cdfo_conv1x1_bf16x3(const cdfo_conv_args* pa, void* stream) {
   const cdfo_conv_args& a = *pa;
   hipStream_t st = static_cast<hipStream_t>(stream);
   if (a.nsrc < 1 || a.nsrc > CDFO_MAXSRC || a.B <= 0 || a.ks != 1 || a.stride != 1 || a.pad != 0) return CDFO_EINVAL;
-  if (a.act == CDFO_ACT_SIGMOID || a.tap_mask || a.src_f16 || a.out_f16 || a.out2_cp16 || a.res_up2 || a.src_plane_wrap) return CDFO_EINVAL;
+  if (a.act == CDFO_ACT_SIGMOID || a.tap_mask || a.src_f16 || a.out_f16 || a.res_up2 || a.src_plane_wrap) return CDFO_EINVAL;
+  // out2_cp16 here = a second output: LayerNorm64 (ln_gamma / ln_beta) of the RESULT as fp16 hi | lo planes [B][8][P][16]
+  const bool ln_out = a.out2_cp16 != nullptr;
+  if (ln_out && (a.Cout != 64 || a.CoutP != 64 || a.store_mode != CDFO_STORE_PLAIN || !a.ln_gamma || !a.ln_beta || a.ldo < 64 ||
+                 !aligned16(a.out2_cp16) || !aligned16(a.ln_gamma) || !aligned16(a.ln_beta)))
+    return CDFO_EINVAL;
   int csum = 0;
   for (int s = 0; s < a.nsrc; ++s) {
     if (a.cs[s] <= 0 || a.cs[s] % 64 || a.ld[s] % 4 || a.ld[s] < a.cs[s]) return CDFO_EINVAL;
@@ -282,8 +289,19 @@ extern "C" int cdfo_conv1x1_bf16x3(const cdfo_conv_args* pa, void* stream) {
   const bool taps = a.store_mode == CDFO_STORE_TAPS9;
   if (!aligned16(a.w) || a.w_bstride % 4 || (!taps && a.ldo % 4) || !aligned16(a.out) || (a.bias && !aligned16(a.bias))) return CDFO_EALIGN;
   if ((a.res1 && (a.ldr1 % 4 || !aligned16(a.res1))) || (!taps && a.res2 && (a.ldr2 % 4 || !aligned16(a.res2)))) return CDFO_EALIGN;
-  if (a.ln_gamma && !(a.nsrc == 1 && a.cs[0] == 64 && a.ln_beta && aligned16(a.ln_gamma) && aligned16(a.ln_beta))) return CDFO_EINVAL;
+  if (!ln_out && a.ln_gamma && !(a.nsrc == 1 && a.cs[0] == 64 && a.ln_beta && aligned16(a.ln_gamma) && aligned16(a.ln_beta))) return CDFO_EINVAL;
   const long long P = (long long)a.H * a.W;
+  if (ln_out) {
+    // the streaming kernel normalises in its epilogue; outside its contract: the convolution, then a LayerNorm pass
+    const int r = cdfo_conv1x1_stream_try(a, st);
+    if (r == 1) return 0;
+    if (r != 0) return r;
+    cdfo_conv_args plain = a;
+    plain.out2_cp16 = nullptr; plain.ln_gamma = nullptr; plain.ln_beta = nullptr;
+    const int rc = cdfo_conv1x1_bf16x3(&plain, stream);
+    if (rc) return rc;
+    return cdfo_layernorm64_cp16hl(a.out, a.ldo, a.ln_gamma, a.ln_beta, a.B, P, a.out2_cp16, stream);
+  }
   {
     static const bool use_stream = [] { const char* e = getenv("CDFO_CONV1X1_STREAM"); return !(e && e[0] == '0'); }();   // developer A/B switch
     if (use_stream && !taps) {

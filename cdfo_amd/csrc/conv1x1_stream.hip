@@ -45,6 +45,10 @@ struct st_args {
   int B; long long P;              // pixels per image
   int tiles_per_image; long long tiles;
   int ns;                          // ring stages per wave
+  // optional second output (Cout == 64): LayerNorm64(result) as fp16 hi | lo chunk-planar planes [B][8][P][16] -- the source of
+  // the split-fp16 3x3 convolution that follows the attention in the feature extractor (arch.py:1470-1474): the values are in
+  // the epilogue's registers, a separate LayerNorm pass would read the 64-channel result back from HBM
+  _Float16* ln_hl; const float* ln_g; const float* ln_b;
 };
 
 __device__ __forceinline__ unsigned st_pack_bf16(float a, float b) {
@@ -259,6 +263,44 @@ __global__ __launch_bounds__(ST_THREADS) void conv1x1_stream_kernel(st_args a) {
         // ---- store: 32 contiguous bytes per lane and 16-channel group
         const long long tile = img_t0 + it / items_per_tile;
         const long long pin = (tile - (long long)b * a.tiles_per_image) * 128 + wave * 32 + r;
+        if (NCB == 1 && a.ln_hl) {
+          // per-pixel LayerNorm over the 64 channels this lane (32 of them) and lane ^ 32 hold; biased variance, eps 1e-5
+          typedef _Float16 st_f16x8 __attribute__((ext_vector_type(8)));
+          float sm = 0.f;
+#pragma unroll
+          for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) sm += acc[0][ni][e];
+          sm += __shfl_xor(sm, 32, 64);
+          const float mu = sm * (1.f / 64.f);
+          float sq = 0.f;
+#pragma unroll
+          for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) { const float d = acc[0][ni][e] - mu; sq = fmaf(d, d, sq); }
+          sq += __shfl_xor(sq, 32, 64);
+          const float rstd = 1.f / sqrtf(sq * (1.f / 64.f) + 1e-5f);
+          if (pin < a.P) {
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+              for (int jj = 0; jj < 2; ++jj) {
+                const int n = ni * 32 + jj * 16 + h * 8;               // 8 consecutive channels = half of chunk n >> 4
+                const f32x4 g0 = *reinterpret_cast<const f32x4*>(a.ln_g + n), g1 = *reinterpret_cast<const f32x4*>(a.ln_g + n + 4);
+                const f32x4 b0 = *reinterpret_cast<const f32x4*>(a.ln_b + n), b1 = *reinterpret_cast<const f32x4*>(a.ln_b + n + 4);
+                st_f16x8 hi, lo;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                  const float y = (acc[0][ni][8 * jj + e] - mu) * rstd * (e < 4 ? g0[e & 3] : g1[e & 3]) + (e < 4 ? b0[e & 3] : b1[e & 3]);
+                  hi[e] = (_Float16)y;
+                  lo[e] = (_Float16)(y - (float)hi[e]);
+                }
+                _Float16* o16 = a.ln_hl + (((long long)b * 8 + (n >> 4)) * a.P + pin) * 16 + h * 8;
+                *reinterpret_cast<st_f16x8*>(o16) = hi;
+                *reinterpret_cast<st_f16x8*>(o16 + 4 * a.P * 16) = lo;
+              }
+          }
+        }
         if (pin < a.P) {
           float* op = a.out + ((long long)b * a.P + pin) * a.ldo;
 #pragma unroll
@@ -288,7 +330,9 @@ __global__ __launch_bounds__(ST_THREADS) void conv1x1_stream_kernel(st_args a) {
 // Returns 1 when the streaming kernel took the launch, 0 when the shapes are outside its contract (the caller falls back to
 // cdfo_conv1x1_bf16x3), < 0 / hipError_t on errors.  Same argument block as cdfo_conv1x1_bf16x3.
 int cdfo_conv1x1_stream_try(const cdfo_conv_args& a, hipStream_t st) {
-  if (a.store_mode != CDFO_STORE_PLAIN || a.ln_gamma || a.CoutP % 64 || a.CoutP > 128 || a.Cout % 8) return 0;
+  const bool ln_out = a.out2_cp16 != nullptr;      // post-LayerNorm hi | lo second output (checked by the caller: Cout == 64)
+  if (a.store_mode != CDFO_STORE_PLAIN || (a.ln_gamma && !ln_out) || a.CoutP % 64 || a.CoutP > 128 || a.Cout % 8) return 0;
+  if (ln_out && (a.CoutP != 64 || a.Cout != 64)) return 0;
   const int ncb = a.CoutP / 64, nkb = a.Cin / 64;
   if (nkb < 1 || nkb > CDFO_MAXSRC * 4) return 0;
   const int w_bytes = 2 * nkb * 4 * 2 * ncb * 64 * 16 + ncb * 64 * 4;
@@ -312,6 +356,7 @@ int cdfo_conv1x1_stream_try(const cdfo_conv_args& a, hipStream_t st) {
   s.w = a.w; s.w_bstride = a.w_bstride; s.bias = a.bias;
   s.Cin = a.Cin; s.Cout = a.Cout; s.CoutP = a.CoutP; s.act_fn = a.act;
   s.out = a.out; s.ldo = a.ldo; s.B = a.B; s.P = P;
+  s.ln_hl = ln_out ? static_cast<_Float16*>(a.out2_cp16) : nullptr; s.ln_g = a.ln_gamma; s.ln_b = a.ln_beta;
   s.tiles_per_image = (int)((P + 127) / 128);
   s.tiles = (long long)a.B * s.tiles_per_image;
   s.ns = ns;

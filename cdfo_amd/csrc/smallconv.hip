@@ -22,13 +22,29 @@ __global__ __launch_bounds__(256) void small_conv3x3_kernel(const float* __restr
   __syncthreads();
   constexpr int CGS = COUT / 4;
   const long long total = (long long)B * Ho * Wo * CGS;
+  // A stride-2 transposed convolution reaches an output pixel through the taps whose parity matches its own (1, 2 or 4 of the
+  // 9): pixels are enumerated phase by phase ((oy & 1, ox & 1) major) so that a wave's 16 pixels share their tap set and the
+  // `continue`s below are wave-uniform -- in raster order every wave walked all nine taps under partial masks (4x the work)
+  const bool phase_major = TRANSPOSED && stride == 2 && !(Ho & 1) && !(Wo & 1);
+  const int Wq = Wo >> 1;
+  const long long quarter = (long long)(Ho >> 1) * Wq;
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
        i += (long long)gridDim.x * blockDim.x) {
     const int cg = i % CGS;
-    const long long p = i / CGS;
-    const int ox = p % Wo;
-    const int oy = (p / Wo) % Ho;
+    long long p = i / CGS;
+    int ox, oy;
     const long long b = p / ((long long)Wo * Ho);
+    if (phase_major) {
+      const long long rr = p - b * (long long)Wo * Ho;
+      const int ph = (int)(rr / quarter);
+      const long long cell = rr - ph * quarter;
+      oy = 2 * (int)(cell / Wq) + (ph >> 1);
+      ox = 2 * (int)(cell % Wq) + (ph & 1);
+      p = (b * Ho + oy) * Wo + ox;
+    } else {
+      ox = p % Wo;
+      oy = (p / Wo) % Ho;
+    }
     f32x4 acc = bias ? *reinterpret_cast<const f32x4*>(bias + cg * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int ky = 0; ky < 3; ++ky) {

@@ -341,7 +341,10 @@ class CVSR_V8(nn.Module):
                 # q and k never reach HBM, only v and 640 sums per frame
                 v, part, n = K.qkv_dw(x1, w[p + "qkv_dw"], raw[p + "attn.qkv_dwconv.weight"], gram=True)
                 fold = K.mdta_fold(part, n, raw[p + "attn.temperature"], raw[p + "attn.project_out.weight"])
-                x1 = self._conv(v, fold, res1=x1)
+                if self.precision == "fp16x2":      # norm2 of the result leaves the same kernel as fp16 hi | lo planes
+                    x1, ln = self._conv(v, fold, res1=x1, ln_out=(raw[p + "norm2.body.weight"], raw[p + "norm2.body.bias"]))
+                else:
+                    x1 = self._conv(v, fold, res1=x1)
             if self.precision == "f32":
                 part, n = K.gram_partial(qkv[..., 0:64], qkv[..., 64:128], 8)
                 fold = K.mdta_fold(part, n, raw[p + "attn.temperature"], raw[p + "attn.project_out.weight"])
@@ -349,7 +352,6 @@ class CVSR_V8(nn.Module):
             if self.precision == "fp16x2":
                 # LayerNorm written as fp16 hi | lo planes; the 3x3 conv as a split-fp16 product (a_hi*w_hi + a_lo*w_hi +
                 # a_hi*w_lo, 22-bit operands: fp32-grade like the split-bf16 path it replaces) on the ring kernel
-                ln = K.layernorm64_hl(x1, raw[p + "norm2.body.weight"], raw[p + "norm2.body.bias"])
                 x1 = K.conv_ring(ln, w[p + "conv_hl"], res1=x1, res2=x2, plane_wrap=8)
             else:
                 ln = K.layernorm64(x1, raw[p + "norm2.body.weight"], raw[p + "norm2.body.bias"])

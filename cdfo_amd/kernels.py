@@ -138,7 +138,9 @@ def pack_conv(weight: torch.Tensor, bias: Optional[torch.Tensor], shuffle2: bool
 def conv(srcs: Sequence[torch.Tensor], pc: PackedConv, *, stride: int = 1, pad: int = 0, act: int = ACT_NONE,
          res1: Optional[torch.Tensor] = None, res2: Optional[torch.Tensor] = None,
          out: Optional[torch.Tensor] = None, prec: int = PREC_F32,
-         ln: Optional[tuple] = None, s2d: bool = False, out_f16: bool = False) -> torch.Tensor:
+         ln: Optional[tuple] = None, s2d: bool = False, out_f16: bool = False, ln_out: Optional[tuple] = None):
+    """ln_out = (gamma, beta) (1x1, Cout = 64, 16-bit modes): also LayerNorm64 of the RESULT as fp16 hi | lo planes
+    [B,8,H,W,16] (layernorm64_hl of the returned tensor); the call then returns the pair (out, planes)."""
     if isinstance(srcs, torch.Tensor):
         srcs = [srcs]
     a = ConvArgs()
@@ -208,9 +210,17 @@ def conv(srcs: Sequence[torch.Tensor], pc: PackedConv, *, stride: int = 1, pad: 
         a.ln_gamma, a.ln_beta = ln[0].data_ptr(), ln[1].data_ptr()
     if (prec != PREC_F32 and pc.ks == 1 and stride == 1 and pad == 0 and pc.CoutP % 64 == 0 and pc.CoutP <= 256
             and all(s.shape[3] % 64 == 0 for s in srcs)):
+        planes = None
+        if ln_out is not None and pc.Cout == 64 and pc.CoutP == 64 and ln is None:
+            planes = torch.empty((B, 8, Ho, Wo, 16), dtype=torch.float16, device=out.device)
+            a.out2_cp16, a.ln_gamma, a.ln_beta = planes.data_ptr(), ln_out[0].data_ptr(), ln_out[1].data_ptr()
         check(_lib.lib().cdfo_conv1x1_bf16x3(C.byref(a), _stream()), "cdfo_conv1x1_bf16x3")
+        if ln_out is not None:
+            return out, (planes if planes is not None else layernorm64_hl(out, ln_out[0], ln_out[1]))
         return out
     check(_lib.lib().cdfo_conv_igemm(C.byref(a), _stream()), "cdfo_conv_igemm")
+    if ln_out is not None:
+        return out, layernorm64_hl(out, ln_out[0], ln_out[1])
     return out
 
 

@@ -558,3 +558,24 @@ def test_stem_conv2_is_two_stencils_of_one_plane():
     refB = F.relu(F.conv2d(img, wB, bB, padding=1)).permute(0, 2, 3, 1)
     assert (outA.cpu() - refA).abs().max().item() <= 1e-5
     assert (outB.cpu() - refB).abs().max().item() <= 1e-5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,H,W", [(2, 16, 24), (3, 9, 50)])
+def test_conv1x1_with_layernorm_planes_of_the_result(B, H, W):
+    """conv(..., ln_out=(gamma, beta)): the 1x1 result plus LayerNorm64 of it as fp16 hi | lo planes (streaming kernel's
+    epilogue), against the two separate kernels."""
+    from cdfo_amd import kernels as K
+    g = torch.Generator(device="cuda").manual_seed(B * 10 + H)
+    x = torch.randn(B, H, W, 64, device="cuda", generator=g)
+    res = torch.randn(B, H, W, 64, device="cuda", generator=g)
+    gamma, beta = torch.rand(64, device="cuda", generator=g) + 0.5, torch.randn(64, device="cuda", generator=g) * 0.2
+    pc = K.pack_conv(torch.randn(64, 64, 1, 1, device="cuda", generator=g) / 8, torch.randn(64, device="cuda", generator=g))
+    out, planes = K.conv([x], pc, res1=res, prec=K.PREC_BF16X3, ln_out=(gamma, beta))
+    ref = K.conv([x], pc, res1=res, prec=K.PREC_BF16X3)
+    assert torch.equal(out, ref)
+    ref_planes = K.layernorm64_hl(ref, gamma, beta)
+    hl = planes.float()[:, 0:4] + planes.float()[:, 4:8]
+    ref_hl = ref_planes.float()[:, 0:4] + ref_planes.float()[:, 4:8]
+    assert (hl - ref_hl).abs().max().item() <= 2e-5
+    assert (planes[:, 0:4].float() - ref_planes[:, 0:4].float()).abs().max().item() <= 4e-3      # hi halves: within an fp16 ulp

@@ -91,7 +91,13 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
   const int ROWB = a.S * 32 + 16;                                   // bytes per pixel row of the B-operand images
   char* col_hi = smem;
   char* col_lo = smem + 64 * ROWB;
-  const int b = blockIdx.y, p0 = blockIdx.x * 64;
+  // Workgroups go round-robin to the 8 XCDs (private 4 MB L2s): each XCD walks its own contiguous band of tiles, so that the
+  // ~64 tiles it has in flight (8.5 image rows at W = 480) gather from ~20 rows of the group-planar copy (2.4 MB) instead of
+  // from the whole image (33 MB): the corner gathers then hit L2 (r1 counters: 0.95 GB per launch re-fetched past it)
+  const int band = gridDim.x >> 3;                                   // gridDim.x is a multiple of 8
+  const int tile = (blockIdx.x & 7) * band + (blockIdx.x >> 3);
+  const int b = blockIdx.y, p0 = tile * 64;
+  if (p0 >= P) return;                                               // (whole workgroup)
   if (tid < T) {
     const int ki = tid / a.kw, kj = tid - ki * a.kw;
     tabh[tid] = (float)(ki * a.dh);
@@ -342,7 +348,7 @@ int cdfo_dcn_forward_fast(const float* in, const float* offset, const float* mas
   FastArgs a{gp, offset, mask, bias, out, reinterpret_cast<const h8*>(whi), reinterpret_cast<const h8*>(wlo), scale,
              B, C, H, W, Co, Ho, Wo, kh, kw, sh, sw, ph, pw, dh, dw, dg, CCH, nchunks, S};
   static CdfoAttrGrow grow1, grow2;
-  dim3 grid(cdiv(Ho * Wo, 64), B);
+  dim3 grid(8 * cdiv(cdiv(Ho * Wo, 64), 8), B);
   if (MT <= 2) {
     if (cdfo_grow_max_lds(grow1, reinterpret_cast<const void*>(&dcn_fast_kernel<1>), (int)lds) != hipSuccess) return 2 + (int)hipErrorInvalidValue;
     hipLaunchKernelGGL(dcn_fast_kernel<1>, grid, dim3(512), lds, st, a);

@@ -380,52 +380,69 @@ __global__ __launch_bounds__(NW * 64) void seq_attn_mfma_kernel(const float* __r
     const int buf = t & 1;
     if (t + 1 < nstages) load_tile((t + 1) * KT);
     if (wave_active) {
+      // The stage's SUB sub-tiles of 32 keys share ONE softmax update: all their score products first (independent
+      // accumulators, back to back on the matrix pipe), one running-maximum step for the 64 keys, then all the V^T P^T products
+      // -- half the rescale tests and longer MFMA runs for the vector work of the SIMD's other wave to hide behind
+      const int kv_stage = L - t * KT;                      // keys of this stage that exist (> 0)
+      const int nsub = kv_stage >= KT ? SUB : (kv_stage + 31) >> 5;
+      f32x16 sacc[SUB];
 #pragma unroll
       for (int sub = 0; sub < SUB; ++sub) {
-        const int kv_left = L - (t * KT + sub * 32);        // keys of this sub-tile that exist (>= 32: all)
-        if (kv_left <= 0) break;
+        if (sub >= nsub) break;
         // ---- S^T = K Q^T (log2 domain)
-        f32x16 sacc;
 #pragma unroll
-        for (int e = 0; e < 16; ++e) sacc[e] = 0.f;
+        for (int e = 0; e < 16; ++e) sacc[sub][e] = 0.f;
         const unsigned char* const kb = sK + buf * K_BYTES + (sub * 32 + r) * KROW + 16 * h;
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
           const attn_f16x8 kh = *reinterpret_cast<const attn_f16x8*>(kb + 32 * s);
           const attn_f16x8 kl = *reinterpret_cast<const attn_f16x8*>(kb + 32 * s + 128);
-          sacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl, qh[s], sacc, 0, 0, 0);
-          sacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, ql[s], sacc, 0, 0, 0);
-          sacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, qh[s], sacc, 0, 0, 0);
+          sacc[sub] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl, qh[s], sacc[sub], 0, 0, 0);
+          sacc[sub] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, ql[s], sacc[sub], 0, 0, 0);
+          sacc[sub] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, qh[s], sacc[sub], 0, 0, 0);
         }
-        // ---- online softmax over this sub-tile's 32 keys (16 here, 16 in the partner half-wave)
+      }
+      // ---- online softmax over the stage's keys (per sub-tile 16 here, 16 in the partner half-wave)
+      float tmax = -INFINITY;
+#pragma unroll
+      for (int sub = 0; sub < SUB; ++sub) {
+        if (sub >= nsub) break;
+        const int kv_left = kv_stage - sub * 32;
         if (kv_left < 32) {                                 // only a sequence's last sub-tile has keys to mask
 #pragma unroll
           for (int e = 0; e < 16; ++e)
-            if ((e & 3) + 8 * (e >> 2) + 4 * h >= kv_left) sacc[e] = -INFINITY;
+            if ((e & 3) + 8 * (e >> 2) + 4 * h >= kv_left) sacc[sub][e] = -INFINITY;
         }
-        float tmax = sacc[0];
 #pragma unroll
-        for (int e = 1; e < 16; ++e) tmax = fmaxf(tmax, sacc[e]);
-        tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
-        const float mn = fmaxf(m, tmax);
-        if (__any(mn > m)) {                                // some lane's running maximum moved: rescale
-          const float alpha = __builtin_amdgcn_exp2f(m - mn);
-          l *= alpha;
+        for (int e = 0; e < 16; ++e) tmax = fmaxf(tmax, sacc[sub][e]);
+      }
+      tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+      const float mn = fmaxf(m, tmax);
+      if (__any(mn > m)) {                                  // some lane's running maximum moved: rescale
+        const float alpha = __builtin_amdgcn_exp2f(m - mn);
+        l *= alpha;
 #pragma unroll
-          for (int e = 0; e < 16; ++e) { o0[e] *= alpha; o1[e] *= alpha; }
-          m = mn;
-        }
-        float psum = 0.f;
+        for (int e = 0; e < 16; ++e) { o0[e] *= alpha; o1[e] *= alpha; }
+        m = mn;
+      }
+      float psum = 0.f;
 #pragma unroll
-        for (int e = 0; e < 16; ++e) { sacc[e] = __builtin_amdgcn_exp2f(sacc[e] - m); psum += sacc[e]; }
-        l += psum;
-        // ---- O^T += V^T P^T
+      for (int sub = 0; sub < SUB; ++sub) {
+        if (sub >= nsub) break;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) { sacc[sub][e] = __builtin_amdgcn_exp2f(sacc[sub][e] - m); psum += sacc[sub][e]; }
+      }
+      l += psum;
+      // ---- O^T += V^T P^T
+#pragma unroll
+      for (int sub = 0; sub < SUB; ++sub) {
+        if (sub >= nsub) break;
         const unsigned char* const vb = sV + buf * V_BYTES + sub * 8192;
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
           attn_f16x8 ph, pl;
 #pragma unroll
-          for (int j = 0; j < 8; ++j) { ph[j] = (_Float16)sacc[8 * u + j]; pl[j] = (_Float16)(sacc[8 * u + j] - (float)ph[j]); }
+          for (int j = 0; j < 8; ++j) { ph[j] = (_Float16)sacc[sub][8 * u + j]; pl[j] = (_Float16)(sacc[sub][8 * u + j] - (float)ph[j]); }
 #pragma unroll
           for (int half = 0; half < 2; ++half) {            // channels 0-31 -> o0, 32-63 -> o1
             const int ch = 32 * half + r, swz = (ch >> 1) & 7, c = 2 * u + h;

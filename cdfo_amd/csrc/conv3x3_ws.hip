@@ -227,6 +227,9 @@ __global__ __launch_bounds__(WS_THREADS) void conv3x3_c64_ws_kernel(ws_args a) {
 #pragma unroll
       for (int t = 0; t < 9; ++t) {
         if (t < 8) load_frags(t + 1, (t & 1) ^ 1);
+        // keep the NEXT tap's fragment reads in front of this tap's MFMAs: left to itself hipcc sinks them behind the MFMAs
+        // and reads each weight fragment right before its use (a counted wait on a just-issued ds_read per tap)
+        __builtin_amdgcn_sched_barrier(0);
         if (t == 0) {
           // Next chunk's DMA, into the OTHER ring buffer, whose last readers were the previous chunk's fragment reads.
           // Those must have returned before a DMA piece can land (one that hits in the CU's L1 lands within ~100
@@ -260,6 +263,7 @@ __global__ __launch_bounds__(WS_THREADS) void conv3x3_c64_ws_kernel(ws_args a) {
             if (DBG & 1) acc[ni][mi][0] += (float)fw[par][ni][0] * (float)fp[par][mi][0];
             else acc[ni][mi] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fw[par][ni], fp[par][mi], acc[ni][mi], 0, 0, 0);
           }
+        __builtin_amdgcn_sched_barrier(0);
       }
     }
 

@@ -28,16 +28,21 @@
 // DMA completion is tracked by hand (hipcc does not count inline-asm memory operations) with counted s_waitcnt; the
 // rules are written next to each wait.
 #include "common.h"
+#include <cstdlib>
 
 namespace {
 
-constexpr int WS_THREADS = 512;
 constexpr int WS_W_BYTES = 4 * 9 * 2 * 64 * 16;            // 73,728: [chunk][tap][k-half][64 cout][8 x fp16]
 constexpr int WS_BIAS_OFF = WS_W_BYTES;                    // 64 floats
 constexpr int WS_STG_OFF = WS_W_BYTES + 256;
 constexpr int WS_BUF = 5 * 1024;                           // one 16-channel chunk of a wave's halo: 136 px x 32 B in 5 DMA pieces
-constexpr int WS_CNT_OFF = WS_STG_OFF + 8 * 2 * WS_BUF;    // work counter of the workgroup
-constexpr int WS_LDS = WS_CNT_OFF + 16;                    // 155,920 bytes
+// NW waves per workgroup: 8 (two per SIMD, each with a 2-deep private staging ring) or 12 (three per SIMD, ONE staging
+// buffer each: 12 x 2 x 5 KB would not fit next to the weights)
+template <int NW> struct WsLds {
+  static constexpr int NBUF = NW == 8 ? 2 : 1;
+  static constexpr int CNT_OFF = WS_STG_OFF + NW * NBUF * WS_BUF;    // work counter of the workgroup
+  static constexpr int TOTAL = CNT_OFF + 16;                         // 155,920 bytes (8 waves) / 135,440 (12 waves)
+};
 constexpr int WS_IW = 34, WS_NPIX = 4 * 34;
 
 typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
@@ -86,8 +91,9 @@ __device__ __forceinline__ void ws_dma5(const unsigned (&voff)[5], i32x4 rsrc, u
 // convolution, arch.py:261-262), optionally also the fp16 chunk-planar copy.  The residual values of a tile are fetched
 // by inline-asm loads while its last chunk computes (hipcc would wait for a visible load with vmcnt(0) and so drain the
 // DMA that is in flight behind it) and consumed behind a counted wait.
-template <int DBG, bool RES = false>
-__global__ __launch_bounds__(WS_THREADS) void conv3x3_c64_ws_kernel(ws_args a) {
+template <int DBG, bool RES = false, int NW = 8>
+__global__ __launch_bounds__(NW * 64) void conv3x3_c64_ws_kernel(ws_args a) {
+  constexpr int WS_THREADS = NW * 64, NBUF = WsLds<NW>::NBUF, WS_CNT_OFF = WsLds<NW>::CNT_OFF;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, r = lane & 31;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -112,7 +118,7 @@ __global__ __launch_bounds__(WS_THREADS) void conv3x3_c64_ws_kernel(ws_args a) {
   }
   if (tid < 64) reinterpret_cast<float*>(smem + WS_BIAS_OFF)[tid] = a.bias ? a.bias[n0 + chan_of_row(tid)] : 0.f;
   unsigned* s_next = reinterpret_cast<unsigned*>(smem + WS_CNT_OFF);
-  if (tid == 0) *s_next = 8;                     // tiles 0..7 of the workgroup go to waves 0..7, the rest first come first served
+  if (tid == 0) *s_next = NW;                    // tiles 0..NW-1 of the workgroup go to its waves, the rest first come first served
   __syncthreads();
 
   // ---- per-lane constants
@@ -136,8 +142,8 @@ __global__ __launch_bounds__(WS_THREADS) void conv3x3_c64_ws_kernel(ws_args a) {
       p_off[rr * 3 + dx] = (2 * p + (h ^ ((p >> 3) & 1))) * 16;
     }
   const unsigned char* sWl = smem + (h * 64 + r) * 16;
-  unsigned char* stg = smem + WS_STG_OFF + wave * (2 * WS_BUF);
-  const unsigned stg_lds = (unsigned)(unsigned long long)(smem) + WS_STG_OFF + wave * (2 * WS_BUF);
+  unsigned char* stg = smem + WS_STG_OFF + wave * (NBUF * WS_BUF);
+  const unsigned stg_lds = (unsigned)(unsigned long long)(smem) + WS_STG_OFF + wave * (NBUF * WS_BUF);
 
   i32x4 rsrc;
   {
@@ -213,7 +219,7 @@ __global__ __launch_bounds__(WS_THREADS) void conv3x3_c64_ws_kernel(ws_args a) {
       // behind 16 residual loads + 5 DMA pieces returned before the older residual loads had landed -- so counted waits
       // here only ever count younger DMA pieces, which do retire in order among themselves.)
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      const unsigned char* sA = stg + (c & 1) * WS_BUF;
+      const unsigned char* sA = stg + (NBUF == 2 ? (c & 1) * WS_BUF : 0);
       const unsigned char* sWc = sWl + c * (9 * 2 * 64 * 16);
       f16x8_t fp[2][2], fw[2][2];                // [parity][mi / ni]: fragments are read one tap ahead
       auto load_frags = [&](int t, int par) {
@@ -248,8 +254,22 @@ __global__ __launch_bounds__(WS_THREADS) void conv3x3_c64_ws_kernel(ws_args a) {
               asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(rv[i]) : "v"(rp) : "memory");
             }
           }
+          if (NBUF == 2) {
+            if (c < 3) {
+              if (!(DBG & 2)) ws_dma5(voff, rsrc, soff0 + (unsigned)(c + 1) * plane, stg_lds + ((c + 1) & 1) * WS_BUF);
+            } else if ((unext = grab()) < total) {
+              make_desc(unext);
+              if (!(DBG & 2)) ws_dma5(voff, rsrc, soff0, stg_lds);
+            }
+          }
+        }
+        if (NBUF == 1 && t == 8) {
+          // single staging buffer: the next chunk's DMA may only be issued once EVERY fragment read of this chunk has
+          // returned (tap 8's were issued one tap ago); it then flies behind tap 8's MFMAs and, between tiles, the epilogue,
+          // while the SIMD's other two waves keep the matrix pipe busy
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
           if (c < 3) {
-            if (!(DBG & 2)) ws_dma5(voff, rsrc, soff0 + (unsigned)(c + 1) * plane, stg_lds + ((c + 1) & 1) * WS_BUF);
+            if (!(DBG & 2)) ws_dma5(voff, rsrc, soff0 + (unsigned)(c + 1) * plane, stg_lds);
           } else if ((unext = grab()) < total) {
             make_desc(unext);
             if (!(DBG & 2)) ws_dma5(voff, rsrc, soff0, stg_lds);
@@ -364,10 +384,21 @@ int ws_num_cus() { return cdfo_num_cus(); }
 
 template <int DBG, bool RES = false>
 int ws_launch(const ws_args& a, int grid, hipStream_t st) {
+  // three waves per SIMD by default (same-box A/B: 1.21 -> 1.18 ms at 64 -> 256 on 8 x 544 x 960, 0.295 -> 0.286 at 272 x 480):
+  // with two, the matrix pipe idles whenever both are outside their MFMA runs at once (counters: pipe busy 67 %);
+  // CDFO_WS_WAVES=8 selects the two-per-SIMD form with its 2-deep staging rings (developer A/B switch)
+  static const bool w12 = [] { const char* e = getenv("CDFO_WS_WAVES"); return !(e && atoi(e) == 8); }();
+  if (DBG == 0 && !RES && w12) {     // (the residual form needs 221 VGPRs: two waves per SIMD only)
+    static CdfoAttrOnce once12;
+    const hipError_t e = cdfo_set_max_lds(once12, reinterpret_cast<const void*>(conv3x3_c64_ws_kernel<DBG, RES, 12>), WsLds<12>::TOTAL);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL((conv3x3_c64_ws_kernel<DBG, RES, 12>), dim3(grid), dim3(12 * 64), WsLds<12>::TOTAL, st, a);
+    return 0;
+  }
   static CdfoAttrOnce once;
-  const hipError_t e = cdfo_set_max_lds(once, reinterpret_cast<const void*>(conv3x3_c64_ws_kernel<DBG, RES>), WS_LDS);
+  const hipError_t e = cdfo_set_max_lds(once, reinterpret_cast<const void*>(conv3x3_c64_ws_kernel<DBG, RES, 8>), WsLds<8>::TOTAL);
   if (e != hipSuccess) return (int)e;
-  hipLaunchKernelGGL((conv3x3_c64_ws_kernel<DBG, RES>), dim3(grid), dim3(WS_THREADS), WS_LDS, st, a);
+  hipLaunchKernelGGL((conv3x3_c64_ws_kernel<DBG, RES, 8>), dim3(grid), dim3(8 * 64), WsLds<8>::TOTAL, st, a);
   return 0;
 }
 

@@ -388,6 +388,7 @@ int ws_launch(const ws_args& a, int grid, hipStream_t st) {
   // with two, the matrix pipe idles whenever both are outside their MFMA runs at once (counters: pipe busy 67 %);
   // CDFO_WS_WAVES=8 selects the two-per-SIMD form with its 2-deep staging rings (developer A/B switch)
   static const bool w12 = [] { const char* e = getenv("CDFO_WS_WAVES"); return !(e && atoi(e) == 8); }();
+  // (four per SIMD -- 16 waves at 128 VGPRs, 8 of them spilled -- was 5 % slower than three)
   if (DBG == 0 && !RES && w12) {     // (the residual form needs 221 VGPRs: two waves per SIMD only)
     static CdfoAttrOnce once12;
     const hipError_t e = cdfo_set_max_lds(once12, reinterpret_cast<const void*>(conv3x3_c64_ws_kernel<DBG, RES, 12>), WsLds<12>::TOTAL);

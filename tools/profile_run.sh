@@ -5,7 +5,7 @@ B="python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-parity --no-extr
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- $B > $O/stats.log 2>&1 && \
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/fetch -- $B > $O/fetch.log 2>&1 && \
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/write -- $B > $O/write.log 2>&1 && \
-python3 tools/pmc_summary.py $O/fetch $O/write $O/r02_pmc_traffic_c3_fp16x2.txt --json $O/traffic_r02.json "conv3x3_c64_ws_kernel<0, false>" conv3x3_ws fp16x2 && \
+python3 tools/pmc_summary.py $O/fetch $O/write $O/r02_pmc_traffic_c3_fp16x2.txt --json $O/traffic_r02.json "conv3x3_c64_ws_kernel<0, false" conv3x3_ws fp16x2 && \
 cp $O/stats/*/*kernel_stats.csv $O/r02_kernel_stats_c3_fp16x2.csv && \
 D="python3 tools/bench_dcn.py --iters 10" && \
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/dstats -- $D > $O/dstats.log 2>&1 && \

@@ -278,7 +278,7 @@ typedef _Float16 attn_f16x4 __attribute__((ext_vector_type(4)));
 // scores in the log2 domain (Q is scaled by log2 e once, p = v_exp_f32(s - m) -- one instruction instead of expf's ten),
 // key masking only in a sequence's last sub-tile, and the accumulator rescale skipped while no lane's running maximum moves.
 template <int MODE, int NW>   // MODE 0: sequence = image row, 1: image column, 2: 8x8 window (row-major inside the window)
-__global__ __launch_bounds__(NW * 64) void seq_attn_mfma_kernel(const float* __restrict__ q, int ldq,
+__global__ __launch_bounds__(NW * 64, NW == 4 ? 3 : 2) void seq_attn_mfma_kernel(const float* __restrict__ q, int ldq,
                                                                 const float* __restrict__ v, int ldv,
                                                                 float* __restrict__ out, int ldo, int B, int H, int W,
                                                                 int nb, int tpb) {

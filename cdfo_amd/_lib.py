@@ -41,6 +41,7 @@ class ConvArgs(C.Structure):
         ("out2_cp16", C.c_void_p),
         ("src_plane_wrap", C.c_int),
         ("res_up2", C.c_void_p), ("ldru", C.c_int),
+        ("out2_lo", C.c_int),
     ]
 
 

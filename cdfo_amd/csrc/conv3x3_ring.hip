@@ -451,9 +451,17 @@ __global__ __launch_bounds__(RG_THREADS) void conv3x3_ring_kernel(cdfo_conv_args
             *reinterpret_cast<f32x4*>(a.out + pix * a.ldo + n) = v0;
             *reinterpret_cast<f32x4*>(a.out + pix * a.ldo + n + 4) = v1;
           }
-          if (a.out2_cp16)   // chunk-planar fp16 copy: record (image, chunk n/16, pixel), halves h*8 .. h*8+7
-            *reinterpret_cast<f16x8_t*>(static_cast<_Float16*>(a.out2_cp16) +
-                                        (((long long)b * (a.Cout >> 4) + (n >> 4)) * H * W + (long long)oy * W + X) * 16 + h * 8) = hv;
+          if (a.out2_cp16) { // chunk-planar fp16 copy: record (image, chunk n/16, pixel), halves h*8 .. h*8+7
+            const int npl = a.out2_lo ? (a.Cout >> 3) : (a.Cout >> 4);      // planes per image: hi | lo, or hi only
+            _Float16* o2 = static_cast<_Float16*>(a.out2_cp16) + (((long long)b * npl + (n >> 4)) * H * W + (long long)oy * W + X) * 16 + h * 8;
+            *reinterpret_cast<f16x8_t*>(o2) = hv;
+            if (a.out2_lo) {   // + the remainders: the pair is the source of a split-fp16 (hi + lo activations) convolution
+              f16x8_t lv;
+#pragma unroll
+              for (int k = 0; k < 4; ++k) { lv[k] = (_Float16)(v0[k] - (float)hv[k]); lv[4 + k] = (_Float16)(v1[k] - (float)hv[4 + k]); }
+              *reinterpret_cast<f16x8_t*>(o2 + (long long)(a.Cout >> 4) * H * W * 16) = lv;
+            }
+          }
         }
     }
   }

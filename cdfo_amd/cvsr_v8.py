@@ -202,6 +202,10 @@ class CVSR_V8(nn.Module):
             pc(key)
         for g in range(7):
             pc(f"recon_trunk.body.{g}.conv")
+            # the same convolution for the ring kernel: fp16 hi + lo activations (planes written by the group's last block) x
+            # weights rounded once to fp16 = the tiled kernel's "fp16x2" arithmetic as a K-expanded (w | w) product
+            w[f"recon_trunk.body.{g}.conv_hl2"] = K.pack_conv_hilo(sd[f"recon_trunk.body.{g}.conv.weight"],
+                                                                   sd[f"recon_trunk.body.{g}.conv.bias"], weight_lo=False)
             for b in range(3):
                 for leaf in ("body.0", "body.2", "down.0", "up.0"):
                     pc(f"recon_trunk.body.{g}.body.{b}.{leaf}")
@@ -430,7 +434,7 @@ class CVSR_V8(nn.Module):
         r = self._conv(o, rb[2], pad=1, act=K.ACT_RELU)
         return self._conv(r, rb[3], pad=1, res1=o, res2=xc, out=out)
 
-    def _block(self, w, p, x, x16=None, want16=False):
+    def _block(self, w, p, x, x16=None, want16=False, want_hl=False):
         """Block_ (arch.py:378-406): x + body(x) + up(body(down(x))) + down(body(up(x))).
         The 1x1 convs commute with the (linear) resampling, so they run on the smaller side of it.
         x16: optional fp16 chunk-planar copy of x; want16: also return such a copy of the result (fp16x2 mode)."""
@@ -452,10 +456,13 @@ class CVSR_V8(nn.Module):
             out = K.conv_ring(c1(x16), b2, res1=x)
             d = K.conv_ring(c1(d16), w[p + "body.2_up"])      # = up.0(body.2(.)) of the x1/2 branch
             t = c1(u16, s2d=True)
+            # want16: the next block's fp16 source; want_hl (a group's last block): fp16 hi | lo planes for the group convolution
             y16 = torch.empty_like(x16) if want16 else None
+            if want_hl:
+                y16 = torch.empty((x16.shape[0], 8) + tuple(x16.shape[2:]), dtype=torch.float16, device=x16.device)
             # the x1/2 branch (bilinear x2 of d) is added by the last convolution's epilogue
-            y = K.conv_ring(t, w[p + "down_fused"], res1=out, res_up2=d, out2_cp16=y16)
-            return (y, y16) if want16 else y
+            y = K.conv_ring(t, w[p + "down_fused"], res1=out, res_up2=d, out2_cp16=y16, out2_hl=want_hl)
+            return (y, y16) if (want16 or want_hl) else y
         out = self._conv(self._conv(x, b0, pad=1, act=K.ACT_LRELU, out_f16=t16, inner=True), b2, pad=1, res1=x)
         # half-resolution branch
         d = self._conv(K.resample2(x, up=False), dn)
@@ -472,10 +479,18 @@ class CVSR_V8(nn.Module):
         y = fused
         for g in range(7):
             r, r16 = y, None
-            for b in range(3):      # blocks 0 and 1 hand their successor an fp16 chunk-planar copy of the result
-                r, r16 = self._block(w, f"recon_trunk.body.{g}.body.{b}.", r, r16, want16=True) if b < 2 else \
-                    (self._block(w, f"recon_trunk.body.{g}.body.{b}.", r, r16), None)
-            y = self._conv(r, w[f"recon_trunk.body.{g}.conv"], pad=1, res1=y, res2=fused if g == 6 else None)
+            fast = self.precision == "fp16x2" and y.shape[1] % 4 == 0 and w[f"recon_trunk.body.{g}.body.0.body.0"].wh is not None
+            for b in range(3):      # blocks 0 and 1 hand their successor an fp16 chunk-planar copy of the result, block 2 hands
+                if b < 2:           # the group convolution fp16 hi | lo planes of it
+                    r, r16 = self._block(w, f"recon_trunk.body.{g}.body.{b}.", r, r16, want16=True)
+                elif fast:
+                    r, r16 = self._block(w, f"recon_trunk.body.{g}.body.{b}.", r, r16, want_hl=True)
+                else:
+                    r, r16 = self._block(w, f"recon_trunk.body.{g}.body.{b}.", r, r16), None
+            if fast:    # SCGroup_.conv (arch.py:435) on the ring kernel: 8 K chunks (hi | lo) against the tiled kernel's restaging
+                y = K.conv_ring(r16, w[f"recon_trunk.body.{g}.conv_hl2"], res1=y, res2=fused if g == 6 else None)
+            else:
+                y = self._conv(r, w[f"recon_trunk.body.{g}.conv"], pad=1, res1=y, res2=fused if g == 6 else None)
         return y
 
     # -- forward ---------------------------------------------------------------------------------------------------

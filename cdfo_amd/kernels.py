@@ -331,7 +331,8 @@ def sparse_taps_f16(pc: PackedConv) -> torch.Tensor:
 def conv_ring(src: torch.Tensor, pc: PackedConv, *, act: int = ACT_NONE, res1: Optional[torch.Tensor] = None,
               res2: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None,
               out_f16: bool = False, out2_cp16: Optional[torch.Tensor] = None,
-              res_up2: Optional[torch.Tensor] = None, plane_wrap: int = 0, dbg: int = 0) -> torch.Tensor:
+              res_up2: Optional[torch.Tensor] = None, plane_wrap: int = 0, dbg: int = 0,
+              out2_hl: bool = False) -> torch.Tensor:
     """3x3/s1/p1 convolution of an fp16 chunk-planar source [B,Cin/16,H,W,16] on the LDS-DMA ring kernel
     (Block_.body[2] and the composed stride-2 convolution).  Result: pixel-major fp32 (or fp16) [B,H,W,Cout]."""
     if not src.is_cuda:
@@ -373,10 +374,11 @@ def conv_ring(src: torch.Tensor, pc: PackedConv, *, act: int = ACT_NONE, res1: O
             raise ValueError(f"res_up2 shape {tuple(res_up2.shape)} is not the half-resolution of the conv output")
         a.res_up2, a.ldru = res_up2.data_ptr(), rld
     if out2_cp16 is not None:       # second, fp16 chunk-planar copy of the result (the next Block_'s body[0] source)
-        if (out2_cp16.dtype != torch.float16 or tuple(out2_cp16.shape) != (B, pc.Cout // 16, H, W, 16)
+        npl = (2 if out2_hl else 1) * (pc.Cout // 16)     # out2_hl: hi | lo planes (the source of a split-fp16 convolution)
+        if (out2_cp16.dtype != torch.float16 or tuple(out2_cp16.shape) != (B, npl, H, W, 16)
                 or not out2_cp16.is_contiguous()):
-            raise ValueError("conv_ring: out2_cp16 must be a contiguous fp16 [B,Cout/16,H,W,16] tensor")
-        a.out2_cp16 = out2_cp16.data_ptr()
+            raise ValueError("conv_ring: out2_cp16 must be a contiguous fp16 [B,Cout/16 (x2 with out2_hl),H,W,16] tensor")
+        a.out2_cp16, a.out2_lo = out2_cp16.data_ptr(), int(out2_hl)
     check(_lib.lib().cdfo_conv3x3_ring(C.byref(a), _stream()), "cdfo_conv3x3_ring")
     return out
 

@@ -60,6 +60,8 @@ typedef struct {
                                  that a K-expanded product (a_hi | a_lo | a_hi) x (w_hi | w_hi | w_lo) needs no duplicated planes */
   const float* res_up2; int ldru;   /* optional, cdfo_conv3x3_ring only: a HALF-resolution residual [B][H/2][W/2][ldru] that is
                                  added after bilinear x2 up-sampling (align_corners=False), i.e. Block_'s x1/2 branch */
+  int out2_lo;                /* cdfo_conv3x3_ring with out2_cp16: the copy is hi | lo planes [B][2*Cout/16][H][W][16] (fp16(v), then
+                                 fp16(v - fp16(v))): the source of a split-fp16 convolution on the same kernel */
 } cdfo_conv_args;
 int cdfo_conv_igemm(const cdfo_conv_args* a, void* stream);
 

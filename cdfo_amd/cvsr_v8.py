@@ -590,15 +590,17 @@ class CVSR_V8(nn.Module):
             side = cache.get((x.device, nstr))
             if side is None:
                 side = cache[(x.device, nstr)] = [torch.cuda.Stream(x.device) for _ in range(nstr)]
-        for st in side:
-            st.wait_stream(main)
         keep = []
         # group size: three frames per group at >= 3 clips (large launches, two groups on two streams); one frame per group
         # (six independent pipelines on up to six streams) for one or two clips, where launches are small and concurrency is
         # what fills the GPU (the streamed B = 1 sequence: 61 vs 58 frames/s)
         gsz = int(getattr(self, "neighbour_group", 0)) or (ctr if B >= 3 else 1)
         groups = [list(range(s, min(s + gsz, e))) for (s0, e) in ((0, ctr), (ctr + 1, N)) for s in range(s0, e, gsz)]
-        xcG = Lf[ctr].repeat(gsz, 1, 1, 1) if gsz > 1 else Lf[ctr]          # the centre features once per neighbour of a group
+        # the centre features once per neighbour of a group.  Enqueued on the caller's stream BEFORE the side streams fork from
+        # it: they read xcG (Gram pass and last residual of _align), so the copy must be ordered ahead of their wait
+        xcG = Lf[ctr].repeat(gsz, 1, 1, 1) if gsz > 1 else Lf[ctr]
+        for st in side:
+            st.wait_stream(main)
         aligned_by_frame = {}
         draw0 = 0
         for gi, idxs in enumerate(groups):

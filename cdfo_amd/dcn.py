@@ -158,6 +158,9 @@ class DeformConvPack(DeformConv):
                                      self.deformable_groups * 2 * self.kernel_size[0] * self.kernel_size[1],
                                      kernel_size=self.kernel_size, stride=_pair(self.stride),
                                      padding=_pair(self.padding), bias=True)
+        self.init_offset()
+
+    def init_offset(self):      # public in the reference (deform_conv.py:254-256)
         self.conv_offset.weight.data.zero_()
         self.conv_offset.bias.data.zero_()
 
@@ -203,6 +206,9 @@ class ModulatedDeformConvPack(ModulatedDeformConv):
                                           self.deformable_groups * 3 * self.kernel_size[0] * self.kernel_size[1],
                                           kernel_size=self.kernel_size, stride=_pair(self.stride),
                                           padding=_pair(self.padding), bias=True)
+        self.init_offset()
+
+    def init_offset(self):      # public in the reference (deform_conv.py:326-328)
         self.conv_offset_mask.weight.data.zero_()
         self.conv_offset_mask.bias.data.zero_()
 

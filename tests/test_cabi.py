@@ -63,3 +63,38 @@ def test_missing_library_fails_loudly(monkeypatch, tmp_path):
     monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))
     with pytest.raises(_lib.CdfoError):
         _lib.lib()
+
+
+def test_top_level_deform_conv_cuda_import_like_the_reference():
+    """ops/dcn/deform_conv.py:4,11 of the reference: `sys.path.append(dirname(__file__)); import deform_conv_cuda` -- the
+    operator module is found as a TOP-LEVEL name from ops/dcn.  Run in a child so this process's sys.path stays as it is."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys, os\n"
+            f"sys.path.insert(0, {root!r})\n"
+            f"sys.path.append(os.path.join({root!r}, 'ops', 'dcn'))\n"
+            "import deform_conv_cuda\n"
+            "names = ['deform_conv_forward_cuda', 'deform_conv_backward_input_cuda', 'deform_conv_backward_parameters_cuda',\n"
+            "         'modulated_deform_conv_cuda_forward', 'modulated_deform_conv_cuda_backward']\n"
+            "assert all(callable(getattr(deform_conv_cuda, n)) for n in names)\n"
+            "import ops.dcn.deform_conv_cuda as pkg, cdfo_amd.deform_conv_cuda as impl\n"
+            "assert all(getattr(pkg, n) is getattr(impl, n) is getattr(deform_conv_cuda, n) for n in names)\n"
+            "print('ok')\n")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd="/tmp")
+    assert r.returncode == 0 and r.stdout.strip() == "ok", r.stderr
+
+
+def test_pack_modules_expose_init_offset():
+    """deform_conv.py:252-256, 324-328: `init_offset()` is a public method of both *Pack classes (called by the ctor)."""
+    from ops.dcn.deform_conv import DeformConvPack, ModulatedDeformConvPack
+    a = DeformConvPack(4, 4, 3, padding=1, deformable_groups=2)
+    b = ModulatedDeformConvPack(4, 4, 3, padding=1, deformable_groups=2)
+    for m, conv in ((a, a.conv_offset), (b, b.conv_offset_mask)):
+        assert float(conv.weight.abs().sum()) == 0.0 and float(conv.bias.abs().sum()) == 0.0
+        conv.weight.data.fill_(1.0)
+        conv.bias.data.fill_(1.0)
+        m.init_offset()
+        assert float(conv.weight.abs().sum()) == 0.0 and float(conv.bias.abs().sum()) == 0.0
+    assert a.conv_offset.out_channels == 2 * 2 * 9 and b.conv_offset_mask.out_channels == 2 * 3 * 9

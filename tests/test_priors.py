@@ -20,6 +20,28 @@ def test_png_roundtrip_every_row_filter(tmp_path, filter_type, shape):
     assert np.array_equal(read_gray_png(p), img)
 
 
+def test_png_decoder_against_an_independent_codec(tmp_path):
+    """cv2 (what test_LD_22_FPS.py:20-74 reads with) is absent; Pillow (libpng) is an independent PNG codec that IS here:
+    files it writes (adaptive per-row filters, several compression settings, grey + alpha) decode to the same pixels, and
+    files written by write_gray_png decode identically in Pillow."""
+    Image = pytest.importorskip("PIL.Image")
+    rs = np.random.RandomState(11)
+    smooth = (np.add.outer(np.arange(37) * 3, np.arange(53) * 2) % 256).astype(np.uint8)      # makes libpng pick Sub/Up/Avg/Paeth
+    for k, img in enumerate((rs.randint(0, 256, (30, 48)).astype(np.uint8), smooth, np.full((5, 9), 200, np.uint8))):
+        for j, kw in enumerate((dict(), dict(optimize=True), dict(compress_level=1), dict(compress_level=9))):
+            p = str(tmp_path / f"pil_{k}_{j}.png")
+            Image.fromarray(img, mode="L").save(p, **kw)
+            assert np.array_equal(read_gray_png(p), img)
+        la = np.stack([img, 255 - img], -1)
+        p = str(tmp_path / f"pil_la_{k}.png")
+        Image.fromarray(la, mode="LA").save(p)
+        assert np.array_equal(read_gray_png(p), img)                      # alpha dropped, like cv2.imread(path, 0)
+        for ft in range(5):
+            p = str(tmp_path / f"own_{k}_{ft}.png")
+            write_gray_png(p, img, ft)
+            assert np.array_equal(np.asarray(Image.open(p)), img)
+
+
 def test_png_rejects_what_it_does_not_decode(tmp_path):
     p = str(tmp_path / "bad.png")
     open(p, "wb").write(b"not a png")

@@ -48,6 +48,38 @@ MFMA16 = {"conv3x3_wide": ("conv3x3_mma16_kernel", None), "conv3x3_ws": ("conv3x
           "conv3x3_ring": ("conv3x3_ring_kernel<false", 1), "conv3x3_ring4": ("conv3x3_ring_kernel<true", 1)}
 
 
+# HBM-bound kernel families of the event profiler -> substrings of the kernel symbols they launch (rocprofv3 names); used to
+# pair a family's algorithmic bytes with the PMC traffic of the same launches (tools/pmc_summary.py --families)
+HBM_FAMILIES = {"conv1x1": ["conv1x1_stream_kernel", "conv1x1_bf16x3_kernel"], "dwconv": ["qkv_dw_kernel", "dwconv3x3_kernel"],
+                "attn_row": ["seq_attn_mfma_kernel<0"], "attn_col": ["seq_attn_mfma_kernel<1"], "attn_win": ["seq_attn_mfma_kernel<2"],
+                "rdab_prep": ["rdab_prep_kernel"], "resample": ["block_pro_kernel", "resample2_kernel"], "stem": ["stem_conv"],
+                "flow_warp": ["flow_warp_kernel"], "colconv9": ["colconv9_kernel"], "chan_sum": ["chan_sum_partial_kernel"],
+                "gram": ["gram_partial_kernel"], "layout": ["swap_outer_kernel", "to_cp16_kernel", "nchw_to_nhwc", "nhwc_to_nchw"],
+                "scale": ["scale_channels_kernel"], "small_conv": ["small_conv3x3_kernel", "udsa_head_kernel"],
+                "spatial_gate": ["spatial_gate16_kernel"], "conv_last": ["conv_last"], "layernorm": ["layernorm64"]}
+HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+
+
+def load_traffic(precision):
+    """profiles/traffic_rNN.json of the newest round: HBM bytes per launch from rocprofv3 PMC passes (separate FETCH_SIZE /
+    WRITE_SIZE runs of this script, tools/profile_run.sh), with the commit they were taken at.  Replayed, not measured here."""
+    for r in range(9, 0, -1):
+        q = os.path.join(ROOT, "profiles", f"traffic_r{r:02d}.json")
+        if not os.path.exists(q):
+            continue
+        try:
+            tj = json.load(open(q))
+        except Exception:
+            return {}
+        if tj.get("precision") != precision:
+            return {}
+        fams = dict(tj.get("families") or {})
+        if "kernel" in tj and tj["kernel"] not in fams:        # rounds 1-2: one kernel per file
+            fams[tj["kernel"]] = {"hbm_bytes_per_launch": tj.get("hbm_bytes_per_launch")}
+        return {"file": os.path.relpath(q, ROOT), "commit": tj.get("commit"), "families": fams}
+    return {}
+
+
 def flops_per_clip(H, W):
     return EXACT_FLOPS.get((H, W), H * W * (73.55e6 + 1536.0 * (W + H)))
 
@@ -88,6 +120,7 @@ def parse_args(argv=None):
     ap.add_argument("--neighbour-streams", type=int, default=0, help="issue the six neighbour-frame pipelines on this many HIP streams (0 = the model's choice: 3 at 8 clips)")
     ap.add_argument("--breakdown", type=str, default="", help="write the per-kernel-family event timings to this file")
     ap.add_argument("--injected-noise", action="store_true", help="time the forward with pre-made Gumbel noise tensors (the parity tests' path) instead of the default in-kernel draws")
+    ap.add_argument("--no-full-size-parity", action="store_true", help="N > 1: skip rank 0's clip-0 check at the timed size (every rank still checks c1)")
     ap.add_argument("--no-extra-modes", action="store_true", help="skip the extra measurements (bf16x3 mode, injected-noise path, DCN / V7 lines)")
     return ap.parse_args(argv)
 
@@ -167,21 +200,34 @@ def main():
 
     # ---- parity against the CPU oracle, on the path that is timed.  N = 1: clip 0 of the timed batch at the timed size
     # (the oracle forward on one 272x480 clip is also the cpu_baseline measurement); N > 1: every rank checks the
-    # reference's own CPU-runnable config (c1: 64x64, B=1) -- N oracle forwards at full size would share one host.
+    # reference's own CPU-runnable config (c1: 64x64, B=1) -- N oracle forwards at full size would share one host -- and
+    # rank 0 ALSO checks clip 0 of its timed batch at the timed size (the grouped, two-stream, full-size schedule that c1's
+    # one-frame-per-stream small-shape kernels do not exercise) while the other ranks wait at the barrier.
     max_abs, psnr, cpu = float("nan"), float("nan"), None
+    max_abs_full, ref_out_full, cap_full = float("nan"), None, None
     parity_cfg = "skipped (--no-parity)"
     if not args.no_parity:
-        if world == 1 and not args.streaming:
+        full = not args.streaming and (world == 1 or (rank == 0 and not args.no_full_size_parity))
+        if full:
             cap = []
             model.capture_noise = None if args.injected_noise else cap
             got, _ = step()
             model.capture_noise = None
-            noise0 = [u[0:1].cpu() for u in (injected if args.injected_noise else cap)]
+            cap_full = injected if args.injected_noise else cap
+            noise0 = [u[0:1].cpu() for u in cap_full]
             clip0 = {k: (v[0:1].cpu() if v is not None else None) for k, v in d.items()}
-            ref_out, cpu = oracle_clip(sd, clip0, noise0, Hp, Wp, time_it=not args.no_cpu_baseline)
+            ref_out_full, cpu = oracle_clip(sd, clip0, noise0, Hp, Wp, time_it=(world == 1 and not args.no_cpu_baseline))
             g0 = got[0:1].cpu()
+            max_abs_full = (g0 - ref_out_full).abs().max().item()
             parity_cfg = f"clip 0 of the timed batch ({Hp}x{Wp}, noise as drawn by the timed path) vs CPU oracle"
-        else:
+            if world == 1:
+                max_abs, psnr = max_abs_full, psnr_y(g0, ref_out_full)
+                if args.no_extra_modes or args.precision == "bf16":
+                    cap_full = None                     # only the bf16_plain extra replays this noise
+            else:                                       # back to this rank's share of the host for the small check below
+                cap_full = None
+                torch.set_num_threads(max(1, (os.cpu_count() or world) // world))
+        if world > 1 or args.streaming:
             c1 = make_inputs(1, 64, 64, 1000)
             cap = []
             model.capture_noise = cap
@@ -191,9 +237,15 @@ def main():
                 ref_out, _ = cvsr_v8_forward(sd, c1["x"], None, c1["mvs1"], c1["pms"], c1["rms"], c1["ufs"], None,
                                              [u.cpu() for u in cap])
             g0 = g0.cpu()
-            parity_cfg = "c1 64x64 B=1 (noise as drawn by the default path) vs CPU oracle, on every rank"
-        max_abs = (g0 - ref_out).abs().max().item()
-        psnr = psnr_y(g0, ref_out)
+            max_abs = (g0 - ref_out).abs().max().item()
+            psnr = psnr_y(g0, ref_out)
+            small = "c1 64x64 B=1 (noise as drawn by the default path) vs CPU oracle, on every rank"
+            if args.streaming:
+                parity_cfg = small + " -- small-config only (the streaming path's timed size is not checked here)"
+            elif math.isfinite(max_abs_full):
+                parity_cfg = small + f"; rank 0 also: clip 0 of its timed batch at {Hp}x{Wp} (the grouped, two-stream, full-size schedule)"
+            else:
+                parity_cfg = small + " -- small-config only (--no-full-size-parity)"
 
     for _ in range(args.warmup):
         step()
@@ -232,14 +284,31 @@ def main():
             extra["bf16x3_fp32_grade"] = {"frames_per_s": round(B * nst / t, 3), "ms_per_step": round(1e3 * t / nst, 3),
                                           "steps": nst, "note": "split-bf16 3-pass MFMA everywhere: <= 1.2e-5 max-abs vs the fp32 reference"}
             model.precision = args.precision
+        if args.precision != "bf16" and cap_full is not None and ref_out_full is not None:
+            # BASELINE's literal c3 dtype: plain bf16 MFMA (one rounding of activations and weights, fp32 accumulate) on the same
+            # batch, replaying the noise of the parity forward so that clip 0 compares with the same oracle output
+            model.precision = "bf16"
+            gb, _ = step(cap_full)
+            t, _ = timed(nst, cap_full)
+            g0b = gb[0:1].cpu()
+            eb = (g0b - ref_out_full).abs().max().item()
+            extra["bf16_plain"] = {"frames_per_s": round(B * nst / t, 3), "ms_per_step": round(1e3 * t / nst, 3), "steps": nst,
+                                   "max_abs": eb, "psnr_y_db": psnr_y(g0b, ref_out_full), "within_1e-3": bool(eb <= PARITY_BOUND),
+                                   "note": "precision='bf16' (BASELINE c3's dtype), noise replayed from the parity forward; outside the "
+                                           "1e-3 bound by design of the format (8-bit mantissa), which is why it is not the default"}
+            model.precision = args.precision
+            del gb
+        cap_full = None
 
     # ---- the single collective: all_gather of per-rank metrics (time, checksum, parity)
     from cdfo_amd.dist import gather_metrics
+    ident = device_identity(local)               # 8 numbers: which physical GPU this rank drove (checked for duplicates below)
     allm = gather_metrics([elapsed, out.double().mean().item(), max_abs, psnr if math.isfinite(psnr) or psnr != psnr else 999.0,
-                           elapsed_prof], dev if backend == "nccl" else None)
+                           elapsed_prof, max_abs_full, float(local), *ident], dev if backend == "nccl" else None)
     t_max = allm[:, 0].max().item()
     # parity gate: a numerically broken build must not print a valid-looking line
-    parity_ok = args.no_parity or all(math.isfinite(v) and v <= PARITY_BOUND for v in allm[:, 2].tolist())
+    parity_ok = args.no_parity or (all(math.isfinite(v) and v <= PARITY_BOUND for v in allm[:, 2].tolist())
+                                   and all(v != v or v <= PARITY_BOUND for v in allm[:, 5].tolist()))
 
     if rank == 0:
         clips_total = B * world * args.steps
@@ -263,22 +332,36 @@ def main():
                     "algorithmic_flop_per_launch": round(fl[k] / max(1, launches[k]), 0),
                     "launches_per_step": launches[k] // max(1, args.steps), "avg_launch_ms": round(avg_ms, 4),
                     "share_of_gpu_time": round(ms[k] / max(1e-9, sum(ms)), 4)}
-        traffic = None
-        tpath = next((q for q in (os.path.join(ROOT, "profiles", f"traffic_r{r:02d}.json") for r in (2, 1)) if os.path.exists(q)), "")
-        if tpath:                            # HBM bytes per launch from rocprofv3 PMC passes (tools/collect_traffic.py)
-            try:
-                tj = json.load(open(tpath))
-                if tj.get("kernel") == KID_NAMES[dom] and tj.get("precision") == args.precision:
-                    traffic = tj.get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
+        tr = load_traffic(args.precision)
+        tfam = tr.get("families", {})
+        traffic = (tfam.get(KID_NAMES[dom]) or {}).get("hbm_bytes_per_launch")
+
+        def hbm_fam(k):
+            name = KID_NAMES[k]
+            avg_ms = ms[k] / max(1, launches[k])
+            bpl = by[k] / max(1, launches[k])
+            gbs = bpl / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+            pmc = (tfam.get(name) or {}).get("hbm_bytes_per_launch")
+            return {"kernel": name, "kernel_symbols": HBM_FAMILIES.get(name, [name]), "bound": "hbm", "achieved": round(gbs, 1),
+                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
+                    "algorithmic_bytes_per_launch": round(bpl), "launches_per_step": launches[k] // max(1, args.steps),
+                    "avg_launch_ms": round(avg_ms, 4), "share_of_gpu_time": round(ms[k] / max(1e-9, sum(ms)), 4),
+                    "traffic": pmc, "traffic_ratio": (round(pmc / bpl, 3) if pmc and bpl else None)}
+        hbm_rows = sorted((k for k in range(nk) if KID_NAMES[k] in HBM_FAMILIES and launches[k] and by[k] > 0), key=lambda k: -ms[k])[:6]
         wf = F * B * args.steps / t_max / 1e12
         roofline = {"bound": "mfma", **fam(dom), "traffic": traffic,
                     "whole_forward_tflops": round(wf, 2), "whole_forward_frac": round(wf / PEAK_TFLOPS[args.precision], 4),
                     "measured_in": f"second pass over the same {args.steps} steps with one HIP-event pair per launch on the launch "
                                    f"stream ({round(1e3 * allm[:, 4].max().item() / args.steps, 3)} ms per step with the events)",
                     # the other matrix-core convolution kernels of the step, same definitions (not the headline entry)
-                    "other_mfma_kernels": [fam(k) for k in range(nk) if KID_NAMES[k] in MFMA16 and k != dom and launches[k]]}
+                    "other_mfma_kernels": [fam(k) for k in range(nk) if KID_NAMES[k] in MFMA16 and k != dom and launches[k]],
+                    # the step's largest HBM-bound kernel families, live HIP-event durations, in situ (the
+                    # neighbour phase runs two streams, so its families' durations overlap); `traffic` as for the headline entry
+                    "hbm_kernels": [hbm_fam(k) for k in hbm_rows],
+                    "traffic_source": ({"file": tr.get("file"), "profiles_commit": tr.get("commit"),
+                                        "note": "replayed from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this script "
+                                                "(tools/profile_run.sh) taken at profiles_commit, not measured in this run"}
+                                       if tr else None)}
         if cpu is None and not args.no_cpu_baseline and world == 1:      # reported on rank 0 at N = 1 only
             cpu = cpu_baseline_scaled(sd, Hp, Wp)       # (--no-parity / --streaming runs: bounded half-size sample)
         res = {
@@ -295,7 +378,12 @@ def main():
                        "weights": "random init (seed 0)"},
             "parity": {"config": parity_cfg, "max_abs": max_abs, "psnr_y_db": psnr, "bound": PARITY_BOUND,
                        "verified": bool(parity_ok and not args.no_parity),
-                       "per_rank_max_abs": [float(v) for v in allm[:, 2]]},
+                       "per_rank_max_abs": [float(v) for v in allm[:, 2]],
+                       "full_size_max_abs": (None if max_abs_full != max_abs_full else max_abs_full)},
+            "world": world, "backend": (dist.get_backend() if world > 1 else None),
+            "ranks": [{"rank": r, "ms_per_step": round(1e3 * allm[r, 0].item() / args.steps, 3), "local_device": int(allm[r, 6].item()),
+                       "device": format_identity(allm[r, 7:15].tolist())} for r in range(world)],
+            "distinct_devices": len({tuple(allm[r, 7:15].tolist()) for r in range(world)}),
             "roofline": roofline, "cpu_baseline": cpu, "fp16_range_guard": range_info, **extra,
         }
         if world == 1 and not args.no_parity and not args.no_extra_modes:
@@ -369,7 +457,7 @@ def dcn_forward_line(device, H, W, B, iters=10):
     nbytes = (C + 3 * dg * 9 + Co) * H * W * 4 * B + w.numel() * 4
     ach = nbytes / ms / 1e6
     traffic = None
-    tpath = next((q for q in (os.path.join(ROOT, "profiles", f"traffic_dcn_r{r:02d}.json") for r in (2, 1)) if os.path.exists(q)), "")
+    tpath = next((q for q in (os.path.join(ROOT, "profiles", f"traffic_dcn_r{r:02d}.json") for r in range(9, 0, -1)) if os.path.exists(q)), "")
     if tpath and (B, H, W) == (8, 272, 480):     # PMC passes of tools/bench_dcn.py at exactly this shape
         try:
             tj = json.load(open(tpath))
@@ -398,12 +486,53 @@ def dcn_forward_line(device, H, W, B, iters=10):
 
 
 def _host_cores():
-    cores = min(os.cpu_count() or 1, 32)
+    """Threads for the CPU baseline: the PHYSICAL cores this process may run on (unique (package, core) pairs of the CPUs in
+    its affinity mask; SMT siblings counted once), capped by a cgroup CPU quota if the box sets one."""
     try:
-        cores = min(cores, len(os.sched_getaffinity(0)))
+        allowed = set(os.sched_getaffinity(0))
+    except Exception:
+        allowed = set(range(os.cpu_count() or 1))
+    cores = set()
+    try:
+        cpu, phys = None, 0
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("processor"):
+                cpu = int(line.split(":")[1])
+            elif line.startswith("physical id"):
+                phys = int(line.split(":")[1])
+            elif line.startswith("core id") and cpu in allowed:
+                cores.add((phys, int(line.split(":")[1])))
+    except Exception:
+        cores = set()
+    n = len(cores) or len(allowed)
+    try:                                             # cgroup v2 quota "max 100000" / "1600000 100000"
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            n = max(1, min(n, int(math.ceil(int(q) / int(per)))))
     except Exception:
         pass
-    return cores
+    return max(1, n)
+
+
+def device_identity(index):
+    """Eight numbers that identify the physical GPU behind cuda:index: PCI domain / bus / device and the 16-byte UUID as four
+    32-bit words (zeros where the runtime does not expose them) -- carried by the single metric all_gather."""
+    pr = torch.cuda.get_device_properties(index)
+    pci = [float(getattr(pr, a, -1)) for a in ("pci_domain_id", "pci_bus_id", "pci_device_id")]
+    words = [0.0] * 4
+    try:
+        raw = getattr(pr, "uuid", None)
+        b = raw.bytes if hasattr(raw, "bytes") else bytes.fromhex(str(raw).replace("-", "").replace("GPU", ""))
+        words = [float(int.from_bytes(b[4 * i:4 * i + 4], "big")) for i in range(4)]
+    except Exception:
+        pass
+    return [*pci, *words, float(pr.multi_processor_count)]
+
+
+def format_identity(v):
+    dom, bus, devn = (int(x) for x in v[0:3])
+    return {"pci": (f"{dom:04x}:{bus:02x}:{devn:02x}.0" if bus >= 0 else None),
+            "uuid": "".join(f"{int(x):08x}" for x in v[3:7]), "compute_units": int(v[7])}
 
 
 def _cpu_model():

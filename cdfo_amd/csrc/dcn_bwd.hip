@@ -259,10 +259,12 @@ __global__ __launch_bounds__(DT_THREADS) void dcn_bwd_data_tile_kernel(DcnBwdArg
     for (int i = 1; i < DT_THREADS / 64; ++i) amax = fmaxf(amax, s_amax[i]);
     int ex = 0;
     if (amax > 0.f && amax < INFINITY) frexpf(amax, &ex);              // amax < 2^ex
+    // fixed point only while 2^(48 - ex) is a representable scale: a finite maximum in [2^120, 2^128) would be scaled by the
+    // CLAMPED exponent and overflow the 63-bit sums -> such a workgroup takes the float path like a non-finite one
+    fx_ok = amax < INFINITY && ex <= 120;
     ex = ex < -60 ? -60 : (ex > 120 ? 120 : ex);
     fx_scale = ldexpf(1.f, 48 - ex);
-    fx_inv = ldexpf(1.f, ex - 48);
-    fx_ok = amax < INFINITY;       // else every sample takes the float path straight to global memory (NaN / inf propagate)
+    fx_inv = ldexpf(1.f, ex - 48);     // !fx_ok: every sample goes straight to global memory as a float (NaN / inf propagate)
   }
 #pragma unroll
   for (int t = 0; t < DT_MAXT; ++t) {
@@ -358,7 +360,10 @@ __global__ __launch_bounds__(DT_THREADS) void dcn_bwd_gw_kernel(DcnBwdArgs a, in
   for (int i = 0; i < 4; ++i)
 #pragma unroll
     for (int q = 0; q < 16; ++q) gacc[i >> 1][i & 1][q] = 0.f;
-  float unit = 1.f;
+  // the accumulators' unit as a binary EXPONENT (a float product of two tile scales can leave fp32's range); it only ever
+  // grows: a tile whose own unit is smaller has its column values scaled down to the running one instead (a power of two,
+  // possibly flushing what is below fp32's resolution of the sums anyway), so no rescale ever multiplies by an infinity
+  int unit_e = -100000;
   for (int ti = 0; ti < tpw; ++ti) {
     const int tile = blockIdx.x * tpw + ti;
     if (tile >= ntiles) break;
@@ -382,15 +387,19 @@ __global__ __launch_bounds__(DT_THREADS) void dcn_bwd_gw_kernel(DcnBwdArgs a, in
         for (int j = 0; j < 4; ++j) cmax = fmaxf(cmax, fmaxf(fabsf(v0[j]), fabsf(v1[j])));
       }
     float cinv;
-    const float csc = dcnb_pow2_scale(wave_max(cmax), cinv);
-    const float un = a.gt_inv[(long long)b * ntiles + tile] * cinv;
-    if (un != unit) {
-      const float f = unit / un;
+    float csc = dcnb_pow2_scale(wave_max(cmax), cinv);
+    const int ue = ilogbf(a.gt_inv[(long long)b * ntiles + tile]) + ilogbf(cinv);     // both exact, normal powers of two
+    if (ue > unit_e) {
+      const int de = unit_e - ue;
+      const float f = ldexpf(1.f, de < -200 ? -200 : de);                             // <= 1; 0 for the first tile (sums are 0)
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int q = 0; q < 16; ++q) gacc[i >> 1][i & 1][q] *= f;
-      unit = un;
+      unit_e = ue;
+    } else if (ue < unit_e) {
+      const int de = ue - unit_e;
+      csc *= ldexpf(1.f, de < -200 ? -200 : de);
     }
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
@@ -422,7 +431,7 @@ __global__ __launch_bounds__(DT_THREADS) void dcn_bwd_gw_kernel(DcnBwdArgs a, in
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
           const int o = 32 * mt + (q & 3) + 8 * (q >> 2) + 4 * h;
-          red[(wave * 64 + o) * DT_COLROWS + et] = gacc[mt][nt][q] * unit;
+          red[(wave * 64 + o) * DT_COLROWS + et] = ldexpf(gacc[mt][nt][q], unit_e < -1000 ? 0 : unit_e);
         }
     }
   __syncthreads();

@@ -10,6 +10,40 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # On a GPU box: start multiprocessing's fork server NOW, while this process has not touched the GPU.  Tests that must start
+    # another GPU program (bench.py's multi-rank launcher) ask the server for a child: that child is forked from a GPU-free
+    # process, so no process that has initialised the GPU ever forks or execs (see clean_process_run below).
+    try:
+        import torch
+        if torch.cuda.device_count() > 0:
+            import multiprocessing.forkserver as fs
+            fs.ensure_running()
+    except Exception:
+        pass
+
+
+def _run_and_report(cmd, env, cwd, timeout, q):
+    import subprocess
+    try:
+        r = subprocess.run(cmd, env=env, cwd=cwd, capture_output=True, text=True, timeout=timeout)
+        q.put((r.returncode, r.stdout[-40000:], r.stderr[-8000:]))
+    except Exception as e:      # noqa: BLE001
+        q.put((-999, "", repr(e)))
+
+
+def clean_process_run(cmd, env=None, cwd=None, timeout=900):
+    """subprocess.run(cmd) executed by a child of the fork server (a process that never initialised the GPU):
+    returns (returncode, stdout tail, stderr tail)."""
+    import multiprocessing as mp
+    ctx = mp.get_context("forkserver")
+    q = ctx.Queue()
+    p = ctx.Process(target=_run_and_report, args=(cmd, env, cwd, timeout, q))
+    p.start()
+    try:
+        res = q.get(timeout=timeout + 60)
+    finally:
+        p.join(30)
+    return res
 
 
 @pytest.fixture(scope="session")

@@ -47,3 +47,32 @@ def test_world_size_mismatch_is_an_error():
     env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], env=env, capture_output=True, text=True)
     assert r.returncode != 0 and "WORLD_SIZE=1" in (r.stderr + r.stdout)
+
+
+@pytest.mark.gpu
+def test_two_rank_bench_line_reports_every_rank():
+    """`python bench.py --gpus 2` as a fresh program (its launcher path: the parent starts the ranks before any GPU call), ranks
+    sharing this box's GPU with the all_gather over gloo (CDFO_BENCH_BACKEND=gloo; the measured configuration is RCCL, one GPU
+    per rank): the JSON line must say n_gpus = 2 and carry one entry per rank (step time, device identity), the backend, and --
+    on rank 0 -- the full-size clip-0 parity next to every rank's c1 check.  Started through the GPU-free fork server
+    (conftest.clean_process_run): this pytest process has initialised the GPU and must not fork / exec GPU programs."""
+    import json
+    from conftest import clean_process_run
+    env = dict(os.environ, CDFO_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--batch", "2", "--steps", "2", "--warmup", "1",
+           "--height", "64", "--width", "96", "--no-extra-modes", "--no-cpu-baseline"]
+    rc, out, err = clean_process_run(cmd, env=env, cwd=ROOT, timeout=900)
+    assert rc == 0, (rc, out[-2000:], err[-4000:])
+    line = [ln for ln in out.splitlines() if ln.startswith("{")][-1]
+    res = json.loads(line)
+    assert res["n_gpus"] == 2 and res["world"] == 2 and res["backend"] == "gloo"
+    assert [r["rank"] for r in res["ranks"]] == [0, 1]
+    assert all(r["ms_per_step"] > 0 and r["device"]["compute_units"] > 0 for r in res["ranks"])
+    assert res["config"]["clips_per_gpu"] == 2 and res["scaling"] == "weak"
+    assert abs(res["value"] - 2 * 2 * 1e3 / res["ms_per_step"]) < 1e-2 * res["value"]          # whole-job rate over the slowest rank
+    assert res["ms_per_step"] >= max(r["ms_per_step"] for r in res["ranks"]) - 1e-3
+    par = res["parity"]
+    assert par["verified"] and len(par["per_rank_max_abs"]) == 2 and all(v <= 1e-3 for v in par["per_rank_max_abs"])
+    assert par["full_size_max_abs"] is not None and par["full_size_max_abs"] <= 1e-3

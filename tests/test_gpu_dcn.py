@@ -411,7 +411,7 @@ def test_dcn_fast_path_full_size_matches_exact_kernel_and_is_reproducible():
     assert err <= 2e-5 * max(1.0, exact.abs().max().item()), err
 
 
-@pytest.mark.parametrize("scale", [1e-12, 1.0, 1e12])
+@pytest.mark.parametrize("scale", [1e-30, 1e-12, 1.0, 1e12])
 def test_dcn_backward_tiled_forms_hold_their_accuracy_at_any_magnitude(scale):
     """The alignment-shape backward scatters grad_input as 64-bit fixed point (scale chosen per workgroup) and contracts the
     weight gradient as split fp16 (scaled per tile / wave): both must keep fp32-grade RELATIVE accuracy whatever the
@@ -429,6 +429,40 @@ def test_dcn_backward_tiled_forms_hold_their_accuracy_at_any_magnitude(scale):
     torch.cuda.synchronize()
     for got, name in ((gi, "grad_input"), (gw, "grad_weight"), (gb, "grad_bias"), (goff, "grad_offset"), (gm, "grad_mask")):
         _close(got.double().cpu().numpy() / scale, ref[name])
+
+
+def test_dcn_backward_tiled_forms_at_the_ends_of_the_float_range():
+    """Two corner cases of the scaled arithmetic (csrc/dcn_bwd.hip): (i) a finite column gradient in [2^120, 2^128) must not
+    take the fixed-point window with a clamped scale (int64 overflow) -- grad_input stays finite and accurate; (ii) tiles of
+    one image whose magnitudes are 2^130 apart: the matrix-core weight gradient's running unit only grows, nothing is
+    multiplied by an infinity."""
+    from cdfo_amd import deform_conv_cuda as ext
+    from oracle.dcn_modules_ref import dcn_backward_ref
+    B, C, Co, H, W, k, s, p, d, g, dg = 1, 16, 24, 40, 37, 3, 1, 1, 1, 1, 4
+    x, w, b, off, msk, go = _bwd_inputs(B, C, Co, H, W, k, s, p, d, g, dg, 777)
+    t = lambda a: torch.from_numpy(a).cuda()  # noqa: E731
+    e = torch.empty(0, device="cuda")
+
+    def run(go_):
+        gi, gw, gb, goff, gm = (torch.zeros_like(t(a)) for a in (x, w, b, off, msk))
+        ext.modulated_deform_conv_cuda_backward(t(x), t(w), t(b), e, t(off), t(msk), e, gi, gw, gb, goff, gm, t(go_), k, k, s, s, p, p,
+                                                d, d, g, dg, True)
+        torch.cuda.synchronize()
+        return gi, gw
+    ref = dcn_backward_ref(x, off, msk, w, go, s, p, d, g, dg)
+    big = np.float32(2.0 ** 121)
+    gi, _ = run(go * big)
+    assert torch.isfinite(gi).all()
+    _close(gi.double().cpu().numpy() / float(big), ref["grad_input"])
+    mixed = go.copy()
+    mixed[:, :, :16] *= np.float32(2.0 ** -65)        # rows 0-15 (their 8-row tiles) tiny, the rest huge
+    mixed[:, :, 16:] *= np.float32(2.0 ** 65)
+    gi, gw = run(mixed)
+    assert torch.isfinite(gi).all() and torch.isfinite(gw).all()
+    go_hi = go.copy()
+    go_hi[:, :, :16] = 0.0                             # what the huge rows alone contribute: the tiny ones are below fp32's resolution
+    ref_hi = dcn_backward_ref(x, off, msk, w, go_hi, s, p, d, g, dg)
+    _close(gw.double().cpu().numpy() / 2.0 ** 65, ref_hi["grad_weight"])
 
 
 def test_dcn_backward_tiled_form_propagates_non_finite_gradients():

@@ -1,5 +1,8 @@
 """Developer tool: summarise rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (separate runs) per kernel symbol.
     python tools/pmc_summary.py <fetch_dir> <write_dir> <out.txt> [--json <out.json> <kernel-substring> <family> <precision>]
+                                                                  [--families <out.json> <precision> <commit>]
+--families writes profiles/traffic_rNN.json in the form bench.py replays: HBM bytes per launch for every kernel family of its
+event profiler (bench.MFMA16 / bench.HBM_FAMILIES map a family to kernel-symbol substrings), with the commit of the run.
 FETCH_SIZE reads 1/2 of the bytes of a 16-B/lane coalesced stream on gfx950 (MI355X_MICROARCH.md, HBM): HBM bytes = 2 * FETCH + WRITE."""
 import csv, glob, json, os, sys
 from collections import defaultdict
@@ -31,6 +34,9 @@ def main():
         fh.write("launches  FETCH_KiB  WRITE_KiB  HBM_MB_per_launch  total_GiB  kernel\n")
         for tot, k, n, f, w in rows[:40]:
             fh.write(f"{n:6d} {f:12.1f} {w:12.1f} {(2 * f + w) * 1024 / 1e6:12.1f} {tot * 1024 / 2**30:10.2f}  {k[:150]}\n")
+    if "--families" in sys.argv:
+        i = sys.argv.index("--families")
+        families(F, Wr, *sys.argv[i + 1:i + 4])
     if "--json" in sys.argv:
         i = sys.argv.index("--json")
         jpath, kern, family, prec = sys.argv[i + 1:i + 5]
@@ -40,6 +46,27 @@ def main():
         json.dump({"kernel": family, "precision": prec, "kernel_symbol_contains": kern, "launches_averaged": [len(fk), len(wk)],
                    "fetch_kib_raw": f, "write_kib_raw": w, "fetch_correction": 2.0, "hbm_bytes_per_launch": round((2.0 * f + w) * 1024.0),
                    "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), tools/pmc_summary.py"}, open(jpath, "w"), indent=1)
+
+
+def families(F, Wr, jpath, prec, commit):
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    fmap = {k: [v[0]] for k, v in bench.MFMA16.items()}
+    fmap.update(bench.HBM_FAMILIES)
+    out = {}
+    for fam, subs in fmap.items():
+        fk = [v for k, vs in F.items() if any(sb in k for sb in subs) for v in vs]
+        wk = [v for k, vs in Wr.items() if any(sb in k for sb in subs) for v in vs]
+        if not fk and not wk:
+            continue
+        n = max(len(fk), len(wk))
+        f, w = sum(fk) / max(1, len(fk)), sum(wk) / max(1, len(wk))
+        out[fam] = {"kernel_symbol_contains": subs, "launches_averaged": [len(fk), len(wk)], "fetch_kib_raw": f, "write_kib_raw": w,
+                    "hbm_bytes_per_launch": round((2.0 * f + w) * 1024.0), "launches": n}
+    json.dump({"precision": prec, "commit": commit, "fetch_correction": 2.0, "families": out,
+               "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) of bench.py, tools/pmc_summary.py --families; HBM bytes "
+                         "= (2 * FETCH_SIZE + WRITE_SIZE) KiB (gfx950: FETCH_SIZE counts half of a 16-B/lane stream, MI355X_MICROARCH.md)"},
+              open(jpath, "w"), indent=1)
 
 
 if __name__ == "__main__":

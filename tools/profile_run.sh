@@ -1,18 +1,21 @@
-# Developer script (GPU box): regenerates the round's profiles/ inputs under gpurun_out/prof/ (separate passes: kernel trace, FETCH_SIZE, WRITE_SIZE)
+# Developer script (GPU box): regenerates the round's profiles/ inputs under gpurun_out/prof/ (separate passes: kernel trace,
+# FETCH_SIZE, WRITE_SIZE).  R = round tag of the file names, COMMIT = the commit the snapshot was taken at (the box has no .git):
+#   gpurun -- "R=r03 COMMIT=$(git rev-parse --short HEAD) bash tools/profile_run.sh"
 set -o pipefail
+R=${R:-r03}; COMMIT=${COMMIT:-unknown}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT && O=gpurun_out/prof && mkdir -p $O
 B="python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-parity --no-extra-modes"
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- $B > $O/stats.log 2>&1 && \
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/fetch -- $B > $O/fetch.log 2>&1 && \
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/write -- $B > $O/write.log 2>&1 && \
-python3 tools/pmc_summary.py $O/fetch $O/write $O/r02_pmc_traffic_c3_fp16x2.txt --json $O/traffic_r02.json "conv3x3_c64_ws_kernel<0, false" conv3x3_ws fp16x2 && \
-cp $O/stats/*/*kernel_stats.csv $O/r02_kernel_stats_c3_fp16x2.csv && \
+python3 tools/pmc_summary.py $O/fetch $O/write $O/${R}_pmc_traffic_c3_fp16x2.txt --families $O/traffic_${R}.json fp16x2 $COMMIT && \
+cp $O/stats/*/*kernel_stats.csv $O/${R}_kernel_stats_c3_fp16x2.csv && \
 D="python3 tools/bench_dcn.py --iters 10" && \
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/dstats -- $D > $O/dstats.log 2>&1 && \
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/dfetch -- $D > $O/dfetch.log 2>&1 && \
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/dwrite -- $D > $O/dwrite.log 2>&1 && \
-python3 tools/pmc_summary.py $O/dfetch $O/dwrite $O/r02_pmc_traffic_dcn_fwd.txt && \
-cp $O/dstats/*/*kernel_stats.csv $O/r02_kernel_stats_dcn_fwd.csv && \
+python3 tools/pmc_summary.py $O/dfetch $O/dwrite $O/${R}_pmc_traffic_dcn_fwd.txt && \
+cp $O/dstats/*/*kernel_stats.csv $O/${R}_kernel_stats_dcn_fwd.csv && \
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/bstats -- python3 tools/bench_dcn.py --backward --iters 5 > $O/bstats.log 2>&1 && \
-cp $O/bstats/*/*kernel_stats.csv $O/r02_kernel_stats_dcn_bwd.csv && \
-python3 tools/phase_times.py 2>&1 | grep -v amdgpu | tail -1 > $O/phases.txt && python3 tools/op_table.py > $O/op_table.txt 2>&1 && cat $O/phases.txt && head -4 $O/r02_pmc_traffic_c3_fp16x2.txt | tail -1 | cut -c1-150
+cp $O/bstats/*/*kernel_stats.csv $O/${R}_kernel_stats_dcn_bwd.csv && \
+python3 tools/phase_times.py 2>&1 | grep -v amdgpu | tail -1 > $O/phases.txt && python3 tools/op_table.py > $O/op_table.txt 2>&1 && cat $O/phases.txt && head -5 $O/${R}_pmc_traffic_c3_fp16x2.txt | tail -1 | cut -c1-150

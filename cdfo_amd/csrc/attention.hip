@@ -281,7 +281,7 @@ template <int MODE, int NW>   // MODE 0: sequence = image row, 1: image column, 
 __global__ __launch_bounds__(NW * 64, NW == 4 ? 3 : 2) void seq_attn_mfma_kernel(const float* __restrict__ q, int ldq,
                                                                 const float* __restrict__ v, int ldv,
                                                                 float* __restrict__ out, int ldo, int B, int H, int W,
-                                                                int nb, int tpb) {
+                                                                int nb, int tpb, int xcd_map) {
   constexpr int KROW = 272;                                 // bytes per staged key row: 128 B hi | 128 B lo | 16 B pad
   constexpr int NT = NW * 64, SUB = NW / 4, KT = 32 * SUB, KQ = KT / 4;
   constexpr int K_BYTES = KT * KROW, V_BYTES = SUB * 64 * 128;
@@ -292,8 +292,15 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 3 : 2) void seq_attn_mfma_kernel
   unsigned char* const sV = attn_smem + 2 * K_BYTES;        // [2][SUB][64][128]
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, h = lane >> 5, r = lane & 31;
   const int L = MODE == 0 ? W : (MODE == 1 ? H : 64);
-  const int blk = blockIdx.x % nb;
-  const long long seq = blockIdx.x / nb;
+  // The nb workgroups of a sequence each stage ALL of its keys / values: give them consecutive slots of ONE XCD (workgroup i
+  // runs on XCD i % 8), so that they run at about the same time behind the same L2 and the sequence leaves HBM once
+  unsigned bid = blockIdx.x;
+  if (xcd_map) {
+    const unsigned q8 = gridDim.x >> 3, r8 = gridDim.x & 7, xcd = bid & 7, idx = bid >> 3;
+    bid = xcd * q8 + (xcd < r8 ? xcd : r8) + idx;
+  }
+  const int blk = bid % nb;
+  const long long seq = bid / nb;
   long long kbase;
   if (MODE == 0) kbase = seq * W;                           // seq = b*H + y
   else if (MODE == 1) { const long long b = seq / W, x = seq - b * W; kbase = b * H * W + x; }
@@ -486,8 +493,9 @@ int seq_attn_launch(const float* q, int ldq, const float* v, int ldv, float* out
   const int ntq = cdiv(L, 32), nb = cdiv(ntq, NW), tpb = cdiv(ntq, nb);
   const long long nseq = MODE == 0 ? (long long)B * H : (MODE == 1 ? (long long)B * W : (long long)B * (H / 8) * (W / 8));
   if (nseq * nb >= (1ll << 31)) return CDFO_EINVAL;
+  static const int xcd_map = []() { const char* e = getenv("CDFO_ATTN_XCD"); return e ? atoi(e) : 1; }();   // developer A/B switch
   hipLaunchKernelGGL((seq_attn_mfma_kernel<MODE, NW>), dim3((unsigned)(nseq * nb)), dim3(NW * 64), LDSB, st, q, ldq, v, ldv,
-                     out, ldo, B, H, W, nb, tpb);
+                     out, ldo, B, H, W, nb, tpb, (nb > 1 && xcd_map) ? 1 : 0);
   return 0;
 }
 

@@ -13,6 +13,7 @@
 // matching weight rows are staged transposed, and the contraction runs on the fp32 matrix cores
 // (v_mfma_f32_32x32x2_f32: M = output channel, N = pixel), so the output tile is written coalesced in NCHW.
 #include "common.h"
+#include <cstdlib>
 
 namespace {
 
@@ -215,6 +216,12 @@ int cdfo_dcn_forward_fast(const float* in, const float* offset, const float* mas
                           hipStream_t st, void (*to_gp)(const float*, float*, int, int, int, long long, unsigned*, hipStream_t),
                           const unsigned** rerun_flag);
 
+// dcn_win.hip
+int cdfo_dcn_forward_win(const float* in, const float* offset, const float* mask, const float* weight, const float* bias,
+                         float* out, int B, int C, int H, int W, int Co, int Ho, int Wo, int kh, int kw, int sh, int sw, int ph,
+                         int pw, int dh, int dw, int groups, int dg, void* workspace, long long workspace_bytes, hipStream_t st,
+                         const unsigned** rerun_flag);
+
 extern "C" int cdfo_dcn_forward(const float* in, const float* offset, const float* mask, const float* weight,
                                 const float* bias, float* out, int B, int C, int H, int W, int Co, int kh, int kw, int sh,
                                 int sw, int ph, int pw, int dh, int dw, int groups, int deformable_groups, void* workspace,
@@ -247,6 +254,17 @@ extern "C" int cdfo_dcn_forward(const float* in, const float* offset, const floa
   CdfoProfScope prof(st, KID_DCN, 2.0 * px * Co * (C / groups) * T,
                      4.0 * (px * (Co + 3.0 * deformable_groups * T) + (double)B * C * H * W + (double)Co * (C / groups) * T));
   const unsigned* rerun = nullptr;
+  // (1) window-sampled kernel (dcn_win.hip): 3x3 / stride 1 / dilation 1 shapes of the alignment module's kind
+  static const int use_win = []() { const char* e = getenv("CDFO_DCN_WIN"); return e ? atoi(e) : 1; }();     // developer A/B switch
+  const int win = use_win ? cdfo_dcn_forward_win(in, offset, mask, weight, bias, out, B, C, H, W, Co, Ho, Wo, kh, kw, sh, sw, ph, pw,
+                                                 dh, dw, groups, deformable_groups, workspace, workspace_bytes, st, &rerun) : 0;
+  if (win > 1) return win - 2;
+  if (win == 1) {      // range-safety re-run as below, from the NCHW input (this path makes no group-planar copy)
+    a.run_if = rerun;
+    hipLaunchKernelGGL(dcn_fwd_kernel<false>, grid, dim3(256), lds, st, a, KCH);
+    CDFO_LAUNCH_CHECK();
+    return 0;
+  }
   const int fast = cdfo_dcn_forward_fast(in, offset, mask, weight, bias, out, B, C, H, W, Co, Ho, Wo, kh, kw, sh, sw, ph, pw, dh,
                                          dw, groups, deformable_groups, workspace, workspace_bytes, st, &launch_to_gp, &rerun);
   if (fast > 1) return fast - 2;

@@ -260,8 +260,9 @@ __global__ __launch_bounds__(DT_THREADS) void dcn_bwd_data_tile_kernel(DcnBwdArg
     int ex = 0;
     if (amax > 0.f && amax < INFINITY) frexpf(amax, &ex);              // amax < 2^ex
     // fixed point only while 2^(48 - ex) is a representable scale: a finite maximum in [2^120, 2^128) would be scaled by the
-    // CLAMPED exponent and overflow the 63-bit sums -> such a workgroup takes the float path like a non-finite one
-    fx_ok = amax < INFINITY && ex <= 120;
+    // CLAMPED exponent and overflow the 63-bit sums, one below 2^-60 would keep fewer than 48 bits (measured: 1.7 % error at
+    // |grad_output| ~ 1e-30) -> such a workgroup takes the float path like a non-finite one
+    fx_ok = amax < INFINITY && ex <= 120 && ex >= -60;
     ex = ex < -60 ? -60 : (ex > 120 ? 120 : ex);
     fx_scale = ldexpf(1.f, 48 - ex);
     fx_inv = ldexpf(1.f, ex - 48);     // !fx_ok: every sample goes straight to global memory as a float (NaN / inf propagate)

@@ -222,6 +222,74 @@ def test_dcn_forward_workspace_paths_agree_with_the_oracle():
             assert np.abs(out.cpu().numpy() - ref1).max() <= 2e-5 * max(1.0, np.abs(ref1).max()), n
 
 
+WIN_CASES = [
+    # B, C, Co, H, W, pad, dg, modulated, far   (3x3, stride 1, dilation 1: the window-sampled kernel, csrc/dcn_win.hip)
+    (2, 64, 64, 37, 70, 1, 16, True, True),       # W % 4 != 0 (scalar window staging), ragged 8x32 tiles, far offsets -> global fallback
+    (1, 12, 32, 23, 64, 2, 3, True, True),        # three 4-channel blocks (last chunk half empty), Co = 32, pad 2, aligned rows
+    (1, 32, 64, 41, 96, 1, 4, False, False),      # 8 channels per deformable group (two blocks share one offset field), DCNv1
+    (1, 64, 64, 272, 480, 1, 16, True, False),    # one c3 frame: every tile position incl. all four borders
+]
+
+
+@pytest.mark.parametrize("B,C,Co,H,W,pad,dg,mod,far", WIN_CASES)
+def test_dcn_window_kernel_matches_oracle(B, C, Co, H, W, pad, dg, mod, far):
+    """cdfo_dcn_forward with a workspace at the shapes the window-sampled kernel takes, against the C oracle: offsets mostly
+    within the staged window, a share beyond it (10-300 pixels: the lane's own global gather), positions straddling every image
+    border, channel planes of very different magnitudes (the per-chunk power-of-two scale)."""
+    import ctypes as C_
+    from cdfo_amd import _lib
+    lib = _lib.lib()
+    rs = np.random.RandomState(C * 100 + W)
+    Ho, Wo = H + 2 * pad - 2, W + 2 * pad - 2
+    x = rs.standard_normal((B, C, H, W)).astype(np.float32)
+    x *= np.float32(10.0) ** rs.randint(-3, 4, size=(1, C, 1, 1)).astype(np.float32)          # 1e-3 ... 1e3 per channel plane
+    w = (rs.standard_normal((Co, C, 3, 3)) / np.sqrt(C * 9)).astype(np.float32)
+    b = rs.standard_normal((Co,)).astype(np.float32) if mod else None
+    off = (rs.standard_normal((B, 2 * dg * 9, Ho, Wo)) * 3.0).astype(np.float32)
+    if far:
+        sel = rs.uniform(size=off.shape) < 0.02
+        off[sel] = (rs.uniform(-1, 1, size=int(sel.sum())) * rs.choice([12.0, 40.0, 300.0], size=int(sel.sum()))).astype(np.float32)
+    msk = rs.uniform(0, 1, (B, dg * 9, Ho, Wo)).astype(np.float32) if mod else None
+    ref = dcn_forward_ref(x, off, msk, w, b, 1, pad, 1, 1, dg)
+    t = lambda a: None if a is None else torch.from_numpy(a).cuda()  # noqa: E731
+    p = lambda v: C_.c_void_p(None if v is None else v.data_ptr())  # noqa: E731
+    need = int(lib.cdfo_dcn_workspace_bytes(B, C, H, W, Co, 3, 3, 1, dg))
+    assert need > 0
+    tx, toff, tm, tw, tb = t(x), t(off), t(msk), t(w), t(b)
+    ws = torch.empty(need, dtype=torch.uint8, device="cuda")
+    outs = []
+    for _ in range(2):
+        out = torch.full((B, Co, Ho, Wo), float("nan"), device="cuda")
+        _lib.check(lib.cdfo_dcn_forward(p(tx), p(toff), p(tm), p(tw), p(tb), p(out), B, C, H, W, Co, 3, 3, 1, 1, pad, pad, 1, 1, 1, dg,
+                                        p(ws), C_.c_longlong(need), None), "cdfo_dcn_forward")
+        torch.cuda.synchronize()
+        outs.append(out)
+    assert torch.equal(outs[0], outs[1])                                 # no atomics on the data path: bit-reproducible
+    err = np.abs(outs[0].cpu().numpy() - ref).max()
+    assert err <= 2e-5 * max(1.0, np.abs(ref).max()), err
+
+
+def test_dcn_window_kernel_range_safety():
+    """Masks far outside [0, 1] push sampled values beyond the scaled fp16 hi + lo range: the kernel must raise its re-run flag
+    and the exact-fp32 kernel's result must come back; tiny and huge inputs keep their relative accuracy without it."""
+    from cdfo_amd.dcn import modulated_deform_conv
+    rs = np.random.RandomState(5)
+    B, C, Co, H, W, dg = 1, 64, 64, 24, 40, 16
+    x = rs.standard_normal((B, C, H, W)).astype(np.float32)
+    w = (rs.standard_normal((Co, C, 3, 3)) / 24).astype(np.float32)
+    b = rs.standard_normal((Co,)).astype(np.float32)
+    off = (rs.standard_normal((B, 2 * dg * 9, H, W)) * 2.0).astype(np.float32)
+    msk = rs.uniform(0, 1, (B, dg * 9, H, W)).astype(np.float32)
+    t = lambda a: torch.from_numpy(a).cuda()  # noqa: E731
+    for scale, mscale in ((1e-20, 1.0), (1e20, 1.0), (1.0, 1e5), (1.0, -3e6)):
+        xs, ms = x * np.float32(scale), msk * np.float32(mscale)
+        ref = dcn_forward_ref(xs, off, ms, w, b * np.float32(0), 1, 1, 1, 1, dg)
+        with torch.no_grad():
+            out = modulated_deform_conv(t(xs), t(off), t(ms), t(w), t(b * np.float32(0)), 1, 1, 1, 1, dg).cpu().numpy()
+        err = np.abs(out - ref).max()
+        assert np.isfinite(out).all() and err <= 2e-5 * np.abs(ref).max(), (scale, mscale, err, np.abs(ref).max())
+
+
 def test_dcn_non_finite_offsets_sample_nothing():
     """Offsets that are inf / NaN fail the validity test (cu:617) like any out-of-range position: the tap contributes 0,
     forward and backward, on every kernel variant -- and nothing converts a non-finite float to an index."""

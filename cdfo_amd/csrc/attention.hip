@@ -40,7 +40,8 @@ __global__ __launch_bounds__(256) void rdab_prep_kernel(const float* __restrict_
                                                         long long P, float* __restrict__ sq, int lds_,
                                                         float* __restrict__ vrow, int ldv, float* __restrict__ qwin,
                                                         int ldw, unsigned long long seed, unsigned draw,
-                                                        float* __restrict__ noise_out) {
+                                                        float* __restrict__ noise_out,
+                                                        const unsigned long long* __restrict__ seed_dev) {
   __shared__ float z[64 * ZS];
   __shared__ float mq[64 * QS];
   __shared__ float vv[64 * QS];
@@ -49,6 +50,7 @@ __global__ __launch_bounds__(256) void rdab_prep_kernel(const float* __restrict_
   const long long b = p0 / P, pin = p0 - b * P;
   // phase 1: logits z[i][c] = vmax[c] - log(-log(u))   (coalesced along pixels)
   if (RNG) {
+    if (seed_dev) seed = *seed_dev;                // key in device memory (graph replays: rewritten between replays)
     const int i = tid & 63;
     for (int j = tid >> 6; j < 16; j += 4) {       // channel group j = channels 4j .. 4j+3 of pixel i
       unsigned o[4];
@@ -508,7 +510,7 @@ extern "C" int cdfo_rdab_prep(const float* xq, int ldx, const float* vmax, const
   if (!aligned16(xq) || !aligned16(sq) || !aligned16(vrow) || !aligned16(qwin)) return CDFO_EALIGN;
   CdfoProfScope prof(static_cast<hipStream_t>(stream), KID_RDAB_PREP, 0, 4.0*(128+64+192)*(double)B*P);
   hipLaunchKernelGGL(rdab_prep_kernel<false>, dim3((unsigned)(B * P / 64)), dim3(256), 0, static_cast<hipStream_t>(stream), xq,
-                     ldx, vmax, noise, wW, bW, P, sq, lds_, vrow, ldv, qwin, ldw, 0ull, 0u, nullptr);
+                     ldx, vmax, noise, wW, bW, P, sq, lds_, vrow, ldv, qwin, ldw, 0ull, 0u, nullptr, nullptr);
   CDFO_LAUNCH_CHECK();
   return 0;
 }
@@ -523,7 +525,20 @@ extern "C" int cdfo_rdab_prep_rng(const float* xq, int ldx, const float* vmax, l
   CdfoProfScope prof(static_cast<hipStream_t>(stream), KID_RDAB_PREP, 0, 4.0*(128+192)*(double)B*P);
   hipLaunchKernelGGL(rdab_prep_kernel<true>, dim3((unsigned)(B * P / 64)), dim3(256), 0, static_cast<hipStream_t>(stream), xq,
                      ldx, vmax, nullptr, wW, bW, P, sq, lds_, vrow, ldv, qwin, ldw, (unsigned long long)seed, (unsigned)draw,
-                     noise_out);
+                     noise_out, nullptr);
+  CDFO_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int cdfo_rdab_prep_rng_dev(const float* xq, int ldx, const float* vmax, const void* seed_dev, int draw, float* noise_out,
+                                      const float* wW, const float* bW, int B, long long P, float* sq, int lds_, float* vrow,
+                                      int ldv, float* qwin, int ldw, void* stream) {
+  if (B <= 0 || P <= 0 || P % 64 || P >= (1ll << 32) || ldx % 4 || lds_ % 4 || ldv % 4 || ldw % 4 || !seed_dev) return CDFO_EINVAL;
+  if (!aligned16(xq) || !aligned16(sq) || !aligned16(vrow) || !aligned16(qwin) || (reinterpret_cast<uintptr_t>(seed_dev) & 7u)) return CDFO_EALIGN;
+  CdfoProfScope prof(static_cast<hipStream_t>(stream), KID_RDAB_PREP, 0, 4.0*(128+192)*(double)B*P);
+  hipLaunchKernelGGL(rdab_prep_kernel<true>, dim3((unsigned)(B * P / 64)), dim3(256), 0, static_cast<hipStream_t>(stream), xq,
+                     ldx, vmax, nullptr, wW, bW, P, sq, lds_, vrow, ldv, qwin, ldw, 0ull, (unsigned)draw, noise_out,
+                     static_cast<const unsigned long long*>(seed_dev));
   CDFO_LAUNCH_CHECK();
   return 0;
 }

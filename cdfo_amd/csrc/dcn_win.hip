@@ -63,7 +63,7 @@ __global__ __launch_bounds__(256) void dcn_win_wmax_kernel(const float* __restri
 }
 
 // one thread per fp16 element: gid = ((((chunk*5 + s)*MJ + mj)*2 + hl)*64 + lane)*8 + e.  K row 8*(lane>>5) + e of step s is
-// item i = 4 s + 2 (lane>>5) + (e>>2), channel e&3: block (i >= 9), tap i % 9 -> input channel 8 chunk + 4 block + (e&3)
+// block (lane>>5) of the chunk, tap 2 s + (e>>2) (tap 9 = the zero pad), channel e&3 -> input channel 8 chunk + 4 block + (e&3)
 __global__ __launch_bounds__(256) void dcn_win_pack_kernel(const float* __restrict__ w, const unsigned* __restrict__ wmax,
                                                            _Float16* __restrict__ wp, int C, int Co, int MJ, long long n) {
   const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
@@ -71,19 +71,29 @@ __global__ __launch_bounds__(256) void dcn_win_pack_kernel(const float* __restri
   const int e = (int)(gid & 7), lane = (int)((gid >> 3) & 63), hl = (int)((gid >> 9) & 1);
   const long long r = gid >> 10;
   const int mj = (int)(r % MJ), s = (int)((r / MJ) % WN_STEPS), chunk = (int)(r / ((long long)MJ * WN_STEPS));
-  const int i = 4 * s + 2 * (lane >> 5) + (e >> 2), blk = i >= WN_T ? 1 : 0, t = i - WN_T * blk;
+  const int blk = lane >> 5, t = 2 * s + (e >> 2);
   const int c = 8 * chunk + 4 * blk + (e & 3), m = mj * 32 + (lane & 31);
   float v = 0.f;
-  if (i < 2 * WN_T && c < C && m < Co) v = w[((long long)m * C + c) * WN_T + t] * wn_pow2_scale(wmax[0]);
+  if (t < WN_T && c < C && m < Co) v = w[((long long)m * C + c) * WN_T + t] * wn_pow2_scale(wmax[0]);
   const _Float16 h = (_Float16)v;
   wp[gid] = hl ? (_Float16)(v - (float)h) : h;
 }
 
-template <int MJ, bool AL4>     // MJ: 32-channel output tiles (Co = 32 MJ); AL4: W % 4 == 0 and a 16-byte aligned input
+__device__ __forceinline__ float wn_bload(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)voff, (int)soff, 0));
+}
+__device__ __forceinline__ f32x4 wn_bload4(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  return __builtin_bit_cast(f32x4, (u32x4)__builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, 0));
+}
+
+// MJ: 32-channel output tiles (Co = 32 MJ); AL4: W % 4 == 0 and a 16-byte aligned input; MASK: modulated (DCNv2)
+template <int MJ, bool AL4, bool MASK>
 __global__ __launch_bounds__(WN_THREADS) void dcn_win_kernel(WinArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int WTS = WN_STEPS * MJ * 2 * 1024;                 // packed weights of one chunk
   constexpr int WSLOTS = WTS / 16, WLD = (WSLOTS + WN_THREADS - 1) / WN_THREADS;
+  constexpr unsigned OOR = 0x80000000u;                          // buffer offset past every descriptor: the load returns zeros
   unsigned char* const sWin = smem;                              // [2 buffers][2 blocks][WN_WIN]
   unsigned char* const sWt = smem + 4 * WN_WIN;                  // [2 buffers][WTS]
   float* const sMax = reinterpret_cast<float*>(smem + 4 * WN_WIN + 2 * WTS);      // [2 buffers][8 waves]
@@ -103,29 +113,23 @@ __global__ __launch_bounds__(WN_THREADS) void dcn_win_kernel(WinArgs a) {
   const bool pvalid = oy < a.Ho && ox < a.Wo;
   const int p = pvalid ? oy * a.Wo + ox : 0;
   const float hb = (float)(oy - a.ph), wb = (float)(ox - a.pw);
-  const float* const in_b = a.in + (long long)b * a.C * HW;
-  const float* const off_b = a.offset + (long long)b * a.dg * 2 * WN_T * P + p;
-  const float* const msk_b = a.mask ? a.mask + (long long)b * a.dg * WN_T * P + p : nullptr;
   const int cdg4 = (a.C / a.dg) >> 2;                            // 4-channel blocks per deformable group
+  // per-image buffer descriptors (wave-uniform): 32-bit lane offsets + scalar offsets, hardware zero fill out of range
+  const float* const in_b = a.in + (long long)b * a.C * HW;
+  const __amdgpu_buffer_rsrc_t r_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(in_b), 0, a.C * HW * 4, 0x00020000);
+  const __amdgpu_buffer_rsrc_t r_off = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(a.offset + (long long)b * a.dg * 2 * WN_T * P), 0, a.dg * 2 * WN_T * P * 4, 0x00020000);
+  const __amdgpu_buffer_rsrc_t r_msk = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(MASK ? a.mask + (long long)b * a.dg * WN_T * P : a.offset), 0, a.dg * WN_T * P * 4, 0x00020000);
 
-  // ---- this lane's ten items of a chunk: k = 2 s + j -> item i = 4 s + 2 half + j
-  int it_t[2 * WN_STEPS], it_blk[2 * WN_STEPS];
-  float it_h[2 * WN_STEPS], it_w[2 * WN_STEPS];
-#pragma unroll
-  for (int k = 0; k < 2 * WN_STEPS; ++k) {
-    const int i = 4 * (k >> 1) + 2 * half + (k & 1);
-    it_blk[k] = i >= WN_T ? 1 : 0;
-    const int t = i - WN_T * it_blk[k];
-    it_t[k] = i < 2 * WN_T ? t : -1;
-    const int ki = t / 3;
-    it_h[k] = (float)ki;
-    it_w[k] = (float)(t - 3 * ki);
-  }
+  // ---- the chunk's two 4-channel blocks belong to the two half-waves: lanes 0-31 sample block 0, lanes 32-63 block 1, both at
+  // taps (2 s, 2 s + 1) in K step s (tap 9 of step 4 is a zero pad: skipped at compile time).  Taps are compile-time constants
+  // and the block only enters through per-lane byte offsets that change once per chunk.
 
   // ---- staging tasks of this thread: (block, window row, quad)
-  int tk_off[WN_NTASK], tk_lds[WN_NTASK], tk_blk[WN_NTASK];
-  bool tk_on[WN_NTASK], tk_in[WN_NTASK];
-  bool tk_el[WN_NTASK][4];
+  unsigned tk_vo[WN_NTASK][AL4 ? 1 : 4];      // byte offset inside a channel plane, OOR where the image ends
+  int tk_lds[WN_NTASK], tk_blk[WN_NTASK];
+  bool tk_on[WN_NTASK];
 #pragma unroll
   for (int q = 0; q < WN_NTASK; ++q) {
     const int task = tid + q * WN_THREADS;
@@ -135,54 +139,54 @@ __global__ __launch_bounds__(WN_THREADS) void dcn_win_kernel(WinArgs a) {
     const int gy = wy0 + r, gx = wx0 + 4 * qx;
     tk_blk[q] = blk;
     tk_lds[q] = blk * WN_WIN + (r * WN_WW + 4 * qx) * 16;
-    const bool row_in = gy >= 0 && gy < H;
-    tk_in[q] = tk_on[q] && row_in && gx >= 0 && gx + 3 < W;
+    const bool row_in = tk_on[q] && gy >= 0 && gy < H;
+    // (the task's block enters through the LANE offset: the scalar offset of a buffer load must be wave-uniform, and a wave's
+    // tasks straddle the two blocks -- a per-lane scalar would make the compiler emit a waterfall loop)
+    const unsigned blk_off = (unsigned)(blk * 4 * HW) * 4u;
+    if (AL4) {
+      tk_vo[q][0] = (row_in && gx >= 0 && gx + 3 < W) ? (unsigned)(gy * W + gx) * 4u + blk_off : OOR;
+    } else {
 #pragma unroll
-    for (int e = 0; e < 4; ++e) tk_el[q][e] = tk_on[q] && row_in && gx + e >= 0 && gx + e < W;
-    tk_off[q] = (row_in ? gy : 0) * W + gx;
+      for (int x = 0; x < 4; ++x)
+        tk_vo[q][AL4 ? 0 : x] = (row_in && gx + x >= 0 && gx + x < W) ? (unsigned)(gy * W + gx + x) * 4u + blk_off : OOR;
+    }
   }
-  f32x4 wr[WN_NTASK][4];       // prefetched window values: [task][channel] = 4 consecutive pixels
-  wn_h8 wtr[WLD];              // prefetched packed weights
-  auto fetch = [&](int chunk) {
+  // Register budget: with one 512-thread workgroup per CU a wave may use 256 VGPRs, and a single spill is ruinous here --
+  // scratch reloads count in vmcnt, so waiting for one drains every prefetch in flight.  Hence the ROLLING prefetch below: a
+  // window task / a tap's offsets are re-requested right after their last use, into the registers that use just freed; and
+  // nothing but the write to LDS (half a chunk later) consumes a fetched register.
+  wn_h8 wtr[WLD];              // prefetched packed weights of the next chunk
+  auto fetch_task = [&](int chunk, int q, f32x4 (&wr)[4]) {
+    const bool blk_ok = 8 * chunk + 4 * tk_blk[q] < a.C;      // per lane (C % 8 == 4: the last chunk has one block)
 #pragma unroll
-    for (int q = 0; q < WN_NTASK; ++q) {
-      const int c0 = 8 * chunk + 4 * tk_blk[q];
+    for (int e = 0; e < 4; ++e) {
+      const unsigned so = (unsigned)((8 * chunk + e) * HW) * 4u;     // wave-uniform
+      if (AL4) {
+        wr[e] = wn_bload4(r_in, blk_ok ? tk_vo[q][0] : OOR, so);
+      } else {
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (c0 + e < a.C) {
-          const float* src = in_b + (long long)(c0 + e) * HW + tk_off[q];
-          if (AL4) {
-            if (tk_in[q]) v = *reinterpret_cast<const f32x4*>(src);
-          } else {
-#pragma unroll
-            for (int x = 0; x < 4; ++x)
-              if (tk_el[q][x]) v[x] = src[x];
-          }
-        }
-        wr[q][e] = v;
+        for (int x = 0; x < 4; ++x) wr[e][x] = wn_bload(r_in, blk_ok ? tk_vo[q][AL4 ? 0 : x] : OOR, so);
       }
     }
+  };
+  auto commit_task = [&](int buf, int q, const f32x4 (&wr)[4], float& m) {      // registers -> window buffer `buf`; m = running |max|
+    if (tk_on[q]) {
+#pragma unroll
+      for (int x = 0; x < 4; ++x) {
+        const f32x4 v = {wr[0][x], wr[1][x], wr[2][x], wr[3][x]};
+        *reinterpret_cast<f32x4*>(sWin + buf * 2 * WN_WIN + tk_lds[q] + x * 16) = v;
+        m = fmaxf(fmaxf(m, fabsf(v[0])), fmaxf(fabsf(v[1]), fmaxf(fabsf(v[2]), fabsf(v[3]))));     // (NaN ignored; inf: see the scale)
+      }
+    }
+  };
+  auto fetch_weights = [&](int chunk) {
 #pragma unroll
     for (int i = 0; i < WLD; ++i) {
       const int slot = tid + i * WN_THREADS;
-      if (slot < WSLOTS) wtr[i] = a.wp[(long long)chunk * WSLOTS + slot];
+      wtr[i] = a.wp[(unsigned)(chunk * WSLOTS + (slot < WSLOTS ? slot : 0))];
     }
   };
-  auto commit = [&](int buf) {      // registers -> LDS buffer `buf` (+ this wave's window maximum)
-    float m = 0.f;
-#pragma unroll
-    for (int q = 0; q < WN_NTASK; ++q) {
-      if (tk_on[q]) {
-#pragma unroll
-        for (int x = 0; x < 4; ++x) {
-          const f32x4 v = {wr[q][0][x], wr[q][1][x], wr[q][2][x], wr[q][3][x]};
-          *reinterpret_cast<f32x4*>(sWin + buf * 2 * WN_WIN + tk_lds[q] + x * 16) = v;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) { const float av = fabsf(v[e]); m = av < 3.0e38f ? fmaxf(m, av) : m; }
-        }
-      }
-    }
+  auto commit_weights = [&](int buf, float m) {
 #pragma unroll
     for (int i = 0; i < WLD; ++i) {
       const int slot = tid + i * WN_THREADS;
@@ -192,23 +196,21 @@ __global__ __launch_bounds__(WN_THREADS) void dcn_win_kernel(WinArgs a) {
     if (lane == 0) sMax[buf * 8 + wave] = m;
   };
 
-  // ---- offsets / mask of a chunk's ten items (prefetched one chunk ahead)
-  float noh[2 * WN_STEPS], now_[2 * WN_STEPS], nmk[2 * WN_STEPS];
-  bool nlive[2 * WN_STEPS];
-  auto load_offsets = [&](int chunk) {
-    const int d0 = (2 * chunk) / cdg4, d1 = (2 * chunk + 1) / cdg4;
-#pragma unroll
-    for (int k = 0; k < 2 * WN_STEPS; ++k) {
-      const bool live = pvalid && it_t[k] >= 0 && 8 * chunk + 4 * it_blk[k] < a.C;
-      nlive[k] = live;
-      noh[k] = now_[k] = 0.f; nmk[k] = 1.f;
-      if (live) {
-        const int ot = (it_blk[k] ? d1 : d0) * WN_T + it_t[k];          // per-image indices fit 32 bits (checked by the launcher)
-        noh[k] = off_b[(long long)(ot * 2) * P];
-        now_[k] = off_b[(long long)(ot * 2 + 1) * P];
-        if (msk_b) nmk[k] = msk_b[(long long)ot * P];
-      }
-    }
+  // ---- offsets / mask of the lane's nine taps: lane byte offset = (its block's deformable group, its pixel), scalar = the tap
+  float oh[WN_T], ow[WN_T], mk[WN_T];
+  auto lane_offsets = [&](int chunk, unsigned& vo_off, unsigned& vo_msk, bool& alive) {
+    int d0 = (2 * chunk) / cdg4, d1 = (2 * chunk + 1) / cdg4;
+    d0 = d0 < a.dg ? d0 : a.dg - 1;
+    d1 = d1 < a.dg ? d1 : a.dg - 1;
+    const int d = half ? d1 : d0;
+    alive = pvalid && 8 * chunk + 4 * half < a.C;
+    vo_off = (unsigned)(d * 2 * WN_T * P + p) * 4u;          // dead lanes read a valid address and are ignored
+    vo_msk = (unsigned)(d * WN_T * P + p) * 4u;
+  };
+  auto load_tap = [&](unsigned vo_off, unsigned vo_msk, int t, float& o_h, float& o_w, float& m_k) {
+    o_h = wn_bload(r_off, vo_off, (unsigned)(2 * t * P) * 4u);
+    o_w = wn_bload(r_off, vo_off, (unsigned)((2 * t + 1) * P) * 4u);
+    m_k = MASK ? wn_bload(r_msk, vo_msk, (unsigned)(t * P) * 4u) : 1.f;
   };
 
   f32x16 acc[MJ];
@@ -219,19 +221,40 @@ __global__ __launch_bounds__(WN_THREADS) void dcn_win_kernel(WinArgs a) {
   int e_run = -100000;          // binary exponent of the accumulators' unit: sampled values are scaled by 2^(3 - e_run)
   unsigned ovfbits = 0;
 
-  fetch(0);
-  load_offsets(0);
-  commit(0);
+  {   // prologue: chunk 0 into buffer 0
+    float m = 0.f;
+    f32x4 w0[4];
+#pragma unroll
+    for (int q = 0; q < WN_NTASK; ++q) {
+      fetch_task(0, q, w0);
+      commit_task(0, q, w0, m);
+    }
+    fetch_weights(0);
+    unsigned vo, vm;
+    bool al;
+    lane_offsets(0, vo, vm, al);
+#pragma unroll
+    for (int t = 0; t < WN_T; ++t) load_tap(vo, vm, t, oh[t], ow[t], mk[t]);
+    commit_weights(0, m);
+  }
   const int nch = a.nchunks;
+  const float fH = (float)H, fW = (float)W;
+  const unsigned char* const win_lane = sWin + half * WN_WIN;
   for (int chunk = 0; chunk < nch; ++chunk) {
     const int buf = chunk & 1;
+    const bool more = chunk + 1 < nch;
+    unsigned vo_c, vm_c, vo_n, vm_n;      // lane offsets of this chunk (cold path) and of the next one (rolling prefetch)
+    bool alive, alive_n;
+    lane_offsets(chunk, vo_c, vm_c, alive);
+    lane_offsets(more ? chunk + 1 : chunk, vo_n, vm_n, alive_n);
     __syncthreads();            // buffer `buf` is complete; nobody still reads the other one
     // ---- this chunk's power-of-two scale from its window maximum
     float M = sMax[buf * 8];
 #pragma unroll
     for (int i = 1; i < 8; ++i) M = fmaxf(M, sMax[buf * 8 + i]);
     int e_c = -100;
-    if (M > 0.f) { frexpf(M, &e_c); e_c = e_c < -100 ? -100 : (e_c > 100 ? 100 : e_c); }       // M < 2^e_c
+    if (M > 0.f && M < INFINITY) { frexpf(M, &e_c); e_c = e_c < -100 ? -100 : (e_c > 100 ? 100 : e_c); }       // M < 2^e_c
+    else if (M > 0.f) e_c = 100;      // an infinity in the window: whatever samples it overflows the halves -> re-run flag
     if (e_c > e_run) {
       const int de = e_run - e_c;
       const float f = ldexpf(1.f, de < -200 ? -200 : de);          // <= 1 (0 for the first chunk: the sums are zero)
@@ -242,80 +265,129 @@ __global__ __launch_bounds__(WN_THREADS) void dcn_win_kernel(WinArgs a) {
       e_run = e_c;
     }
     const float s_in = ldexpf(1.f, 3 - e_run);
-    // ---- current offsets; next chunk's window / weights / offsets go in flight behind them
-    float oh[2 * WN_STEPS], ow[2 * WN_STEPS], mk[2 * WN_STEPS];
-    bool live[2 * WN_STEPS];
-#pragma unroll
-    for (int k = 0; k < 2 * WN_STEPS; ++k) { oh[k] = noh[k]; ow[k] = now_[k]; mk[k] = nmk[k]; live[k] = nlive[k]; }
-    if (chunk + 1 < nch) {
-      fetch(chunk + 1);
-      load_offsets(chunk + 1);
-    }
-    const unsigned char* const win = sWin + buf * 2 * WN_WIN;
+    const unsigned char* const win = win_lane + buf * 2 * WN_WIN;
     const unsigned char* const wt = sWt + buf * WTS + lane * 16;
-#pragma unroll
-    for (int s = 0; s < WN_STEPS; ++s) {
-      float val[8];
-#pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        const int k = 2 * s + j;
-        const float h_im = hb + it_h[k] + oh[k], w_im = wb + it_w[k] + ow[k];
-        const bool valid = live[k] && h_im > -1.f && w_im > -1.f && h_im < (float)H && w_im < (float)W;      // cu:617
-        const float hs = valid ? h_im : 0.f, ws = valid ? w_im : 0.f;
-        const float fh = floorf(hs), fw = floorf(ws);
-        const int hl = (int)fh, wl = (int)fw;
-        const float lh = hs - fh, lw = ws - fw, hh = 1.f - lh, hw = 1.f - lw;
-        const int ly = hl - wy0, lx = wl - wx0;
-        const bool inwin = ly >= 0 && ly < WN_WH - 1 && lx >= 0 && lx < WN_WW - 1;
-        f32x4 v1, v2, v3, v4;
-        if (__builtin_expect(valid && !inwin, 0)) {
-          // beyond the window: this lane gathers its four corners from global memory (zero outside the image, cu:481-488)
-          const int c0 = 8 * chunk + 4 * it_blk[k];
-          const bool r0 = hl >= 0, r1 = hl + 1 <= H - 1, q0 = wl >= 0, q1 = wl + 1 <= W - 1;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const float* pl = in_b + (long long)(c0 + e) * HW;
-            v1[e] = (r0 && q0) ? pl[hl * W + wl] : 0.f;
-            v2[e] = (r0 && q1) ? pl[hl * W + wl + 1] : 0.f;
-            v3[e] = (r1 && q0) ? pl[(hl + 1) * W + wl] : 0.f;
-            v4[e] = (r1 && q1) ? pl[(hl + 1) * W + wl + 1] : 0.f;
-          }
-        } else {
-          const int o = (valid ? (ly * WN_WW + lx) * 16 : 0) + it_blk[k] * WN_WIN;
-          v1 = *reinterpret_cast<const f32x4*>(win + o);
-          v2 = *reinterpret_cast<const f32x4*>(win + o + 16);
-          v3 = *reinterpret_cast<const f32x4*>(win + o + WN_WW * 16);
-          v4 = *reinterpret_cast<const f32x4*>(win + o + WN_WW * 16 + 16);
-        }
-        const float w1 = hh * hw, w2 = hh * lw, w3 = lh * hw, w4 = lh * lw;
-        const float ms = mk[k] * s_in;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const float sv = (w1 * v1[e] + w2 * v2[e] + w3 * v3[e] + w4 * v4[e]) * ms;
-          val[4 * j + e] = valid ? sv : 0.f;
-        }
-      }
+    unsigned fbmask = 0;                 // taps of this lane whose corners leave the window (redone below from global memory)
+    typedef __fp16 hp2 __attribute__((ext_vector_type(2)));
+    auto split_mma = [&](const float (&val)[8], const wn_h8 (&Ah)[MJ], const wn_h8 (&Al)[MJ]) {
       // fp16 hi + lo with the packed round-toward-zero conversion (hi truncated, lo = the exact remainder truncated)
-      typedef __fp16 hp2 __attribute__((ext_vector_type(2)));
       union { hp2 h[4]; wn_h8 v8; } uh, ul;
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         uh.h[q] = __builtin_amdgcn_cvt_pkrtz(val[2 * q], val[2 * q + 1]);
-        ul.h[q] = __builtin_amdgcn_cvt_pkrtz(val[2 * q] - (float)uh.h[q][0], val[2 * q + 1] - (float)uh.h[q][1]);
+        ul.h[q] = __builtin_amdgcn_cvt_pkrtz(__builtin_fmaf((float)uh.h[q][0], -1.f, val[2 * q]),
+                                             __builtin_fmaf((float)uh.h[q][1], -1.f, val[2 * q + 1]));      // (v_fma_mix_f32)
         union { hp2 h; unsigned u; } cv;       // range check on the CONVERTED halves (see dcn_fast.hip): >= 0x7bff, inf, NaN
         cv.h = uh.h[q];
         ovfbits |= ((cv.u & 0x7fff7fffu) + 0x04010401u) & 0x80008000u;
       }
 #pragma unroll
+      for (int j = 0; j < MJ; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah[j], uh.v8, acc[j], 0, 0, 0);
+#pragma unroll
+      for (int j = 0; j < MJ; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Al[j], uh.v8, acc[j], 0, 0, 0);
+#pragma unroll
+      for (int j = 0; j < MJ; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah[j], ul.v8, acc[j], 0, 0, 0);
+    };
+    // next chunk's window: task 0 is requested now and written after step 2, task 1 then and written after step 4 (16 staging
+    // registers at a time); its packed weights ride along
+    float wmax_n = 0.f;
+    f32x4 wr[4];
+    if (more) {
+      fetch_task(chunk + 1, 0, wr);
+      fetch_weights(chunk + 1);
+    }
+#pragma unroll
+    for (int s = 0; s < WN_STEPS; ++s) {
+      wn_h8 Ah[MJ], Al[MJ];
+#pragma unroll
       for (int j = 0; j < MJ; ++j) {
-        const wn_h8 Ah = *reinterpret_cast<const wn_h8*>(wt + ((s * MJ + j) * 2 + 0) * 1024);
-        const wn_h8 Al = *reinterpret_cast<const wn_h8*>(wt + ((s * MJ + j) * 2 + 1) * 1024);
-        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah, uh.v8, acc[j], 0, 0, 0);
-        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Al, uh.v8, acc[j], 0, 0, 0);
-        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah, ul.v8, acc[j], 0, 0, 0);
+        Ah[j] = *reinterpret_cast<const wn_h8*>(wt + ((s * MJ + j) * 2 + 0) * 1024);
+        Al[j] = *reinterpret_cast<const wn_h8*>(wt + ((s * MJ + j) * 2 + 1) * 1024);
+      }
+      float val[8];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int t = 2 * s + j;                     // compile-time tap
+        if (t >= WN_T) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) val[4 * j + e] = 0.f;
+          continue;
+        }
+        const float h_im = hb + (float)(t / 3) + oh[t], w_im = wb + (float)(t % 3) + ow[t];
+        const bool valid = alive && h_im > -1.f && w_im > -1.f && h_im < fH && w_im < fW;      // cu:617
+        const float fh = floorf(h_im), fw = floorf(w_im);
+        const int ly = (int)fh - wy0, lx = (int)fw - wx0;          // (the conversion saturates; NaN -> 0)
+        const bool inwin = (unsigned)ly < (unsigned)(WN_WH - 1) && (unsigned)lx < (unsigned)(WN_WW - 1);
+        const bool use = valid && inwin;
+        fbmask |= (valid && !inwin) ? (1u << t) : 0u;
+        const float lh = h_im - fh, lw = w_im - fw;
+        const int o = use ? (ly * WN_WW + lx) * 16 : 0;
+        const f32x4 v1 = *reinterpret_cast<const f32x4*>(win + o);
+        const f32x4 v2 = *reinterpret_cast<const f32x4*>(win + o + 16);
+        const f32x4 v3 = *reinterpret_cast<const f32x4*>(win + o + WN_WW * 16);
+        const f32x4 v4 = *reinterpret_cast<const f32x4*>(win + o + WN_WW * 16 + 16);
+        // An unused tap has weight 0 (no per-value select): should the dummy read or an infinite offset turn 0 * x into a NaN,
+        // the converted half raises the re-run flag below and the exact kernel recomputes the result -- correct, merely slower.
+        const float ms = use ? mk[t] * s_in : 0.f;
+        const float mlh = lh * ms, mhh = ms - mlh;                 // (1 - lh) * ms
+        const float w4 = mlh * lw, w3 = mlh - w4, w2 = mhh * lw, w1 = mhh - w2;
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          val[4 * j + e] = __builtin_fmaf(w4, v4[e], __builtin_fmaf(w3, v3[e], __builtin_fmaf(w2, v2[e], w1 * v1[e])));
+        load_tap(vo_n, vm_n, t, oh[t], ow[t], mk[t]);      // this tap's next offsets, into the registers just freed (the last
+                                                           // chunk re-reads its own: harmless, and no branch in the stream)
+      }
+      split_mma(val, Ah, Al);
+      if (more && s == 2) {
+        commit_task(buf ^ 1, 0, wr, wmax_n);
+        fetch_task(chunk + 1, 1, wr);
       }
     }
-    if (chunk + 1 < nch) commit(buf ^ 1);
+    // ---- cold path, wave-uniform: some lane sampled beyond its window (offsets past ~10 pixels).  Those taps were zero above;
+    // gather them from global memory now (zero outside the image, cu:481-488) and add their product -- the contraction is
+    // linear.  (Their offsets are re-read: the registers already hold the next chunk's.)
+    if (__builtin_expect(__ballot(fbmask != 0) != 0ull, 0)) {
+#pragma unroll
+      for (int s = 0; s < WN_STEPS; ++s) {
+        if (__ballot(((fbmask >> (2 * s)) & 3u) != 0) == 0ull) continue;
+        wn_h8 Ah[MJ], Al[MJ];
+#pragma unroll
+        for (int j = 0; j < MJ; ++j) {
+          Ah[j] = *reinterpret_cast<const wn_h8*>(wt + ((s * MJ + j) * 2 + 0) * 1024);
+          Al[j] = *reinterpret_cast<const wn_h8*>(wt + ((s * MJ + j) * 2 + 1) * 1024);
+        }
+        float val[8];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const int t = 2 * s + j;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) val[4 * j + e] = 0.f;
+          if (t < WN_T && ((fbmask >> t) & 1u)) {
+            float o_h, o_w, m_k;
+            load_tap(vo_c, vm_c, t, o_h, o_w, m_k);
+            const float h_im = hb + (float)(t / 3) + o_h, w_im = wb + (float)(t % 3) + o_w;
+            const float fh = floorf(h_im), fw = floorf(w_im);
+            const int hl = (int)fh, wl = (int)fw;
+            const float lh = h_im - fh, lw = w_im - fw, hh = 1.f - lh, hw = 1.f - lw;
+            const bool r0 = hl >= 0, r1 = hl + 1 <= H - 1, q0 = wl >= 0, q1 = wl + 1 <= W - 1;
+            const int c0 = 8 * chunk + 4 * half;
+            const float ms = m_k * s_in;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const float* pl = in_b + (long long)(c0 + e) * HW;
+              const float g1 = (r0 && q0) ? pl[hl * W + wl] : 0.f, g2 = (r0 && q1) ? pl[hl * W + wl + 1] : 0.f;
+              const float g3 = (r1 && q0) ? pl[(hl + 1) * W + wl] : 0.f, g4 = (r1 && q1) ? pl[(hl + 1) * W + wl + 1] : 0.f;
+              val[4 * j + e] = ((hh * hw) * g1 + (hh * lw) * g2 + (lh * hw) * g3 + (lh * lw) * g4) * ms;
+            }
+          }
+        }
+        split_mma(val, Ah, Al);
+      }
+    }
+    if (more) {
+      commit_task(buf ^ 1, 1, wr, wmax_n);
+      commit_weights(buf ^ 1, wmax_n);
+    }
   }
   if (ovfbits) atomicOr(a.flags + 2, 1u);      // out of the fp16 hi + lo range somewhere: the exact kernel re-runs (dcn.hip)
   // ---- store D[row = cout][col = pixel] (+ bias), NCHW: 32 lanes = 128 contiguous bytes of one output row
@@ -331,13 +403,13 @@ __global__ __launch_bounds__(WN_THREADS) void dcn_win_kernel(WinArgs a) {
   }
 }
 
-template <int MJ, bool AL4>
+template <int MJ, bool AL4, bool MASK>
 hipError_t wn_launch(const WinArgs& a, dim3 grid, hipStream_t st) {
   constexpr int LDSB = 4 * WN_WIN + 2 * (WN_STEPS * MJ * 2 * 1024) + 64;
   static CdfoAttrOnce once;
-  const hipError_t e = cdfo_set_max_lds(once, reinterpret_cast<const void*>(&dcn_win_kernel<MJ, AL4>), LDSB);
+  const hipError_t e = cdfo_set_max_lds(once, reinterpret_cast<const void*>(&dcn_win_kernel<MJ, AL4, MASK>), LDSB);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL((dcn_win_kernel<MJ, AL4>), grid, dim3(WN_THREADS), LDSB, st, a);
+  hipLaunchKernelGGL((dcn_win_kernel<MJ, AL4, MASK>), grid, dim3(WN_THREADS), LDSB, st, a);
   return hipGetLastError();
 }
 
@@ -359,7 +431,7 @@ int cdfo_dcn_forward_win(const float* in, const float* offset, const float* mask
                          const unsigned** rerun_flag) {
   const long long need = cdfo_dcn_win_workspace_bytes(C, Co, kh, kw, sh, sw, dh, dw, groups, dg);
   if (!need || !workspace || workspace_bytes < need || !aligned16(workspace)) return 0;
-  if ((long long)C * H * W >= (1ll << 30) || (long long)dg * 2 * WN_T * Ho * Wo >= (1ll << 30)) return 0;      // 32-bit per-image indices
+  if ((long long)C * H * W >= (1ll << 29) || (long long)dg * 2 * WN_T * Ho * Wo >= (1ll << 29)) return 0;      // 31-bit per-image byte offsets (0x80000000 = out of range)
   if (ph < 0 || pw < 0 || ph > 8 || pw > 8) return 0;                                                          // window margins assume a small pad
   const int MJ = Co / 32, nch = (C + 7) / 8;
   char* ws = static_cast<char*>(workspace);
@@ -378,7 +450,16 @@ int cdfo_dcn_forward_win(const float* in, const float* offset, const float* mask
   dim3 grid(8 * cdiv(a.ntiles, 8), B);
   const bool al4 = W % 4 == 0 && aligned16(in);
   hipError_t e;
-  if (MJ == 1) e = al4 ? wn_launch<1, true>(a, grid, st) : wn_launch<1, false>(a, grid, st);
-  else e = al4 ? wn_launch<2, true>(a, grid, st) : wn_launch<2, false>(a, grid, st);
+  const int variant = (MJ == 2 ? 4 : 0) | (al4 ? 2 : 0) | (mask ? 1 : 0);
+  switch (variant) {
+    case 0: e = wn_launch<1, false, false>(a, grid, st); break;
+    case 1: e = wn_launch<1, false, true>(a, grid, st); break;
+    case 2: e = wn_launch<1, true, false>(a, grid, st); break;
+    case 3: e = wn_launch<1, true, true>(a, grid, st); break;
+    case 4: e = wn_launch<2, false, false>(a, grid, st); break;
+    case 5: e = wn_launch<2, false, true>(a, grid, st); break;
+    case 6: e = wn_launch<2, true, false>(a, grid, st); break;
+    default: e = wn_launch<2, true, true>(a, grid, st); break;
+  }
   return e == hipSuccess ? 1 : 2 + (int)e;
 }

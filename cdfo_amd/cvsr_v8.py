@@ -165,6 +165,7 @@ class CVSR_V8(nn.Module):
         self.debug_taps: Optional[dict] = None      # set to {} to collect stage outputs (tests only)
         self.capture_noise: Optional[list] = None   # set to [] to receive the six uniform tensors the default path drew
         self._noise_seed = 0
+        self._noise_key: Optional[torch.Tensor] = None   # device-side Philox key of captured forwards (refresh_noise_key)
         # fp16 range guard of the fp16x2 mode (see forward); costs one 16-byte device->host readback per forward.  Callers
         # that capture the forward into a HIP graph (no synchronisation allowed) set it to False
         self.range_guard = True
@@ -500,7 +501,16 @@ class CVSR_V8(nn.Module):
         with K.on_device(x):     # the operands' device becomes the current one: streams, per-device caches of the library
             noise = gumbel_uniform if gumbel_uniform is not None else self.gumbel_uniform
             if noise is None:
-                self._noise_seed = K.next_noise_seed(x.device)
+                if torch.cuda.is_current_stream_capturing():
+                    # a captured forward must not freeze its Philox key into the graph: the mask kernels read it from device
+                    # memory, and the owner of the graph calls refresh_noise_key() before every replay (arch.py:2169 draws
+                    # fresh uniforms per forward)
+                    if self._noise_key is None or self._noise_key.device != x.device:
+                        raise RuntimeError("CVSR_V8 (HIP): call model.refresh_noise_key(device) before capturing a forward "
+                                           "that draws its own Gumbel noise")
+                    self._noise_seed = self._noise_key
+                else:
+                    self._noise_seed = K.next_noise_seed(x.device)
             if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
                 # training call (train_LD_37.py:376-381): the operator graph under autograd, exact-fp32 HIP kernels in both
                 # directions (cdfo_amd/cvsr_v8_train.py); the fused inference schedule below is forward-only
@@ -540,6 +550,19 @@ class CVSR_V8(nn.Module):
                 self.precision = "fp16x2"
 
     FP16_WINDOW = (2.0 ** -6, 2.0 ** 11)
+
+    def refresh_noise_key(self, device=None) -> int:
+        """Write a fresh Philox key (advancing torch's default generator like an eager forward does) into the device word that
+        CAPTURED forwards read: call before capturing and before every replay of a HIP graph of this model, so that each
+        replayed forward draws its own Gumbel noise like the reference does per call (arch.py:2169)."""
+        dev = torch.device(device) if device is not None else next(self.parameters()).device
+        if dev.type == "cuda" and dev.index is None:
+            dev = torch.device("cuda", torch.cuda.current_device())
+        seed = K.next_noise_seed(dev)
+        if self._noise_key is None or self._noise_key.device != dev:
+            self._noise_key = torch.empty(1, dtype=torch.int64, device=dev)
+        self._noise_key.fill_(seed)
+        return seed
 
     def _forward(self, x, mvs0, mvs1, pms, rms, ufs, pre_L1_fea=None, gumbel_uniform=None):
         B, N, C, H, W = x.shape

@@ -778,6 +778,13 @@ def rdab_prep_rng(xq: torch.Tensor, vmax: torch.Tensor, seed: int, draw: int, wW
                                   or noise_out.dtype != torch.float32):
         raise ValueError("rdab_prep_rng: noise_out must be a contiguous fp32 [B,64,H,W] tensor")
     sq, vrow, qwin = _prep_outs(outs, B, H, W, xq.device)
+    if isinstance(seed, torch.Tensor):      # the key lives in device memory (int64[1]): graph replays re-read it
+        if seed.dtype != torch.int64 or seed.numel() != 1 or seed.device != xq.device:
+            raise ValueError("rdab_prep_rng: a device-side key must be an int64[1] tensor on the operands' device")
+        check(_lib.lib().cdfo_rdab_prep_rng_dev(_vp(xq), ld, _vp(vmax), _vp(seed), draw, _vp(noise_out), _vp(wW), _vp(bW), B,
+                                                C.c_longlong(H * W), _vp(sq), 64, _vp(vrow), 64, _vp(qwin), 64, _stream()),
+              "cdfo_rdab_prep_rng_dev")
+        return sq, vrow, qwin
     check(_lib.lib().cdfo_rdab_prep_rng(_vp(xq), ld, _vp(vmax), C.c_longlong(seed & 0x7FFFFFFFFFFFFFFF), draw, _vp(noise_out),
                                         _vp(wW), _vp(bW), B, C.c_longlong(H * W), _vp(sq), 64, _vp(vrow), 64, _vp(qwin), 64,
                                         _stream()), "cdfo_rdab_prep_rng")
@@ -791,13 +798,15 @@ def next_noise_seed(device) -> int:
     """A fresh 63-bit Philox key per forward, reproducible under torch.manual_seed: taken from (and advancing) the state
     of torch's default generator of `device` -- plumbing only, no random numbers are drawn by torch."""
     global _seed_counter
-    try:
+    if torch.cuda.is_current_stream_capturing():
+        # the generator refuses state changes during a graph capture; a captured forward reads its key from device memory
+        # anyway (CVSR_V8.refresh_noise_key rewrites it before every replay), so this value only seeds the capture run
+        base, off = int(torch.initial_seed()), 4 * _seed_counter
+        _seed_counter += 1
+    else:
         g = torch.cuda.default_generators[device.index if device.index is not None else torch.cuda.current_device()]
         base, off = int(g.initial_seed()), int(g.get_offset())
         g.set_offset(off + 4)
-    except Exception:
-        base, off = int(torch.initial_seed()), 4 * _seed_counter
-        _seed_counter += 1
     return (base * 0x9E3779B97F4A7C15 + off * 0xD1B54A32D192ED03 + 0x632BE59BD9B4E019) & 0x7FFFFFFFFFFFFFFF
 
 

@@ -124,8 +124,9 @@ class StreamingSR:
         if self._graph is None:
             st = [t.clone() for t in ins]
             # no host synchronisation may happen inside a captured forward: the fp16 range guard (a readback) is off for the
-            # captured step (the eager first frame of the sequence ran with it).  With noise=None the Philox key of the mask
-            # kernels is a launch argument and therefore frozen into the graph: every replay draws the same uniforms.
+            # captured step (the eager first frame of the sequence ran with it).  With noise=None the mask kernels read their
+            # Philox key from a device word that is rewritten before every replay (model.refresh_noise_key), so each frame draws
+            # fresh uniforms like the reference's per-call torch.rand_like (arch.py:2169).
             def call():
                 guard = getattr(self.model, "range_guard", False)
                 self.model.range_guard = False
@@ -134,20 +135,28 @@ class StreamingSR:
                                       gumbel_uniform=None if noise is None else st[7:])
                 finally:
                     self.model.range_guard = guard
+            # the warm-up and capture runs below must not consume the generator: frame i's key is then the same whether the
+            # loop runs eagerly or from the graph (one advance per frame, by refresh_noise_key before the replay)
+            rng_state = torch.cuda.get_rng_state(self.dev)
             side = torch.cuda.Stream(self.dev)
             side.wait_stream(torch.cuda.current_stream(self.dev))
             with torch.cuda.stream(side), torch.no_grad():          # warm-up on a side stream, as graph capture requires
                 call()
             torch.cuda.current_stream(self.dev).wait_stream(side)
+            if noise is None:
+                self.model.refresh_noise_key(self.dev)
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g), torch.no_grad():
                 out, fea = call()
             self._graph, self._static = g, (st, out, fea)
+            torch.cuda.set_rng_state(rng_state, self.dev)
         st, out, fea = self._static
         torch.cuda.synchronize(self.dev)
         t0 = time.perf_counter()
         for dst, src in zip(st, ins):
             dst.copy_(src)
+        if noise is None:
+            self.model.refresh_noise_key(self.dev)
         self._graph.replay()
         torch.cuda.synchronize(self.dev)
         self.seconds += time.perf_counter() - t0

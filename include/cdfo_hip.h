@@ -212,6 +212,12 @@ int cdfo_rdab_prep(const float* xq, int ldx, const float* vmax, const float* noi
 int cdfo_rdab_prep_rng(const float* xq, int ldx, const float* vmax, long long seed, int draw, float* noise_out,
                        const float* wW, const float* bW, int B, long long P, float* sq, int lds_, float* vrow, int ldv,
                        float* qwin, int ldw, void* stream);
+/* cdfo_rdab_prep_rng with the Philox key read from DEVICE memory (seed_dev: one 64-bit word, 8-byte aligned): a captured
+ * HIP graph then draws fresh uniforms on every replay -- the caller rewrites the word between replays -- instead of
+ * freezing a launch argument (the reference draws per forward, arch.py:2169). */
+int cdfo_rdab_prep_rng_dev(const float* xq, int ldx, const float* vmax, const void* seed_dev, int draw, float* noise_out,
+                           const float* wW, const float* bW, int B, long long P, float* sq, int lds_, float* vrow, int ldv,
+                           float* qwin, int ldw, void* stream);
 int cdfo_colconv9(const float* in, int ldi, const float* wH, const float* bH, int B, int H, int W, float* out, int ldo,
                   void* stream);
 /* Evaluation metrics on the device (metric/psnr_ssim.py:278-317 calculate_psnr, :320-399 _ssim / calculate_ssim): fp64

@@ -31,15 +31,24 @@ typedef _Float16 wn_h8 __attribute__((ext_vector_type(8)));
 
 namespace {
 
-constexpr int WN_TH = 8, WN_TW = 32;                 // output tile
-constexpr int WN_WH = 31, WN_WW = 56;                // window: rows oy0 - ph - 10 .. + 30, columns floor4(ox0 - pw - 10) .. + 55
-constexpr int WN_RY = 10, WN_RX = 10;
-constexpr int WN_WIN = WN_WH * WN_WW * 16;           // 27,776 bytes per 4-channel block
-constexpr int WN_T = 9, WN_STEPS = 5;                // 18 items (2 blocks x 9 taps) + 2 zero items = 5 K steps of 4 items
-constexpr int WN_THREADS = 512;
-constexpr int WN_QPR = WN_WW / 4;                    // 14 four-pixel quads per window row
-constexpr int WN_TASKS = WN_WH * WN_QPR;             // 434 staging tasks per block
-constexpr int WN_NTASK = 2;                          // tasks per thread and chunk: 2 * 512 >= 2 * 434
+// Geometry.  WN_NW waves per workgroup = tile rows: 8 (two per SIMD, <= 256 VGPRs).  The kernel is latency-, not throughput-
+// bound (VALU 26 %, MFMA 15 %, LDS ~35 % busy, 37 % of the wave-cycles parked on waits: profiles/r03_pmc_counters_dcn_fwd.txt),
+// so more waves are what it wants -- but the 16-wave form (a 16 x 32 tile fits the LDS with a +-8 pixel window) needs the
+// per-wave state in 128 VGPRs and hipcc spills 130 of them (a spill is ruinous here, see the kernel); -DWN_NW=16 builds it.
+#ifndef WN_NW
+#define WN_NW 8
+#endif
+constexpr int WN_TH = WN_NW, WN_TW = 32;             // output tile
+// window: rows oy0 - ph - RY .. + WH - 1, columns floor4(ox0 - pw - RX) .. + WW - 1  (reach: ~10 pixels at 8 waves, ~8 at 16)
+constexpr int WN_WH = WN_NW == 8 ? 31 : 35, WN_WW = WN_NW == 8 ? 56 : 52;
+constexpr int WN_RY = WN_NW == 8 ? 10 : 8, WN_RX = WN_NW == 8 ? 10 : 7;
+constexpr int WN_WIN = WN_WH * WN_WW * 16;           // bytes per 4-channel block (27,776 / 29,120)
+constexpr int WN_T = 9, WN_STEPS = 5;                // 2 blocks x (9 taps + 1 zero pad) = 5 K steps of 4 items
+constexpr int WN_THREADS = 64 * WN_NW;
+constexpr int WN_QPR = WN_WW / 4;                    // four-pixel quads per window row
+constexpr int WN_TASKS = WN_WH * WN_QPR;             // staging tasks per block
+constexpr int WN_NTASK = (2 * WN_TASKS + WN_THREADS - 1) / WN_THREADS;     // tasks per thread and chunk (2 at 8 waves, 1 at 16)
+static_assert(WN_NTASK == 1 || WN_NTASK == 2, "staging schedule");
 
 struct WinArgs {
   const float* in; const float* offset; const float* mask; const float* bias; float* out;
@@ -96,7 +105,7 @@ __global__ __launch_bounds__(WN_THREADS) void dcn_win_kernel(WinArgs a) {
   constexpr unsigned OOR = 0x80000000u;                          // buffer offset past every descriptor: the load returns zeros
   unsigned char* const sWin = smem;                              // [2 buffers][2 blocks][WN_WIN]
   unsigned char* const sWt = smem + 4 * WN_WIN;                  // [2 buffers][WTS]
-  float* const sMax = reinterpret_cast<float*>(smem + 4 * WN_WIN + 2 * WTS);      // [2 buffers][8 waves]
+  unsigned* const sMax = reinterpret_cast<unsigned*>(smem + 4 * WN_WIN + 2 * WTS);   // [2 buffers][waves]: max |bits| of the windows
   const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, n = lane & 31;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   // workgroups go round-robin to the 8 XCDs: each XCD walks its own contiguous band of tiles (its L2 then sees a band of image
@@ -169,13 +178,15 @@ __global__ __launch_bounds__(WN_THREADS) void dcn_win_kernel(WinArgs a) {
       }
     }
   };
-  auto commit_task = [&](int buf, int q, const f32x4 (&wr)[4], float& m) {      // registers -> window buffer `buf`; m = running |max|
+  auto commit_task = [&](int buf, int q, const f32x4 (&wr)[4], unsigned& m) {   // registers -> window buffer `buf`; m = running max |bits|
     if (tk_on[q]) {
 #pragma unroll
       for (int x = 0; x < 4; ++x) {
         const f32x4 v = {wr[0][x], wr[1][x], wr[2][x], wr[3][x]};
         *reinterpret_cast<f32x4*>(sWin + buf * 2 * WN_WIN + tk_lds[q] + x * 16) = v;
-        m = fmaxf(fmaxf(m, fabsf(v[0])), fmaxf(fabsf(v[1]), fmaxf(fabsf(v[2]), fabsf(v[3]))));     // (NaN ignored; inf: see the scale)
+        // running maximum of |bits|: as integers, so that a NaN (pattern above infinity's) is SEEN, not skipped like fmax does
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { const unsigned ub = __float_as_uint(v[e]) & 0x7fffffffu; m = ub > m ? ub : m; }
       }
     }
   };
@@ -186,14 +197,15 @@ __global__ __launch_bounds__(WN_THREADS) void dcn_win_kernel(WinArgs a) {
       wtr[i] = a.wp[(unsigned)(chunk * WSLOTS + (slot < WSLOTS ? slot : 0))];
     }
   };
-  auto commit_weights = [&](int buf, float m) {
+  auto commit_weights = [&](int buf, unsigned m) {
 #pragma unroll
     for (int i = 0; i < WLD; ++i) {
       const int slot = tid + i * WN_THREADS;
       if (slot < WSLOTS) *reinterpret_cast<wn_h8*>(sWt + buf * WTS + slot * 16) = wtr[i];
     }
-    m = wave_max(m);
-    if (lane == 0) sMax[buf * 8 + wave] = m;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { const unsigned t = (unsigned)__shfl_xor((int)m, o, 64); m = t > m ? t : m; }
+    if (lane == 0) sMax[buf * WN_NW + wave] = m;
   };
 
   // ---- offsets / mask of the lane's nine taps: lane byte offset = (its block's deformable group, its pixel), scalar = the tap
@@ -220,9 +232,10 @@ __global__ __launch_bounds__(WN_THREADS) void dcn_win_kernel(WinArgs a) {
     for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
   int e_run = -100000;          // binary exponent of the accumulators' unit: sampled values are scaled by 2^(3 - e_run)
   unsigned ovfbits = 0;
+  float vmax = 0.f;            // largest |scaled sample| of this lane
 
   {   // prologue: chunk 0 into buffer 0
-    float m = 0.f;
+    unsigned m = 0u;
     f32x4 w0[4];
 #pragma unroll
     for (int q = 0; q < WN_NTASK; ++q) {
@@ -239,6 +252,8 @@ __global__ __launch_bounds__(WN_THREADS) void dcn_win_kernel(WinArgs a) {
   }
   const int nch = a.nchunks;
   const float fH = (float)H, fW = (float)W;
+  const float fwy0 = (float)wy0, fwy1 = (float)(wy0 + WN_WH - 2), fwx0 = (float)wx0, fwx1 = (float)(wx0 + WN_WW - 2);
+  const float hbt[3] = {hb, hb + 1.f, hb + 2.f}, wbt[3] = {wb, wb + 1.f, wb + 2.f};       // base position per tap row / column
   const unsigned char* const win_lane = sWin + half * WN_WIN;
   for (int chunk = 0; chunk < nch; ++chunk) {
     const int buf = chunk & 1;
@@ -249,12 +264,17 @@ __global__ __launch_bounds__(WN_THREADS) void dcn_win_kernel(WinArgs a) {
     lane_offsets(more ? chunk + 1 : chunk, vo_n, vm_n, alive_n);
     __syncthreads();            // buffer `buf` is complete; nobody still reads the other one
     // ---- this chunk's power-of-two scale from its window maximum
-    float M = sMax[buf * 8];
+    unsigned Mb = sMax[buf * WN_NW];
 #pragma unroll
-    for (int i = 1; i < 8; ++i) M = fmaxf(M, sMax[buf * 8 + i]);
+    for (int i = 1; i < WN_NW; ++i) Mb = sMax[buf * WN_NW + i] > Mb ? sMax[buf * WN_NW + i] : Mb;
     int e_c = -100;
-    if (M > 0.f && M < INFINITY) { frexpf(M, &e_c); e_c = e_c < -100 ? -100 : (e_c > 100 ? 100 : e_c); }       // M < 2^e_c
-    else if (M > 0.f) e_c = 100;      // an infinity in the window: whatever samples it overflows the halves -> re-run flag
+    if (Mb >= 0x7f800000u) {        // an infinity or a NaN in the window: this path is not exact for it -> the exact kernel re-runs
+      ovfbits = 1u;
+      e_c = 100;
+    } else if (Mb > 0u) {
+      frexpf(__uint_as_float(Mb), &e_c);                             // max < 2^e_c
+      e_c = e_c < -100 ? -100 : (e_c > 100 ? 100 : e_c);
+    }
     if (e_c > e_run) {
       const int de = e_run - e_c;
       const float f = ldexpf(1.f, de < -200 ? -200 : de);          // <= 1 (0 for the first chunk: the sums are zero)
@@ -275,11 +295,14 @@ __global__ __launch_bounds__(WN_THREADS) void dcn_win_kernel(WinArgs a) {
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         uh.h[q] = __builtin_amdgcn_cvt_pkrtz(val[2 * q], val[2 * q + 1]);
-        ul.h[q] = __builtin_amdgcn_cvt_pkrtz(__builtin_fmaf((float)uh.h[q][0], -1.f, val[2 * q]),
-                                             __builtin_fmaf((float)uh.h[q][1], -1.f, val[2 * q + 1]));      // (v_fma_mix_f32)
-        union { hp2 h; unsigned u; } cv;       // range check on the CONVERTED halves (see dcn_fast.hip): >= 0x7bff, inf, NaN
-        cv.h = uh.h[q];
-        ovfbits |= ((cv.u & 0x7fff7fffu) + 0x04010401u) & 0x80008000u;
+        // remainders val - hi in ONE instruction each: v_fma_mix_f32 reads the fp16 half straight out of the packed register
+        float r0, r1;
+        asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(r0) : "v"(uh.h[q]), "v"(val[2 * q]));
+        asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r1) : "v"(uh.h[q]), "v"(val[2 * q + 1]));
+        ul.h[q] = __builtin_amdgcn_cvt_pkrtz(r0, r1);
+        // range: the largest |value| of the lane (the round-toward-zero conversion would clamp silently at 65504); a NaN can only
+        // come from a NaN mask (the reference's result is NaN there too) -- non-finite window data is caught by the window maximum
+        vmax = fmaxf(vmax, fmaxf(fabsf(val[2 * q]), fabsf(val[2 * q + 1])));
       }
 #pragma unroll
       for (int j = 0; j < MJ; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah[j], uh.v8, acc[j], 0, 0, 0);
@@ -290,7 +313,7 @@ __global__ __launch_bounds__(WN_THREADS) void dcn_win_kernel(WinArgs a) {
     };
     // next chunk's window: task 0 is requested now and written after step 2, task 1 then and written after step 4 (16 staging
     // registers at a time); its packed weights ride along
-    float wmax_n = 0.f;
+    unsigned wmax_n = 0u;
     f32x4 wr[4];
     if (more) {
       fetch_task(chunk + 1, 0, wr);
@@ -313,22 +336,23 @@ __global__ __launch_bounds__(WN_THREADS) void dcn_win_kernel(WinArgs a) {
           for (int e = 0; e < 4; ++e) val[4 * j + e] = 0.f;
           continue;
         }
-        const float h_im = hb + (float)(t / 3) + oh[t], w_im = wb + (float)(t % 3) + ow[t];
-        const bool valid = alive && h_im > -1.f && w_im > -1.f && h_im < fH && w_im < fW;      // cu:617
+        const float h_im = hbt[t / 3] + oh[t], w_im = wbt[t % 3] + ow[t];
         const float fh = floorf(h_im), fw = floorf(w_im);
-        const int ly = (int)fh - wy0, lx = (int)fw - wx0;          // (the conversion saturates; NaN -> 0)
-        const bool inwin = (unsigned)ly < (unsigned)(WN_WH - 1) && (unsigned)lx < (unsigned)(WN_WW - 1);
-        const bool use = valid && inwin;
-        fbmask |= (valid && !inwin) ? (1u << t) : 0u;
-        const float lh = h_im - fh, lw = w_im - fw;
-        const int o = use ? (ly * WN_WW + lx) * 16 : 0;
+        // inside the staged window?  (float compares: a NaN / infinite offset fails them and goes to the cold path, which applies
+        // the reference's range test cu:617.  No such test is needed HERE: the window is zero-filled outside the image, so a
+        // position the reference rejects -- all four corners outside -- samples zeros.)
+        const bool use = alive && fh >= fwy0 && fh <= fwy1 && fw >= fwx0 && fw <= fwx1;
+        fbmask |= (alive && !use) ? (1u << t) : 0u;
+        // branch-free: fractions clamped (max / min drop a NaN from inf - inf), window coordinates clamped (an unused tap reads
+        // somewhere harmless inside the window and gets weight 0)
+        const float lh = fminf(fmaxf(h_im - fh, 0.f), 1.f), lw = fminf(fmaxf(w_im - fw, 0.f), 1.f);
+        const int ly = min(max((int)fh - wy0, 0), WN_WH - 2), lx = min(max((int)fw - wx0, 0), WN_WW - 2);
+        const int o = (ly * WN_WW + lx) * 16;
         const f32x4 v1 = *reinterpret_cast<const f32x4*>(win + o);
         const f32x4 v2 = *reinterpret_cast<const f32x4*>(win + o + 16);
         const f32x4 v3 = *reinterpret_cast<const f32x4*>(win + o + WN_WW * 16);
         const f32x4 v4 = *reinterpret_cast<const f32x4*>(win + o + WN_WW * 16 + 16);
-        // An unused tap has weight 0 (no per-value select): should the dummy read or an infinite offset turn 0 * x into a NaN,
-        // the converted half raises the re-run flag below and the exact kernel recomputes the result -- correct, merely slower.
-        const float ms = use ? mk[t] * s_in : 0.f;
+        const float ms = use ? mk[t] * s_in : 0.f;                 // an unused tap has weight 0 (finite: lh, lw were sanitised)
         const float mlh = lh * ms, mhh = ms - mlh;                 // (1 - lh) * ms
         const float w4 = mlh * lw, w3 = mlh - w4, w2 = mhh * lw, w1 = mhh - w2;
 #pragma unroll
@@ -338,7 +362,7 @@ __global__ __launch_bounds__(WN_THREADS) void dcn_win_kernel(WinArgs a) {
                                                            // chunk re-reads its own: harmless, and no branch in the stream)
       }
       split_mma(val, Ah, Al);
-      if (more && s == 2) {
+      if (WN_NTASK == 2 && more && s == 2) {
         commit_task(buf ^ 1, 0, wr, wmax_n);
         fetch_task(chunk + 1, 1, wr);
       }
@@ -365,7 +389,9 @@ __global__ __launch_bounds__(WN_THREADS) void dcn_win_kernel(WinArgs a) {
           if (t < WN_T && ((fbmask >> t) & 1u)) {
             float o_h, o_w, m_k;
             load_tap(vo_c, vm_c, t, o_h, o_w, m_k);
-            const float h_im = hb + (float)(t / 3) + o_h, w_im = wb + (float)(t % 3) + o_w;
+            float h_im = hb + (float)(t / 3) + o_h, w_im = wb + (float)(t % 3) + o_w;
+            const bool valid = h_im > -1.f && w_im > -1.f && h_im < fH && w_im < fW;      // cu:617 (false for NaN)
+            if (!valid) { h_im = 0.f; w_im = 0.f; m_k = 0.f; }
             const float fh = floorf(h_im), fw = floorf(w_im);
             const int hl = (int)fh, wl = (int)fw;
             const float lh = h_im - fh, lw = w_im - fw, hh = 1.f - lh, hw = 1.f - lw;
@@ -385,10 +411,11 @@ __global__ __launch_bounds__(WN_THREADS) void dcn_win_kernel(WinArgs a) {
       }
     }
     if (more) {
-      commit_task(buf ^ 1, 1, wr, wmax_n);
+      commit_task(buf ^ 1, WN_NTASK - 1, wr, wmax_n);
       commit_weights(buf ^ 1, wmax_n);
     }
   }
+  if (!(vmax < 65504.f)) ovfbits = 1u;
   if (ovfbits) atomicOr(a.flags + 2, 1u);      // out of the fp16 hi + lo range somewhere: the exact kernel re-runs (dcn.hip)
   // ---- store D[row = cout][col = pixel] (+ bias), NCHW: 32 lanes = 128 contiguous bytes of one output row
   if (pvalid) {
@@ -405,7 +432,8 @@ __global__ __launch_bounds__(WN_THREADS) void dcn_win_kernel(WinArgs a) {
 
 template <int MJ, bool AL4, bool MASK>
 hipError_t wn_launch(const WinArgs& a, dim3 grid, hipStream_t st) {
-  constexpr int LDSB = 4 * WN_WIN + 2 * (WN_STEPS * MJ * 2 * 1024) + 64;
+  constexpr int LDSB = 4 * WN_WIN + 2 * (WN_STEPS * MJ * 2 * 1024) + 2 * WN_NW * 4;
+  static_assert(LDSB <= 160 * 1024, "LDS budget");
   static CdfoAttrOnce once;
   const hipError_t e = cdfo_set_max_lds(once, reinterpret_cast<const void*>(&dcn_win_kernel<MJ, AL4, MASK>), LDSB);
   if (e != hipSuccess) return e;

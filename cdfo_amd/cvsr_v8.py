@@ -26,6 +26,7 @@ Differences, all deliberate:
 from __future__ import annotations
 
 import contextlib
+import os
 
 import math
 from typing import Dict, List, Optional, Sequence
@@ -147,6 +148,9 @@ class CVSR_V8(nn.Module):
         # terms): measured 1.7e-3 on the RETURNED feature cache (|L1_fea| up to 7), outside the 1e-3 bound, for 1.3 ms per
         # step -- so the three-term product stays.  Set before the first forward (it selects the weight packing).
         self.fe_weight_lo = True
+        # fp16x2 mode, conv_expand_fea_r (arch.py:4454; 128 -> 64, 3x3, twice per forward on 3*B images): False = fp16 hi + lo
+        # activations (two MFMA passes), True = activations rounded once to fp16 like the convolutions inside Block_ (one pass)
+        self.fea_r_single_pass = os.environ.get("CDFO_FEA_R_1PASS", "0") not in ("", "0")
         for key, shape, fan_in, init in _param_spec():
             t = torch.empty(shape)
             if init == "default":
@@ -686,7 +690,7 @@ class CVSR_V8(nn.Module):
             else:
                 noises.append(noise[draw].to(device=x_dev, dtype=torch.float32).contiguous())
         x_n = self._rdab(w, du0, fea_com, noises)
-        fea_i = self._conv([feaG, x_n], w["conv_expand_fea_r"], pad=1)
+        fea_i = self._conv([feaG, x_n], w["conv_expand_fea_r"], pad=1, inner=self.fea_r_single_pass)
         al = K.empty_act(GB, H, W, NF, x_dev)
         xc = xcG if xcG.shape[0] == GB else xcG[:GB]
         self._align(w, xc, fea_i, ufs_prior, [mvs1[:, i] for i in idxs], N * 2 * P, al)

@@ -388,7 +388,7 @@ def test_conv3x3_ring_half_resolution_residual():
     _cmp(out, ref, 1e-4, "ring conv + half-resolution residual")
 
 
-@pytest.mark.parametrize("B,H,W", [(2, 36, 44), (1, 64, 96), (2, 272, 480)])
+@pytest.mark.parametrize("B,H,W", [(2, 36, 44), (1, 64, 96), (1, 56, 40), (1, 48, 70), (3, 16, 64), (2, 272, 480)])
 def test_conv3x3_ring_sparse_taps_with_residuals(B, H, W):
     """Four-tap form with every epilogue input of Block_'s last convolution: res1, the half-resolution residual (staged
     in LDS by DMA in this form) and the fp16 chunk-planar second output; several tiles per workgroup at 272 x 480."""
@@ -416,6 +416,14 @@ def test_conv3x3_ring_sparse_taps_with_residuals(B, H, W):
     torch.cuda.synchronize()
     _cmp(out, ref, 1e-4, "ring conv, four taps + residuals")
     assert torch.equal(K.from_cp16(o16), out.half())
+    # hi | lo planes as the second output (a group's last block feeds the split-fp16 group convolution), and run-to-run equality
+    ohl = torch.zeros(B, 2 * (Cout // 16), H, W, 16, dtype=torch.float16, device="cuda")
+    out2 = K.conv_ring(K.to_cp16(_nhwc(x).cuda()), pc, res1=_nhwc(r1).cuda(), res_up2=_nhwc(e).cuda(), out2_cp16=ohl, out2_hl=True)
+    torch.cuda.synchronize()
+    assert torch.equal(out2, out)
+    hl = K.from_cp16(ohl).float()
+    assert torch.equal(hl[..., :Cout].half(), out.half())
+    assert ((hl[..., :Cout] + hl[..., Cout:]) - out).abs().max().item() <= 2e-3 * 2.0 ** -10 * max(1.0, out.abs().max().item())
 
 
 @pytest.mark.parametrize("B,H,W", [(2, 8, 24), (1, 12, 40)])

@@ -19,12 +19,12 @@ def main():
     mv = np.repeat(np.repeat(mv, 8, axis=2), 8, axis=3)[:, :, :H, :W]
     model = CVSR_V8()
     model = model.cuda().eval()
-    for use_graph, nstr in ((False, 1), (True, 1), (False, 3), (False, 6)):
-        model.neighbour_streams = nstr
+    for use_graph, nstr, grp in ((False, 1, 1), (True, 1, 1), (False, 6, 1), (True, 6, 1), (False, 2, 3), (True, 2, 3), (True, 1, 3)):
+        model.neighbour_streams, model.neighbour_group = nstr, grp
         s = StreamingSR(model, lr, pms, rms, ufs, mv[0], mv[1], use_graph=use_graph)
         s.run()                               # warm-up (weight packing, first-touch allocations, graph capture)
         outs = s.run()
-        print(f"streaming, 1 sequence of {T} frames {H}x{W} -> {tuple(outs[0].shape)}, HIP graph {use_graph}, neighbour streams {nstr}: "
+        print(f"streaming, 1 sequence of {T} frames {H}x{W} -> {tuple(outs[0].shape)}, HIP graph {use_graph}, neighbour streams {nstr}, frames per group {grp}: "
               f"{s.fps:.2f} frames/s ({1e3 * s.seconds / T:.1f} ms per frame, forward only, B=1)", flush=True)
 
 

@@ -481,9 +481,6 @@ int rg_launch(const cdfo_conv_args& a, const ring_extra& e, int grid, hipStream_
 
 }  // namespace
 
-// conv3x3_ring4.hip: the four-tap form on 32-row tiles (returns 1 = launched, 0 = not applicable, 2 + hipError_t = failed)
-int cdfo_conv3x3_ring4_tall(const cdfo_conv_args& a, hipStream_t st);
-
 extern "C" int cdfo_conv3x3_ring(const cdfo_conv_args* pa, void* stream) {
   const cdfo_conv_args& a = *pa;
   hipStream_t st = static_cast<hipStream_t>(stream);
@@ -514,14 +511,6 @@ extern "C" int cdfo_conv3x3_ring(const cdfo_conv_args* pa, void* stream) {
   const double px = (double)a.B * a.Ho * a.Wo;
   CdfoProfScope prof(st, a.tap_mask ? KID_CONV3_RING4 : KID_CONV3_RING, 2.0 * px * a.Cout * a.Cin * taps,
                      2.0 * px * a.Cin + (a.out_f16 ? 2.0 : 4.0) * px * a.Cout + 2.0 * taps * a.Cin * a.Cout);
-  if (a.tap_mask && (a.prec >> 8) == 0) {
-    static const int tall = []() { const char* v = getenv("CDFO_RING4_TALL"); return v ? atoi(v) : 1; }();     // developer A/B switch
-    if (tall) {
-      const int t = cdfo_conv3x3_ring4_tall(a, st);
-      if (t > 1) return t - 2;
-      if (t == 1) return 0;
-    }
-  }
   int rc;
   switch (a.prec >> 8) {
     case 0: rc = a.tap_mask ? rg_launch<true, 0>(a, e, grid, st) : rg_launch<false, 0>(a, e, grid, st); break;

@@ -289,32 +289,33 @@ __global__ __launch_bounds__(RG_THREADS) void conv3x3_ring_kernel(cdfo_conv_args
         // the chunk's four taps are a 2x2 window of the 3x3 stencil (checked by the host wrapper): top-left (y0, x0)
         const unsigned tm = e.tap_mask[c];
         const int win = ((tm & 0x7u) ? 0 : 2) + ((tm & 0x49u) ? 0 : 1);
-        auto window = [&](auto Y0, auto X0) {
-          constexpr int y0 = decltype(Y0)::value, x0 = decltype(X0)::value;
-          auto load_frags = [&](int j, int par) {      // j = dy*2 + dx inside the window = slab slot
-            const int dy = y0 + (j >> 1), dx = x0 + (j & 1);
+        // (round 3: no switch over the four windows -- with four copies of the tap loop hipcc sits at 256 VGPRs and spills; the
+        // window origin enters through six fragment addresses computed per chunk)
+        const int y0 = win >> 1, x0 = win & 1;
+        int f_off[3][2];
 #pragma unroll
-            for (int mi = 0; mi < 2; ++mi) fa[par][mi] = *reinterpret_cast<const f16x8_t*>(st + p_off[(mi + dy) * 3 + dx]);
+        for (int rr = 0; rr < 3; ++rr)
 #pragma unroll
-            for (int ni = 0; ni < 2; ++ni) fb[par][ni] = *reinterpret_cast<const f16x8_t*>(sW + (j * 2 * 64 + ni * 32) * 16);
-          };
-          load_frags(0, 0);
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            if (j < 3) load_frags(j + 1, (j & 1) ^ 1);
-            // (scheduling fences: keep the next tap's fragment reads in FRONT of this tap's MFMAs -- hipcc otherwise sinks
-            // them behind and waits on a just-issued ds_read at every tap)
-            __builtin_amdgcn_sched_barrier(0);
-            mma_tap(j & 1);
-            __builtin_amdgcn_sched_barrier(0);
-            if (do_issue) issue_piece(j);
+          for (int dx = 0; dx < 2; ++dx) {
+            const int p = (wave * 2 + rr + y0) * RG_IW + x0 + dx + r;
+            f_off[rr][dx] = (2 * p + (h ^ ((p >> 3) & 1))) * 16;
           }
+        auto load_frags = [&](int j, int par) {      // j = dy*2 + dx inside the window = slab slot
+#pragma unroll
+          for (int mi = 0; mi < 2; ++mi) fa[par][mi] = *reinterpret_cast<const f16x8_t*>(st + f_off[mi + (j >> 1)][j & 1]);
+#pragma unroll
+          for (int ni = 0; ni < 2; ++ni) fb[par][ni] = *reinterpret_cast<const f16x8_t*>(sW + (j * 2 * 64 + ni * 32) * 16);
         };
-        switch (win) {
-          case 0: window(IntC<0>{}, IntC<0>{}); break;
-          case 1: window(IntC<0>{}, IntC<1>{}); break;
-          case 2: window(IntC<1>{}, IntC<0>{}); break;
-          default: window(IntC<1>{}, IntC<1>{}); break;
+        load_frags(0, 0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          if (j < 3) load_frags(j + 1, (j & 1) ^ 1);
+          // (scheduling fences: keep the next tap's fragment reads in FRONT of this tap's MFMAs -- hipcc otherwise sinks
+          // them behind and waits on a just-issued ds_read at every tap)
+          __builtin_amdgcn_sched_barrier(0);
+          mma_tap(j & 1);
+          __builtin_amdgcn_sched_barrier(0);
+          if (do_issue) issue_piece(j);
         }
       } else {
         auto load_frags = [&](int t, int par) {

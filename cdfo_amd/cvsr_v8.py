@@ -142,7 +142,7 @@ class CVSR_V8(nn.Module):
         # HIP side streams for the two independent neighbour groups (frames 0-2 and 4-6): 1 = everything on the caller's
         # stream, 0 = auto = 2 (one side stream per group)
         self.neighbour_streams = 0
-        self.neighbour_group = 0        # frames per neighbour group: 0 = auto (3 at >= 3 clips, else 1)
+        self.neighbour_group = 0        # frames per neighbour group: 0 = auto = 3
         # fp16x2 mode, the feature extractor's two 3x3 convolutions on the ring kernel: True = activations fp16 hi + lo x
         # weights fp16 hi + lo (three terms, fp32-grade: L1_fea 1.3e-5 max-abs); False = weights rounded once to fp16 (two
         # terms): measured 1.7e-3 on the RETURNED feature cache (|L1_fea| up to 7), outside the 1e-3 bound, for 1.3 ms per
@@ -609,7 +609,7 @@ class CVSR_V8(nn.Module):
         # images instead of three times on B.  Only what reads a per-neighbour input plane (prior stems, noise draw, motion
         # field) is launched per neighbour, into slices of the group's tensors.  The two groups are independent: with
         # `neighbour_streams` > 1 they are issued on two side streams (joined before the temporal fusion).
-        nstr = int(getattr(self, "neighbour_streams", 0)) or (2 if B >= 3 else 6)
+        nstr = int(getattr(self, "neighbour_streams", 0)) or 2
         main = torch.cuda.current_stream(x.device)
         side = []
         if nstr > 1:
@@ -618,10 +618,11 @@ class CVSR_V8(nn.Module):
             if side is None:
                 side = cache[(x.device, nstr)] = [torch.cuda.Stream(x.device) for _ in range(nstr)]
         keep = []
-        # group size: three frames per group at >= 3 clips (large launches, two groups on two streams); one frame per group
-        # (six independent pipelines on up to six streams) for one or two clips, where launches are small and concurrency is
-        # what fills the GPU (the streamed B = 1 sequence: 61 vs 58 frames/s)
-        gsz = int(getattr(self, "neighbour_group", 0)) or (ctr if B >= 3 else 1)
+        # group size: three frames per group (one launch per operator and group, two groups on two streams) at every batch size.
+        # Round 2 kept one frame per group on six streams for one or two clips; measured again in round 3 on the streamed B = 1
+        # sequence (tools/bench_streaming.py, 270x480): 66.7 frames/s grouped on two streams against 62.5 (68.1 / 65.6 under
+        # HIP-graph replay)
+        gsz = int(getattr(self, "neighbour_group", 0)) or ctr
         groups = [list(range(s, min(s + gsz, e))) for (s0, e) in ((0, ctr), (ctr + 1, N)) for s in range(s0, e, gsz)]
         # the centre features once per neighbour of a group.  Enqueued on the caller's stream BEFORE the side streams fork from
         # it: they read xcG (Gram pass and last residual of _align), so the copy must be ordered ahead of their wait

@@ -204,7 +204,7 @@ def main():
     # rank 0 ALSO checks clip 0 of its timed batch at the timed size (the grouped, two-stream, full-size schedule that c1's
     # one-frame-per-stream small-shape kernels do not exercise) while the other ranks wait at the barrier.
     max_abs, psnr, cpu = float("nan"), float("nan"), None
-    max_abs_full, ref_out_full, cap_full = float("nan"), None, None
+    max_abs_full, ref_out_full, cap_full, pending_full = float("nan"), None, None, None
     parity_cfg = "skipped (--no-parity)"
     if not args.no_parity:
         full = not args.streaming and (world == 1 or (rank == 0 and not args.no_full_size_parity))
@@ -214,19 +214,14 @@ def main():
             got, _ = step()
             model.capture_noise = None
             cap_full = injected if args.injected_noise else cap
-            noise0 = [u[0:1].cpu() for u in cap_full]
-            clip0 = {k: (v[0:1].cpu() if v is not None else None) for k, v in d.items()}
-            ref_out_full, cpu = oracle_clip(sd, clip0, noise0, Hp, Wp, time_it=(world == 1 and not args.no_cpu_baseline))
-            g0 = got[0:1].cpu()
-            max_abs_full = (g0 - ref_out_full).abs().max().item()
+            # The CPU oracle on this clip (tens of seconds of host work) runs AFTER the timed region: a GPU that sat idle through
+            # it clocks down, and the first timed steps after a one-step warm-up would be measured on a cold device
+            pending_full = (got[0:1].cpu(), [u[0:1].cpu() for u in cap_full],
+                            {k: (v[0:1].cpu() if v is not None else None) for k, v in d.items()})
             parity_cfg = f"clip 0 of the timed batch ({Hp}x{Wp}, noise as drawn by the timed path) vs CPU oracle"
-            if world == 1:
-                max_abs, psnr = max_abs_full, psnr_y(g0, ref_out_full)
-                if args.no_extra_modes or args.precision == "bf16":
-                    cap_full = None                     # only the bf16_plain extra replays this noise
-            else:                                       # back to this rank's share of the host for the small check below
-                cap_full = None
-                torch.set_num_threads(max(1, (os.cpu_count() or world) // world))
+            if world > 1 or args.no_extra_modes or args.precision == "bf16":
+                cap_full = None                         # only the bf16_plain extra replays this noise
+            del got
         if world > 1 or args.streaming:
             c1 = make_inputs(1, 64, 64, 1000)
             cap = []
@@ -242,7 +237,7 @@ def main():
             small = "c1 64x64 B=1 (noise as drawn by the default path) vs CPU oracle, on every rank"
             if args.streaming:
                 parity_cfg = small + " -- small-config only (the streaming path's timed size is not checked here)"
-            elif math.isfinite(max_abs_full):
+            elif full:
                 parity_cfg = small + f"; rank 0 also: clip 0 of its timed batch at {Hp}x{Wp} (the grouped, two-stream, full-size schedule)"
             else:
                 parity_cfg = small + " -- small-config only (--no-full-size-parity)"
@@ -284,21 +279,31 @@ def main():
             extra["bf16x3_fp32_grade"] = {"frames_per_s": round(B * nst / t, 3), "ms_per_step": round(1e3 * t / nst, 3),
                                           "steps": nst, "note": "split-bf16 3-pass MFMA everywhere: <= 1.2e-5 max-abs vs the fp32 reference"}
             model.precision = args.precision
-        if args.precision != "bf16" and cap_full is not None and ref_out_full is not None:
+        if args.precision != "bf16" and cap_full is not None and pending_full is not None:
             # BASELINE's literal c3 dtype: plain bf16 MFMA (one rounding of activations and weights, fp32 accumulate) on the same
-            # batch, replaying the noise of the parity forward so that clip 0 compares with the same oracle output
+            # batch, replaying the noise of the parity forward so that clip 0 compares with the same oracle output (below)
             model.precision = "bf16"
             gb, _ = step(cap_full)
             t, _ = timed(nst, cap_full)
-            g0b = gb[0:1].cpu()
-            eb = (g0b - ref_out_full).abs().max().item()
-            extra["bf16_plain"] = {"frames_per_s": round(B * nst / t, 3), "ms_per_step": round(1e3 * t / nst, 3), "steps": nst,
-                                   "max_abs": eb, "psnr_y_db": psnr_y(g0b, ref_out_full), "within_1e-3": bool(eb <= PARITY_BOUND),
-                                   "note": "precision='bf16' (BASELINE c3's dtype), noise replayed from the parity forward; outside the "
-                                           "1e-3 bound by design of the format (8-bit mantissa), which is why it is not the default"}
+            g0_bf16 = gb[0:1].cpu()
+            extra["bf16_plain"] = {"frames_per_s": round(B * nst / t, 3), "ms_per_step": round(1e3 * t / nst, 3), "steps": nst}
             model.precision = args.precision
             del gb
         cap_full = None
+
+    # ---- the deferred full-size parity check: CPU oracle on clip 0 (also the cpu_baseline measurement at N = 1)
+    if pending_full is not None:
+        g0f, noise0, clip0 = pending_full
+        ref_out_full, cpu = oracle_clip(sd, clip0, noise0, Hp, Wp, time_it=(world == 1 and not args.no_cpu_baseline))
+        max_abs_full = (g0f - ref_out_full).abs().max().item()
+        if world == 1:
+            max_abs, psnr = max_abs_full, psnr_y(g0f, ref_out_full)
+        if "bf16_plain" in extra:
+            eb = (g0_bf16 - ref_out_full).abs().max().item()
+            extra["bf16_plain"].update({"max_abs": eb, "psnr_y_db": psnr_y(g0_bf16, ref_out_full), "within_1e-3": bool(eb <= PARITY_BOUND),
+                                        "note": "precision='bf16' (BASELINE c3's dtype), noise replayed from the parity forward; outside "
+                                                "the 1e-3 bound by design of the format (8-bit mantissa), which is why it is not the default"})
+        pending_full = None
 
     # ---- the single collective: all_gather of per-rank metrics (time, checksum, parity)
     from cdfo_amd.dist import gather_metrics
@@ -456,12 +461,15 @@ def dcn_forward_line(device, H, W, B, iters=10):
     ms = e0.elapsed_time(e1) / iters
     nbytes = (C + 3 * dg * 9 + Co) * H * W * 4 * B + w.numel() * 4
     ach = nbytes / ms / 1e6
-    traffic = None
+    traffic, traffic_commit = None, None
     tpath = next((q for q in (os.path.join(ROOT, "profiles", f"traffic_dcn_r{r:02d}.json") for r in range(9, 0, -1)) if os.path.exists(q)), "")
     if tpath and (B, H, W) == (8, 272, 480):     # PMC passes of tools/bench_dcn.py at exactly this shape
         try:
             tj = json.load(open(tpath))
-            traffic = tj["hbm_bytes_per_launch"] + tj["prepass_hbm_bytes_per_launch"]
+            # the kernel the file was measured on must be the one this build runs (dcn_win since round 3)
+            if tj.get("kernel", "").startswith("dcn_win"):
+                traffic = tj["hbm_bytes_per_launch"] + tj["prepass_hbm_bytes_per_launch"]
+                traffic_commit = tj.get("commit")
         except Exception:
             traffic = None
     # the operator's backward at the same shape (all five gradients, as tools/bench_dcn.py --backward)
@@ -481,7 +489,8 @@ def dcn_forward_line(device, H, W, B, iters=10):
     ms_b = e0.elapsed_time(e1) / iters
     return {"workload": f"DCNv2 forward C=Co=64 dg=16 3x3, {B}x{H}x{W}, MV-like offsets", "ms_per_launch": round(ms, 4),
             "roofline": {"bound": "hbm", "achieved": round(ach, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(ach / 8000.0, 4),
-                         "algorithmic_bytes_per_launch": nbytes, "traffic": traffic},
+                         "algorithmic_bytes_per_launch": nbytes, "traffic": traffic,
+                         "traffic_ratio": (round(traffic / nbytes, 3) if traffic else None), "profiles_commit": traffic_commit},
             "backward_ms_per_launch": round(ms_b, 4)}
 
 

@@ -34,6 +34,21 @@ def main():
         fh.write("launches  FETCH_KiB  WRITE_KiB  HBM_MB_per_launch  total_GiB  kernel\n")
         for tot, k, n, f, w in rows[:40]:
             fh.write(f"{n:6d} {f:12.1f} {w:12.1f} {(2 * f + w) * 1024 / 1e6:12.1f} {tot * 1024 / 2**30:10.2f}  {k[:150]}\n")
+    if "--dcn" in sys.argv:      # the DCN forward line of bench.py: main kernel + everything else the operator call launches
+        i = sys.argv.index("--dcn")
+        jpath, commit = sys.argv[i + 1:i + 3]
+        def tot(match):
+            f = sum(sum(v) / len(v) for k, v in F.items() if match(k))
+            w = sum(sum(v) / len(v) for k, v in Wr.items() if match(k))
+            return f, w
+        main_sym = next((m for m in ("dcn_win_kernel", "dcn_fast_kernel") if any(m in k for k in F)), "dcn_fwd_kernel")
+        fm, wm = tot(lambda k: main_sym in k)
+        fp, wp = tot(lambda k: main_sym not in k and ("dcn" in k.lower()))
+        json.dump({"kernel": main_sym, "workload": "C=Co=64 dg=16 3x3 272x480 B=8", "commit": commit, "fetch_kib_raw": fm, "write_kib_raw": wm,
+                   "fetch_correction": 2.0, "hbm_bytes_per_launch": round((2.0 * fm + wm) * 1024.0),
+                   "prepass_hbm_bytes_per_launch": round((2.0 * fp + wp) * 1024.0),
+                   "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) of tools/bench_dcn.py, tools/pmc_summary.py --dcn; "
+                             "prepass = the call's other kernels (weight maximum / packing, the idle re-run kernel)"}, open(jpath, "w"), indent=1)
     if "--families" in sys.argv:
         i = sys.argv.index("--families")
         families(F, Wr, *sys.argv[i + 1:i + 4])

@@ -14,7 +14,7 @@ D="python3 tools/bench_dcn.py --iters 10" && \
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/dstats -- $D > $O/dstats.log 2>&1 && \
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/dfetch -- $D > $O/dfetch.log 2>&1 && \
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/dwrite -- $D > $O/dwrite.log 2>&1 && \
-python3 tools/pmc_summary.py $O/dfetch $O/dwrite $O/${R}_pmc_traffic_dcn_fwd.txt && \
+python3 tools/pmc_summary.py $O/dfetch $O/dwrite $O/${R}_pmc_traffic_dcn_fwd.txt --dcn $O/traffic_dcn_${R}.json $COMMIT && \
 cp $O/dstats/*/*kernel_stats.csv $O/${R}_kernel_stats_dcn_fwd.csv && \
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/bstats -- python3 tools/bench_dcn.py --backward --iters 5 > $O/bstats.log 2>&1 && \
 cp $O/bstats/*/*kernel_stats.csv $O/${R}_kernel_stats_dcn_bwd.csv && \

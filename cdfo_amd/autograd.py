@@ -23,6 +23,13 @@ from ._lib import check
 from .kernels import ACT_LRELU, ACT_NONE, ACT_RELU, ACT_SIGMOID, PackedConv, _stream, _vp
 
 F32 = K.PREC_F32
+# Arithmetic of the training path's convolutions (forward and input gradient; the weight gradient is a separate exact-fp32
+# kernel).  PREC_BF16X3 (default since round 3): 3x3 / stride 1 / pad 1 convolutions with Cin % 16 == 0 run on the split-bf16
+# three-pass MFMA kernel (fp32-grade: ~1e-6 relative per product; everything else stays exact fp32 -- kernels.conv falls back by
+# itself where the 16-bit packing does not exist); PREC_F32 (or CDFO_TRAIN_EXACT=1): the exact-fp32 MFMA everywhere, 1 / 16 of
+# the 16-bit matrix rate: 127 of the 419 ms of a training step at 20 x 64 x 64 were these convolutions.
+import os as _os
+CONV_PREC = K.PREC_F32 if _os.environ.get("CDFO_TRAIN_EXACT", "0") not in ("", "0") else K.PREC_BF16X3
 
 
 def _c(t: torch.Tensor) -> torch.Tensor:
@@ -77,7 +84,7 @@ def coldot(a: torch.Tensor, b: Optional[torch.Tensor], nimg: int, scale: float =
     Cc = a.shape[-1]
     rows = a.numel() // Cc if a.is_contiguous() else a.shape[:-1].numel()
     P = rows // nimg
-    nchunk = max(1, min(64, P // 256))
+    nchunk = max(1, min(512, P // 64))      # (round 3: 64 chunks of >= 256 rows left most of the GPU idle: 160 us per bias gradient)
     part = torch.empty(nimg * nchunk * Cc, dtype=torch.float32, device=a.device)
     out = torch.empty((nimg, Cc), dtype=torch.float32, device=a.device)
     if b is not None:
@@ -116,7 +123,7 @@ class _Conv(Function):
         srcs, res = list(ts[:nsrc]), [t for t in ts[nsrc:] if t is not None]
         pc = K.pack_conv(weight.detach(), None if bias is None else bias.detach())
         srcs_d = [_dense_rows(s.detach()) for s in srcs]
-        y = K.conv(srcs_d, pc, stride=stride, pad=pad, act=act, prec=F32)
+        y = K.conv(srcs_d, pc, stride=stride, pad=pad, act=act, prec=CONV_PREC)
         out = y
         for r in res:
             out = ew(out, _dense_rows(r.detach()), 2)
@@ -147,7 +154,7 @@ class _Conv(Function):
             if stride != 1:
                 raise NotImplementedError("input gradient of a strided convolution is only implemented for the 16-channel layers")
             wt = weight.detach().flip(2, 3).transpose(0, 1).contiguous()           # [Ci][Co][k][k]: the adjoint's weights
-            dx = K.conv([gp], K.pack_conv(wt, None), stride=1, pad=ks - 1 - pad, prec=F32)
+            dx = K.conv([gp], K.pack_conv(wt, None), stride=1, pad=ks - 1 - pad, prec=CONV_PREC)
             off = 0
             for i, c in enumerate(cs):
                 if ctx.needs_input_grad[6 + i]:
@@ -246,7 +253,7 @@ class _DwConv(Function):
         g = _c(g)
         B, H, W, Cc = x.shape
         dx = K.dwconv3x3(g, weight.detach().flip(2, 3).contiguous())
-        nblk = max(1, min(256, B * H * W // 256))
+        nblk = max(1, min(4096, B * H * W // 64))       # (round 3: 256 blocks = 2240 pixels per thread, 5.1 ms per launch)
         part = torch.empty((nblk, 9, Cc), dtype=torch.float32, device=x.device)
         check(_lib.lib().cdfo_dwconv3x3_wgrad(_vp(x), x.stride(-2), _vp(g), Cc, B, H, W, Cc, _vp(part), nblk, _stream()),
               "cdfo_dwconv3x3_wgrad")

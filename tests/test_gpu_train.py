@@ -47,26 +47,41 @@ def _hip_step(wseed, inp, hr, noise):
     return m, out.detach().cpu(), loss.item(), {k: p.grad for k, p in m.named_parameters()}
 
 
+@pytest.fixture(params=["exact", "default"])
+def conv_mode(request):
+    """The training path's two convolution arithmetics (cdfo_amd.autograd.CONV_PREC): exact-fp32 MFMA -- what the tolerances
+    below were derived for -- and the round-3 default, split-bf16 three-pass MFMA for the 3x3 convolutions (fp32-grade products;
+    the operands keep ~16 bits, so the median gradient error moves from ~3e-7-1e-6 to 1e-5-4e-5 of max |g| -- two orders below what
+    bf16 mixed-precision training works with, and below the kink noise that sets the upper percentiles; bound here: 1e-4)."""
+    from cdfo_amd import autograd as A
+    from cdfo_amd import kernels as K
+    old = A.CONV_PREC
+    A.CONV_PREC = K.PREC_F32 if request.param == "exact" else K.PREC_BF16X3
+    yield request.param
+    A.CONV_PREC = old
+
+
 @pytest.mark.parametrize("path", GOLD, ids=lambda p: os.path.basename(p)[13:-4])
-def test_hip_training_step_matches_reference_gradients(path):
+def test_hip_training_step_matches_reference_gradients(path, conv_mode):
     from oracle.cvsr_v8_ref import make_inputs
+    exact = conv_mode == "exact"
     g = np.load(path)
     B, H, W = int(g["B"]), int(g["H"]), int(g["W"])
     inp = make_inputs(B, H, W, int(g["iseed"]), "b1n")
     hr = torch.from_numpy(np.random.RandomState(int(g["hr_seed"])).uniform(0, 1, (B, 1, 4 * H, 4 * W)).astype(np.float32))
     m, out, loss, grads = _hip_step(int(g["wseed"]), inp, hr, [u.cuda() for u in inp["gumbel_u"]])
-    assert np.abs(out.numpy() - g["out"]).max() <= 1e-5
+    assert np.abs(out.numpy() - g["out"]).max() <= (1e-5 if exact else 3e-5)
     assert abs(loss - float(g["loss"])) <= 1e-5 * abs(float(g["loss"]))
     rows = golden_errors(g, grads)
     errs = np.array([r[0] for r in rows])
-    print(f"HIP training step vs the reference's gradients ({os.path.basename(path)}): {len(rows)} tensors, median {np.median(errs):.2e}, "
-          f"90th percentile {np.quantile(errs, 0.9):.2e}, worst {rows[0][0]:.2e} ({rows[0][1]})")
-    assert np.median(errs) <= 5e-6 and np.quantile(errs, 0.75) <= 1e-3 and np.quantile(errs, 0.9) <= 5e-3 and errs.max() <= 2e-2
+    print(f"HIP training step ({conv_mode} convolutions) vs the reference's gradients ({os.path.basename(path)}): {len(rows)} tensors, "
+          f"median {np.median(errs):.2e}, 90th percentile {np.quantile(errs, 0.9):.2e}, worst {rows[0][0]:.2e} ({rows[0][1]})")
+    assert np.median(errs) <= (5e-6 if exact else 1e-4) and np.quantile(errs, 0.75) <= 1e-3 and np.quantile(errs, 0.9) <= 5e-3 and errs.max() <= 2e-2
     if H * W <= 64:
         assert errs.max() <= 1e-3
 
 
-def test_hip_training_step_matches_oracle_autograd_at_another_size():
+def test_hip_training_step_matches_oracle_autograd_at_another_size(conv_mode):
     """B = 2 clips of 24x16 (non-square, two images per launch: per-image attention weights, batch strides).  Truth = the
     oracle's float64 autograd; the HIP (fp32) gradients must be as close to it as the oracle's own float32 gradients are."""
     from oracle.cvsr_v8_ref import make_inputs
@@ -76,7 +91,8 @@ def test_hip_training_step_matches_oracle_autograd_at_another_size():
     inp = make_inputs(2, 24, 16, 301, "b1n")
     hr = torch.from_numpy(np.random.RandomState(308).uniform(0, 1, (2, 1, 96, 64)).astype(np.float32))
     m, out, loss, grads = _hip_step(31, inp, hr, [u.cuda() for u in inp["gumbel_u"]])
-    assert (out.double() - out_o).abs().max().item() <= 1e-5
+    exact = conv_mode == "exact"
+    assert (out.double() - out_o).abs().max().item() <= (1e-5 if exact else 3e-5)
     rows = []
     for k, go in g64.items():
         if go is None:
@@ -88,9 +104,9 @@ def test_hip_training_step_matches_oracle_autograd_at_another_size():
         rows.append(((grads[k].cpu().double() - go).abs().max().item() / scale, (g32[k].double() - go).abs().max().item() / scale, k))
     rows.sort(reverse=True)
     e_hip, e_cpu = np.array([r[0] for r in rows]), np.array([r[1] for r in rows])
-    print(f"24x16, B=2 vs float64 oracle autograd: HIP median {np.median(e_hip):.2e} (float32 CPU oracle {np.median(e_cpu):.2e}), "
+    print(f"24x16, B=2 ({conv_mode} convolutions) vs float64 oracle autograd: HIP median {np.median(e_hip):.2e} (float32 CPU oracle {np.median(e_cpu):.2e}), "
           f"90th percentile {np.quantile(e_hip, 0.9):.2e}, worst {rows[0][0]:.2e} ({rows[0][2]})")
-    assert np.median(e_hip) <= max(5e-6, 3 * np.median(e_cpu)) and np.quantile(e_hip, 0.75) <= 1e-3 and np.quantile(e_hip, 0.9) <= 5e-3 \
+    assert np.median(e_hip) <= (max(5e-6, 3 * np.median(e_cpu)) if exact else 1e-4) and np.quantile(e_hip, 0.75) <= 1e-3 and np.quantile(e_hip, 0.9) <= 5e-3 \
         and e_hip.max() <= 2e-2
 
 

@@ -103,8 +103,9 @@ def conv_wgrad(S: torch.Tensor, L: torch.Tensor, ks: int, stride: int, pad: int,
     nsplit = max(1, min(N * Hs // 4 if N * Hs >= 4 else 1, 1024 // nblk if nblk < 1024 else 1, 256))
     n = int(_lib.lib().cdfo_conv_wgrad_slab_floats(A, Bc, ks, nsplit))
     slab = torch.empty(n, dtype=torch.float32, device=S.device)
-    check(_lib.lib().cdfo_conv_wgrad(_vp(S), S.stride(-2), A, _vp(L), L.stride(-2), Bc, N, Hs, Ws, Hl, Wl, ks, stride, pad, nsplit,
-                                     _vp(slab), _vp(dw), Btot, b_off, _stream()), "cdfo_conv_wgrad")
+    prec = CONV_PREC if (ks == 3 and A >= 16 and Bc >= 16) else F32      # the 16-bit form where the convolutions themselves use it
+    check(_lib.lib().cdfo_conv_wgrad_prec(_vp(S), S.stride(-2), A, _vp(L), L.stride(-2), Bc, N, Hs, Ws, Hl, Wl, ks, stride, pad, nsplit,
+                                          _vp(slab), _vp(dw), Btot, b_off, prec, _stream()), "cdfo_conv_wgrad_prec")
 
 
 def _pack_per_image(Wb: torch.Tensor) -> PackedConv:

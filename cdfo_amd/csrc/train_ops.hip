@@ -106,6 +106,90 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(wg_args g) {
   }
 }
 
+// The same block decomposition with split-bf16 operands (round 3): 16 pixels per step instead of 2 -- a lane loads 8 consecutive
+// pixels of its a / b channel (the K half its fragment holds), splits them into bf16 hi + lo in registers and the step runs
+// hi*lo + lo*hi + hi*hi on v_mfma_f32_32x32x16_bf16: 12 MFMAs of 32 cycles per 16 pixels against 32 of 64 cycles above.
+typedef __bf16 wg_bf16x8 __attribute__((ext_vector_type(8)));
+__global__ __launch_bounds__(256) void conv_wgrad_bf16x3_kernel(wg_args g) {
+  __shared__ float red[3][64 * 64];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, r = lane & 31, kk = lane >> 5;
+  const int ab = blockIdx.x % g.a_blocks, bb = blockIdx.x / g.a_blocks;
+  const int tap = blockIdx.y, ky = tap / g.ks, kx = tap - ky * g.ks, sp = blockIdx.z;
+  const long long rows = (long long)g.N * g.Hs;
+  const long long r0 = rows * sp / g.nsplit, r1 = rows * (sp + 1) / g.nsplit;
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+  const int a0 = ab * 64 + r, b0 = bb * 64 + r;
+  const bool am[2] = {a0 < g.A, a0 + 32 < g.A}, bm[2] = {b0 < g.Bc, b0 + 32 < g.Bc};
+  int x_lo = 0, x_hi = g.Ws;
+  {
+    const int off = kx - g.pad;
+    if (off < 0) x_lo = (-off + g.stride - 1) / g.stride;
+    const int lim = g.Wl - 1 - off;
+    x_hi = lim < 0 ? 0 : min(g.Ws, lim / g.stride + 1);
+  }
+  for (long long row = r0 + wave; row < r1; row += 4) {
+    const int n = (int)(row / g.Hs), y = (int)(row - (long long)n * g.Hs);
+    const int yl = y * g.stride + ky - g.pad;
+    if (yl < 0 || yl >= g.Hl) continue;
+    const float* Sr = g.S + ((long long)n * g.Hs + y) * g.Ws * g.lds_;
+    const float* Lr = g.L + (((long long)n * g.Hl + yl) * g.Wl + (kx - g.pad)) * g.ldl;
+    for (int x = x_lo; x < x_hi; x += 16) {
+      wg_bf16x8 sh[2], sl[2], lh[2], ll[2];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int xx = x + 8 * kk + j;
+        const bool v = xx < x_hi;
+        const float* sp_ = Sr + (long long)(v ? xx : x_lo) * g.lds_;
+        const float* lp = Lr + (long long)(v ? xx : x_lo) * g.stride * g.ldl;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          const float sv = (v && am[i]) ? sp_[a0 + 32 * i] : 0.f, lv = (v && bm[i]) ? lp[b0 + 32 * i] : 0.f;
+          sh[i][j] = (__bf16)sv; sl[i][j] = (__bf16)(sv - (float)sh[i][j]);
+          lh[i][j] = (__bf16)lv; ll[i][j] = (__bf16)(lv - (float)lh[i][j]);
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sh[i], ll[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sl[i], lh[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sh[i], lh[j], acc[i][j], 0, 0, 0);
+        }
+    }
+  }
+  if (wave > 0) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e)
+          red[wave - 1][(i * 32 + (e & 3) + 8 * (e >> 2) + 4 * kk) * 64 + j * 32 + r] = acc[i][j][e];
+  }
+  __syncthreads();
+  if (wave == 0) {
+    const int T = g.ks * g.ks;
+    float* out = g.slab + (((long long)sp * T + tap) * (g.a_blocks * 64)) * (g.b_blocks * 64);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int ra = i * 32 + (e & 3) + 8 * (e >> 2) + 4 * kk, cb = j * 32 + r;
+          const float v = ((acc[i][j][e] + red[0][ra * 64 + cb]) + red[1][ra * 64 + cb]) + red[2][ra * 64 + cb];
+          out[(long long)(ab * 64 + ra) * (g.b_blocks * 64) + bb * 64 + cb] = v;
+        }
+  }
+}
+
 // dw[(a * Btot + b_off + b) * T + tap] = scale * sum_sp slab[sp][tap][a][b]   (fixed order)
 __global__ __launch_bounds__(256) void conv_wgrad_reduce_kernel(const float* __restrict__ slab, int nsplit, int T, int A, int Bc,
                                                                 int Apad, int Bpad, int Btot, int b_off, float* __restrict__ dw) {
@@ -623,16 +707,27 @@ extern "C" long long cdfo_conv_wgrad_slab_floats(int A, int Bc, int ks, int nspl
   return (long long)nsplit * ks * ks * ((A + 63) / 64 * 64) * ((Bc + 63) / 64 * 64);
 }
 
+extern "C" int cdfo_conv_wgrad_prec(const float* S, int lds_, int A, const float* L, int ldl, int Bc, int N, int Hs, int Ws, int Hl,
+                                    int Wl, int ks, int stride, int pad, int nsplit, float* slab, float* dw, int Btot, int b_off,
+                                    int prec, void* stream);
 extern "C" int cdfo_conv_wgrad(const float* S, int lds_, int A, const float* L, int ldl, int Bc, int N, int Hs, int Ws, int Hl,
                                int Wl, int ks, int stride, int pad, int nsplit, float* slab, float* dw, int Btot, int b_off,
                                void* stream) {
+  return cdfo_conv_wgrad_prec(S, lds_, A, L, ldl, Bc, N, Hs, Ws, Hl, Wl, ks, stride, pad, nsplit, slab, dw, Btot, b_off, CDFO_PREC_F32, stream);
+}
+
+extern "C" int cdfo_conv_wgrad_prec(const float* S, int lds_, int A, const float* L, int ldl, int Bc, int N, int Hs, int Ws, int Hl,
+                                    int Wl, int ks, int stride, int pad, int nsplit, float* slab, float* dw, int Btot, int b_off,
+                                    int prec, void* stream) {
   if (!S || !L || !slab || !dw || A <= 0 || Bc <= 0 || N <= 0 || Hs <= 0 || Ws <= 0 || Hl <= 0 || Wl <= 0 || ks <= 0 || ks > 9 ||
       stride <= 0 || nsplit <= 0 || nsplit > 65535 || lds_ < A || ldl < Bc || Btot < b_off + Bc)
     return CDFO_EINVAL;
   hipStream_t st = static_cast<hipStream_t>(stream);
   wg_args g{S, lds_, A, L, ldl, Bc, N, Hs, Ws, Hl, Wl, ks, stride, pad, slab, nsplit, (A + 63) / 64, (Bc + 63) / 64};
   CdfoProfScope prof(st, KID_CONV3_NARROW, 2.0 * N * Hs * Ws * (double)A * Bc * ks * ks, 4.0 * N * ((double)Hs * Ws * A + (double)Hl * Wl * Bc));
-  hipLaunchKernelGGL(conv_wgrad_kernel, dim3(g.a_blocks * g.b_blocks, ks * ks, nsplit), dim3(256), 0, st, g);
+  if (prec != CDFO_PREC_F32 && prec != CDFO_PREC_BF16X3) return CDFO_EINVAL;
+  if (prec == CDFO_PREC_BF16X3) hipLaunchKernelGGL(conv_wgrad_bf16x3_kernel, dim3(g.a_blocks * g.b_blocks, ks * ks, nsplit), dim3(256), 0, st, g);
+  else hipLaunchKernelGGL(conv_wgrad_kernel, dim3(g.a_blocks * g.b_blocks, ks * ks, nsplit), dim3(256), 0, st, g);
   hipLaunchKernelGGL(conv_wgrad_reduce_kernel, dim3(tr_grid((long long)A * Bc * ks * ks)), dim3(256), 0, st, slab, nsplit, ks * ks, A, Bc,
                      g.a_blocks * 64, g.b_blocks * 64, Btot, b_off, dw);
   CDFO_LAUNCH_CHECK();

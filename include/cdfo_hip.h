@@ -335,6 +335,11 @@ int cdfo_dcn_backward_dt(int dtype, const void* in, const void* offset, const vo
 long long cdfo_conv_wgrad_slab_floats(int A, int Bc, int ks, int nsplit);
 int cdfo_conv_wgrad(const float* S, int lds_, int A, const float* L, int ldl, int Bc, int N, int Hs, int Ws, int Hl, int Wl,
                     int ks, int stride, int pad, int nsplit, float* slab, float* dw, int Btot, int b_off, void* stream);
+/* the same contraction with both operands split into bf16 hi + lo on the fly (three MFMA passes, fp32 accumulate: ~16 operand
+ * bits) -- the training path's default since round 3; prec = CDFO_PREC_F32 runs cdfo_conv_wgrad's exact kernel */
+int cdfo_conv_wgrad_prec(const float* S, int lds_, int A, const float* L, int ldl, int Bc, int N, int Hs, int Ws, int Hl, int Wl,
+                         int ks, int stride, int pad, int nsplit, float* slab, float* dw, int Btot, int b_off, int prec,
+                         void* stream);
 int cdfo_coldot(const float* a, int lda, const float* b, int ldb, int nimg, long long P, int C, int nchunk, float scale,
                 float* part, float* out, void* stream);
 int cdfo_ew(const float* a, int lda, const float* b, int ldb, long long rows, int C, int mode, int aux, float scale, long long P,

@@ -221,14 +221,18 @@ __global__ __launch_bounds__(256) void coldot_partial_kernel(const float* __rest
   __syncthreads();
   if (rl == 0 && c < C) part[((long long)img * nchunk + chunk) * C + c] = ((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x];
 }
+// one WAVE per output: lane l sums chunks l, l + 64, ... (fixed order), then a fixed shuffle tree -- a serial sum over up to 512
+// chunks by a handful of threads took 100 us per bias gradient
 __global__ __launch_bounds__(256) void coldot_finish_kernel(const float* __restrict__ part, int nchunk, int C, int nimg, float scale,
                                                             float* __restrict__ out) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (i >= nimg * C) return;
   const int img = i / C, c = i - img * C;
   float s = 0.f;
-  for (int k = 0; k < nchunk; ++k) s += part[((long long)img * nchunk + k) * C + c];
-  out[i] = s * scale;
+  for (int k = lane; k < nchunk; k += 64) s += part[((long long)img * nchunk + k) * C + c];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+  if (lane == 0) out[i] = s * scale;
 }
 
 // ------------------------------------------------------------------------------------------------ element-wise
@@ -741,7 +745,7 @@ extern "C" int cdfo_coldot(const float* a, int lda, const float* b, int ldb, int
     return CDFO_EINVAL;
   hipStream_t st = static_cast<hipStream_t>(stream);
   hipLaunchKernelGGL(coldot_partial_kernel, dim3(nchunk, (C + 63) / 64, nimg), dim3(256), 0, st, a, lda, b, ldb, P, C, nchunk, part);
-  hipLaunchKernelGGL(coldot_finish_kernel, dim3((nimg * C + 255) / 256), dim3(256), 0, st, part, nchunk, C, nimg, scale, out);
+  hipLaunchKernelGGL(coldot_finish_kernel, dim3((nimg * C + 3) / 4), dim3(256), 0, st, part, nchunk, C, nimg, scale, out);
   CDFO_LAUNCH_CHECK();
   return 0;
 }

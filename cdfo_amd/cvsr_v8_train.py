@@ -136,6 +136,15 @@ def forward_train(model, x, mvs0, mvs1, pms, rms, ufs, noise):
     P: Dict[str, torch.Tensor] = dict(model.named_parameters())
     B, N, C, H, W = x.shape
     ctr = N // 2
+    # Envelope: the backward kernels of this path are sized for the training scripts' crops (train_LD_37.py:39,316-325: 64 x 64).
+    # Several are serial by construction at large frames -- the spatial gate's weight gradient runs 99 workgroups over all pixels,
+    # the attention backward re-reads a sequence's keys for every query pair (O(L^2) global reads) -- so a grad-enabled forward at
+    # validation size works but is slow; say so once instead of silently entering it (evaluation belongs under torch.no_grad()).
+    if H * W > 256 * 256 and not getattr(model, "_warned_train_size", False):
+        import warnings
+        warnings.warn(f"CVSR_V8 (HIP): autograd forward at {H}x{W}: the training path is tuned for 64x64 crops; wrap evaluation in "
+                      "torch.no_grad() to get the fused inference schedule")
+        model._warned_train_size = True
     x = x.contiguous().float()
     pms = pms.contiguous().float()
     mvs1 = mvs1.contiguous().float()

@@ -1,5 +1,5 @@
 """Developer tool (GPU box only): event-bracketed time of every cdfo_amd.kernels call of one single-stream CVSR_V8
-forward at the c3 shape, grouped by (function, tensor shapes).  Nested wrappers (a call made by another K function)
+forward at the c3 shape (--batch N clips, --streaming = the cached-feature call), grouped by (function, tensor shapes).  Nested wrappers (a call made by another K function)
 are charged to the outermost call only."""
 import sys, os, collections, types
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -43,6 +43,8 @@ def wrap(name, fn):
 def main():
     B, H, W = 8, 272, 480
     streaming = "--streaming" in sys.argv
+    if "--batch" in sys.argv:
+        B = int(sys.argv[sys.argv.index("--batch") + 1])
     m = CVSR_V8()
     m = m.cuda().eval()
     m.neighbour_streams = 1

@@ -143,6 +143,13 @@ class CVSR_V8(nn.Module):
         # stream, 0 = auto = 2 (one side stream per group)
         self.neighbour_streams = 0
         self.neighbour_group = 0        # frames per neighbour group: 0 = auto = 3
+        # cached-feature call on one sequence (B = 1): the group of frames 0-2 (cached features only) starts beside the new
+        # frame's feature extraction instead of behind it (see _forward)
+        self.overlap_new_frame = os.environ.get("CDFO_OVERLAP_NEW", "1") not in ("", "0")
+        # ... and the new frame's own neighbour pipeline follows the extraction as a group of one, frames 4-5 on the second side
+        # stream (tools/bench_streaming.py, 24 frames 270x480, eager / HIP graph: 65.4 / 67.1 frames/s without the overlap,
+        # 66.7 / 67.6 with it, 66.9 / 68.0 with the new frame alone)
+        self.new_frame_alone = os.environ.get("CDFO_NEW_ALONE", "1") not in ("", "0")
         # fp16x2 mode, the feature extractor's two 3x3 convolutions on the ring kernel: True = activations fp16 hi + lo x
         # weights fp16 hi + lo (three terms, fp32-grade: L1_fea 1.3e-5 max-abs); False = weights rounded once to fp16 (two
         # terms): measured 1.7e-3 on the RETURNED feature cache (|L1_fea| up to 7), outside the 1e-3 bound, for 1.3 ms per
@@ -583,19 +590,33 @@ class CVSR_V8(nn.Module):
         mvs1 = mvs1.contiguous().float()
         P = H * W
 
+        nstr = int(getattr(self, "neighbour_streams", 0)) or 2       # see step 2
+        gsz = int(getattr(self, "neighbour_group", 0)) or ctr
+        deferred_new = None
+
         # 1. feature extraction (arch.py:4416-4427)
         if pre_L1_fea is None:
             f = K.stem_conv(x, P, B * N, H, W, raw["conv_first.weight"], raw["conv_first.bias"], K.ACT_LRELU)
             L1 = self._feature_extraction(w, f, pms, P, B * N)           # [B*7,H,W,64], clip-major
         else:
             last_x, last_p = x[:, -1].contiguous(), pms[:, -1].contiguous()
-            f = K.stem_conv(last_x, P, B, H, W, raw["conv_first.weight"], raw["conv_first.bias"], K.ACT_LRELU)
-            new = self._feature_extraction(w, f, last_p, P, B)           # [B,H,W,64]
             pre = self._as_pixel_major(pre_L1_fea, B * N, H, W)
             L1 = torch.empty_like(pre)
             L1v, prev = L1.view(B, N, H, W, NF), pre.view(B, N, H, W, NF)
             L1v[:, :-1].copy_(prev[:, 1:])                               # device-side shift of the feature cache
-            L1v[:, -1].copy_(new)
+
+            def new_frame_features():
+                f = K.stem_conv(last_x, P, B, H, W, raw["conv_first.weight"], raw["conv_first.bias"], K.ACT_LRELU)
+                L1v[:, -1].copy_(self._feature_extraction(w, f, last_p, P, B))       # [B,H,W,64]
+
+            # One streamed sequence (B = 1, test_LD_22_FPS.py:155-192): L1 is already frame-major, and the neighbour group of
+            # frames 0-2 reads cached features only.  It is forked onto its side stream BEFORE the new frame's feature
+            # extraction is enqueued -- ~35 launches on ONE frame, which leave most of the GPU idle -- and runs beside it;
+            # the group that holds the new frame follows the extraction on the caller's stream.
+            if B == 1 and nstr > 1 and gsz == ctr and self.overlap_new_frame:
+                deferred_new = new_frame_features
+            else:
+                new_frame_features()
         Lf = (K.swap_outer(L1, B, N) if B > 1 else L1).view(N, B, H, W, NF)   # frame-major views for the loop
 
         # 2. per-neighbour compensation + alignment (arch.py:4443-4460)
@@ -609,7 +630,6 @@ class CVSR_V8(nn.Module):
         # images instead of three times on B.  Only what reads a per-neighbour input plane (prior stems, noise draw, motion
         # field) is launched per neighbour, into slices of the group's tensors.  The two groups are independent: with
         # `neighbour_streams` > 1 they are issued on two side streams (joined before the temporal fusion).
-        nstr = int(getattr(self, "neighbour_streams", 0)) or 2
         main = torch.cuda.current_stream(x.device)
         side = []
         if nstr > 1:
@@ -622,21 +642,25 @@ class CVSR_V8(nn.Module):
         # Round 2 kept one frame per group on six streams for one or two clips; measured again in round 3 on the streamed B = 1
         # sequence (tools/bench_streaming.py, 270x480): 66.7 frames/s grouped on two streams against 62.5 (68.1 / 65.6 under
         # HIP-graph replay)
-        gsz = int(getattr(self, "neighbour_group", 0)) or ctr
         groups = [list(range(s, min(s + gsz, e))) for (s0, e) in ((0, ctr), (ctr + 1, N)) for s in range(s0, e, gsz)]
+        if deferred_new is not None and self.new_frame_alone:
+            groups = [list(range(0, ctr)), list(range(ctr + 1, N - 1)), [N - 1]]     # the new frame is a group of its own
         # the centre features once per neighbour of a group.  Enqueued on the caller's stream BEFORE the side streams fork from
         # it: they read xcG (Gram pass and last residual of _align), so the copy must be ordered ahead of their wait
         xcG = Lf[ctr].repeat(gsz, 1, 1, 1) if gsz > 1 else Lf[ctr]
         for st in side:
             st.wait_stream(main)
+        if deferred_new is not None:
+            deferred_new()       # on the caller's stream, behind the fork: the side streams do not wait for it
         aligned_by_frame = {}
         draw0 = 0
         for gi, idxs in enumerate(groups):
-            ctx = torch.cuda.stream(side[gi % len(side)]) if side else contextlib.nullcontext()
+            on_side = bool(side) and not (deferred_new is not None and N - 1 in idxs)
+            ctx = torch.cuda.stream(side[gi % len(side)]) if on_side else contextlib.nullcontext()
             with ctx:
                 al = self._neighbour_group(w, raw, Lf, idxs, xcG, ufs, rms, mvs1, noise, draw0, B, H, W, P, N, keep)
             draw0 += len(idxs)
-            if side:
+            if on_side:
                 al.record_stream(main)               # produced on a side stream, consumed on the caller's
             for n, i in enumerate(idxs):
                 aligned_by_frame[i] = al[n * B:(n + 1) * B]

@@ -19,12 +19,15 @@ def main():
     mv = np.repeat(np.repeat(mv, 8, axis=2), 8, axis=3)[:, :, :H, :W]
     model = CVSR_V8()
     model = model.cuda().eval()
-    for use_graph, nstr, grp in ((False, 1, 1), (True, 1, 1), (False, 6, 1), (True, 6, 1), (False, 2, 3), (True, 2, 3), (True, 1, 3)):
-        model.neighbour_streams, model.neighbour_group = nstr, grp
+    # (HIP graph, neighbour streams, frames per group, group of frames 0-2 beside the new frame's feature extraction, new frame alone)
+    for use_graph, nstr, grp, ovl, alone in ((False, 2, 3, False, False), (True, 2, 3, False, False), (False, 2, 3, True, False),
+                                             (True, 2, 3, True, False), (False, 2, 3, True, True), (True, 2, 3, True, True),
+                                             (True, 1, 3, False, False)):
+        model.neighbour_streams, model.neighbour_group, model.overlap_new_frame, model.new_frame_alone = nstr, grp, ovl, alone
         s = StreamingSR(model, lr, pms, rms, ufs, mv[0], mv[1], use_graph=use_graph)
         s.run()                               # warm-up (weight packing, first-touch allocations, graph capture)
         outs = s.run()
-        print(f"streaming, 1 sequence of {T} frames {H}x{W} -> {tuple(outs[0].shape)}, HIP graph {use_graph}, neighbour streams {nstr}, frames per group {grp}: "
+        print(f"streaming, 1 sequence of {T} frames {H}x{W} -> {tuple(outs[0].shape)}, HIP graph {use_graph}, neighbour streams {nstr}, frames per group {grp}, overlap {ovl}, new frame alone {alone}: "
               f"{s.fps:.2f} frames/s ({1e3 * s.seconds / T:.1f} ms per frame, forward only, B=1)", flush=True)
 
 

@@ -44,7 +44,8 @@ template <bool SPARSE> struct RingLds {
   static constexpr int ETILE = NS * STAGE;
   static constexpr int DUMP = ETILE + (SPARSE ? RG_ET_PIECES * 1024 : 0);         // target of the padding DMA pieces
   static constexpr int BIAS = DUMP + 1024;
-  static constexpr int TOTAL = BIAS + 4096;
+  static constexpr int WINTAB = BIAS + 4096;                                      // four-tap form: window origin per chunk (bytes)
+  static constexpr int TOTAL = WINTAB + (SPARSE ? 1024 : 0);
 };
 
 typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
@@ -117,6 +118,13 @@ __global__ __launch_bounds__(RG_THREADS) void conv3x3_ring_kernel(cdfo_conv_args
   for (int i = tid; i < a.CoutP; i += RG_THREADS)
     reinterpret_cast<float*>(smem + L::BIAS)[i] = (a.bias && i < a.Cout) ? a.bias[i] : 0.f;
   // (made visible to the other waves by the barriers of the chunk loop, long before the first epilogue)
+  // four-tap form: the chunk's four taps are a 2x2 window of the 3x3 stencil (checked by the host wrapper); its origin
+  // (2 y0 + x0) per chunk goes into an LDS table ONCE.  Reading e.tap_mask[c] inside the chunk loop (rounds 2-3) put a
+  // vector global load and the compiler's s_waitcnt vmcnt(0) -- which also drains every LDS-DMA piece in flight -- between
+  // the barrier and the chunk's first MFMA: one exposed memory latency per chunk in every wave at once.
+  auto win_of = [](unsigned tm) { return ((tm & 0x7u) ? 0 : 2) + ((tm & 0x49u) ? 0 : 1); };
+  if (SPARSE)
+    for (int i = tid; i < nc; i += RG_THREADS) smem[L::WINTAB + i] = (unsigned char)win_of(e.tap_mask[i]);
 
   // ---- per-lane DMA descriptors
   // activation piece q = PPW*wave + j: slot s = 64 q + lane -> pixel p = s >> 1 of the 18 x 34 halo, k-half
@@ -222,6 +230,21 @@ __global__ __launch_bounds__(RG_THREADS) void conv3x3_ring_kernel(cdfo_conv_args
   const float slope = a.act == CDFO_ACT_NONE ? 1.f : (a.act == CDFO_ACT_LRELU ? 0.1f : 0.f);
 
   int g = 0;                          // batch being consumed
+  // four-tap form: LDS byte addresses (stage base included) of the six fragment positions of the chunk about to be consumed --
+  // halo rows 2w + rr + y0, columns x0 + dx + r.  Computed one chunk AHEAD, behind the previous chunk's last MFMAs: nothing but
+  // the fragment reads themselves sits between a chunk's barrier and its first MFMA.
+  int f_cur[3][2] = {{0, 0}, {0, 0}, {0, 0}};
+  auto frag_addresses = [&](int win, int stage_base) {
+    const int y0 = win >> 1, x0 = win & 1;
+#pragma unroll
+    for (int rr = 0; rr < 3; ++rr)
+#pragma unroll
+      for (int dx = 0; dx < 2; ++dx) {
+        const int p = (wave * 2 + rr + y0) * RG_IW + x0 + dx + r;
+        f_cur[rr][dx] = stage_base + (2 * p + (h ^ ((p >> 3) & 1))) * 16;
+      }
+  };
+  if (SPARSE) frag_addresses(__builtin_amdgcn_readfirstlane(win_of(e.tap_mask[0])), 0);
   for (int ord = 0; ord < my_units; ++ord) {
     // transposed product: M = output channels (weights = A operand), N = pixels -> acc[ni][mi][8jj + q] is channel
     // ni*32 + jj*16 + h*8 + q of pixel r in tile row 2w + mi
@@ -286,27 +309,17 @@ __global__ __launch_bounds__(RG_THREADS) void conv3x3_ring_kernel(cdfo_conv_args
           }
       };
       if (SPARSE) {
-        // the chunk's four taps are a 2x2 window of the 3x3 stencil (checked by the host wrapper): top-left (y0, x0)
-        const unsigned tm = e.tap_mask[c];
-        const int win = ((tm & 0x7u) ? 0 : 2) + ((tm & 0x49u) ? 0 : 1);
         // (round 3: no switch over the four windows -- with four copies of the tap loop hipcc sits at 256 VGPRs and spills; the
-        // window origin enters through six fragment addresses computed per chunk)
-        const int y0 = win >> 1, x0 = win & 1;
-        int f_off[3][2];
-#pragma unroll
-        for (int rr = 0; rr < 3; ++rr)
-#pragma unroll
-          for (int dx = 0; dx < 2; ++dx) {
-            const int p = (wave * 2 + rr + y0) * RG_IW + x0 + dx + r;
-            f_off[rr][dx] = (2 * p + (h ^ ((p >> 3) & 1))) * 16;
-          }
+        // window origin enters through the six fragment addresses f_cur)
         auto load_frags = [&](int j, int par) {      // j = dy*2 + dx inside the window = slab slot
 #pragma unroll
-          for (int mi = 0; mi < 2; ++mi) fa[par][mi] = *reinterpret_cast<const f16x8_t*>(st + f_off[mi + (j >> 1)][j & 1]);
+          for (int mi = 0; mi < 2; ++mi) fa[par][mi] = *reinterpret_cast<const f16x8_t*>(smem + f_cur[mi + (j >> 1)][j & 1]);
 #pragma unroll
           for (int ni = 0; ni < 2; ++ni) fb[par][ni] = *reinterpret_cast<const f16x8_t*>(sW + (j * 2 * 64 + ni * 32) * 16);
         };
         load_frags(0, 0);
+        // window origin of the NEXT chunk (the next tile's chunk 0 after the last one): an LDS byte, consumed after the taps
+        const int win_n = smem[L::WINTAB + (c + 1 == nc ? 0 : c + 1)];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           if (j < 3) load_frags(j + 1, (j & 1) ^ 1);
@@ -317,6 +330,7 @@ __global__ __launch_bounds__(RG_THREADS) void conv3x3_ring_kernel(cdfo_conv_args
           __builtin_amdgcn_sched_barrier(0);
           if (do_issue) issue_piece(j);
         }
+        frag_addresses(__builtin_amdgcn_readfirstlane(win_n), ((g + 1) % RG_NS) * STAGE);
       } else {
         auto load_frags = [&](int t, int par) {
           const int dy = t / 3, dx = t - dy * 3;

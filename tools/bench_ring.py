@@ -11,8 +11,11 @@ SHAPES = [(256, 64, 272, 480, 8, False), (256, 64, 136, 240, 8, False), (1024, 6
 
 def main():
     reps = int(sys.argv[1]) if len(sys.argv) > 1 else 3
-    dbgs = [int(d) for d in sys.argv[2].split(",")] if len(sys.argv) > 2 else []
+    dbgs = [int(d) for d in sys.argv[2].split(",")] if len(sys.argv) > 2 and sys.argv[2] else []
+    only = sys.argv[3] if len(sys.argv) > 3 else ""          # "sparse" / "dense": that form only (counter passes)
     for (Cin, Cout, H, W, B, sparse) in SHAPES:
+        if (only == "sparse" and not sparse) or (only == "dense" and (sparse or H != 272)):
+            continue
         x = torch.randn(B, H, W, Cin, device="cuda").half()
         w = torch.randn(Cout, Cin, 3, 3, device="cuda") / (Cin * (4 if sparse else 9)) ** 0.5
         masks = None

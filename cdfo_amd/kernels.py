@@ -361,7 +361,7 @@ def conv_ring(src: torch.Tensor, pc: PackedConv, *, act: int = ACT_NONE, res1: O
     a.out, a.store_mode, a.prec = out.data_ptr(), 0, PREC_FP16 | (dbg << 8)
     a.src_f16, a.out_f16 = 1, int(out_f16)
     a.src_plane_wrap = plane_wrap
-    for nm, r in (("res1", res1), ("res2", res2)):
+    for nm, r in (("res1", res1), ("res2", None if dbg & 16 else res2)):
         if r is not None:
             rb, rh, rw, rc, rld = _chk_act(r, nm)
             if (rb, rh, rw) != (B, H, W) or rc < pc.Cout:
@@ -373,6 +373,10 @@ def conv_ring(src: torch.Tensor, pc: PackedConv, *, act: int = ACT_NONE, res1: O
         if (rb, rh * 2, rw * 2) != (B, H, W) or rc < pc.Cout:
             raise ValueError(f"res_up2 shape {tuple(res_up2.shape)} is not the half-resolution of the conv output")
         a.res_up2, a.ldru = res_up2.data_ptr(), rld
+    if dbg & 16:                    # developer timeline probe: res2 carries a u64 stamp buffer (see conv3x3_ring.hip)
+        if res2 is None or res2.dtype != torch.int64:
+            raise ValueError("conv_ring: dbg 16 expects res2 = int64 stamp buffer [workgroups, 8, 4, 10]")
+        a.res2, a.ldr2 = res2.data_ptr(), 0
     if out2_cp16 is not None:       # second, fp16 chunk-planar copy of the result (the next Block_'s body[0] source)
         npl = (2 if out2_hl else 1) * (pc.Cout // 16)     # out2_hl: hi | lo planes (the source of a split-fp16 convolution)
         if (out2_cp16.dtype != torch.float16 or tuple(out2_cp16.shape) != (B, npl, H, W, 16)

@@ -45,7 +45,7 @@ KID_NAMES = ["conv3x3_wide", "conv3x3_narrow", "conv1x1", "conv3x3_s2", "stem", 
 # conv3x3_wide (the tiled kernel) runs the --precision mode's passes: fp16x2 = 2 (3 for the split-bf16 feature cache)
 MFMA16 = {"conv3x3_wide": ("conv3x3_mma16_kernel", None), "conv3x3_ws": ("conv3x3_c64_ws_kernel<0, false, 12>", 1),
           "conv3x3_ws_res": ("conv3x3_c64_ws_kernel<0, true, 8>", 1),
-          "conv3x3_ring": ("conv3x3_ring_kernel<false", 1), "conv3x3_ring4": ("conv3x3_ring_kernel<true", 1)}
+          "conv3x3_ring": ("conv3x3_ring_kernel<false", 1), "conv3x3_ring4": ("conv3x3_ring_split_kernel<true", 1)}
 
 
 # HBM-bound kernel families of the event profiler -> substrings of the kernel symbols they launch (rocprofv3 names); used to

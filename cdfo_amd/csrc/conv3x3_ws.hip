@@ -380,10 +380,642 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_c64_ws_kernel(ws_args a) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Ring-fed, wave-specialised form of the non-residual kernel (round 3).  Same product, same fp16 chunk-planar / space-to-depth
+// result, same weight image in LDS; what changes is who does what:
+//   * the workgroup (12 waves) owns a 16-row x 32-pixel tile at a time, as two 8-row HALF-TILES; a half-tile's 10 x 34 pixel halo
+//     of a 16-channel chunk is staged once and shared by the four waves that consume it (the form above stages a private 4 x 34
+//     halo per wave: 2.1x the tile's bytes through LDS-DMA instead of 1.3x);
+//   * waves 0-7 are CONSUMERS, two per SIMD: waves 0-3 (group A) take the upper half-tile, waves 4-7 (group B) the lower one,
+//     rows 2w, 2w + 1 of it each -- nothing in their instruction stream but fragment reads and MFMAs, then the 16-byte stores
+//     of the epilogue.  Group B runs TWO CHUNKS (half a tile) behind group A: a SIMD's two consumers never reach their
+//     epilogues (activation + fp16 pack + stores: ~18 % of the launch when all eight did it at once) together, one keeps the
+//     matrix pipe busy while the other converts and stores;
+//   * waves 8-11 (one per SIMD) are PRODUCERS: waves 8, 9 feed group A's ring (6 + 5 DMA pieces per chunk), waves 10, 11
+//     group B's, each ring four stages deep (two chunks in flight behind the one being consumed), across tile boundaries;
+//   * one workgroup barrier per step: a producer arrives when ITS pieces of the batch its group consumes next have landed
+//     (counted vmcnt), a consumer when its fragment reads of the previous batch have returned; behind the barrier the
+//     producers refill the stage of the batch just retired.
+// Why: the timeline probe of the ring kernel (conv3x3_ring.hip, dbg 16) showed that a wave which interleaves DMA issue (100-200
+// cycles per instruction) and ring bookkeeping with its MFMAs needs 250-400 cycles per tap for 128 cycles of matrix work, and
+// that consumer-only waves reach 86 % matrix-pipe duty inside a chunk; the form above sits at 67 % over the launch.
+// LDS: 2 rings x 4 stages x 11 KiB + the 72 KiB weight image = exactly 160 KiB (the bias lives in registers).
+constexpr int WR_HT = 8, WR_IW = 34, WR_NPIX = 10 * 34, WR_PIECES = 11, WR_ACT = WR_PIECES * 1024, WR_NS = 4;
+constexpr int WR_CONS = 8, WR_THREADS = 12 * 64, WR_LAG = 2;      // group B runs WR_LAG steps behind group A
+#ifndef WR_PRIO
+#define WR_PRIO 1
+#endif
+#ifndef WR_ROWSPLIT
+#define WR_ROWSPLIT 0      // last chunk row by row with the first row's epilogue between the second row's taps: measured no gain
+#endif
+constexpr int WR_W_OFF = 2 * WR_NS * WR_ACT;           // 90,112
+constexpr int WR_TOTAL = WR_W_OFF + WS_W_BYTES;        // 163,840 bytes
+static_assert(WR_TOTAL <= 160 * 1024, "LDS budget");
+
+// six / five 1 KiB LDS-DMA pieces into consecutive kilobytes, ONE asm block each (m0 is live across the pieces; see ws_dma5)
+__device__ __forceinline__ void wr_dma6(const unsigned (&voff)[6], i32x4 rsrc, unsigned soff, unsigned lds) {
+  unsigned keep;
+  asm volatile(
+      "s_nop 4\n\t"
+      "s_mov_b32 %0, m0\n\t"
+      "s_mov_b32 m0, %8\n\ts_nop 0\n\t"
+      "buffer_load_dwordx4 %1, %7, %9 offen lds\n\t"
+      "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\t"
+      "buffer_load_dwordx4 %2, %7, %9 offen lds\n\t"
+      "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\t"
+      "buffer_load_dwordx4 %3, %7, %9 offen lds\n\t"
+      "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\t"
+      "buffer_load_dwordx4 %4, %7, %9 offen lds\n\t"
+      "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\t"
+      "buffer_load_dwordx4 %5, %7, %9 offen lds\n\t"
+      "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\t"
+      "buffer_load_dwordx4 %6, %7, %9 offen lds\n\t"
+      "s_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(voff[0]), "v"(voff[1]), "v"(voff[2]), "v"(voff[3]), "v"(voff[4]), "v"(voff[5]), "s"(rsrc), "s"(lds), "s"(soff)
+      : "memory", "scc");
+}
+__device__ __forceinline__ void wr_dma5(const unsigned (&voff)[6], i32x4 rsrc, unsigned soff, unsigned lds) {
+  const unsigned v5[5] = {voff[0], voff[1], voff[2], voff[3], voff[4]};
+  ws_dma5(v5, rsrc, soff, lds);
+}
+
+// DBG: 1 = skip the MFMAs, 2 = skip the DMA, 8 = skip the epilogue (developer ablations); 32 = timeline probe: a.clk receives
+// s_memtime stamps [workgroup][wave 0-11][4][8] of the consumers' third tile (per chunk: entry, barrier passed, after taps 2 / 5 /
+// 8, end) and, in slot 6 of rows 0 / 1, the epilogue-start times of the fourth and fifth tile (undisturbed tile period)
+template <int DBG>
+__global__ __launch_bounds__(WR_THREADS) void conv3x3_c64_wsr_kernel(ws_args a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, r = lane & 31;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const bool consumer = wave < WR_CONS;
+  const int H = a.H, W = a.W;
+  // the nco output-channel blocks of a tile sequence sit on one XCD (shared L2); each XCD walks its own band of tiles
+  const int nco = a.Cout >> 6;
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, nslots = gridDim.x >> 3;
+  const int nq = nslots / nco, nb = slot % nco, q = slot / nco;
+  const int tiles_x = (W + 31) >> 5, tiles_y = (H + 2 * WR_HT - 1) / (2 * WR_HT), tiles = tiles_x * tiles_y;
+  const int all_tiles = a.B * tiles;
+  const int band = (all_tiles + 7) >> 3, band0 = xcd * band;
+  const int band_n = min(band, all_tiles - band0);
+  const int my_tiles = (q < nq && band_n > q) ? (band_n - q + nq - 1) / nq : 0;
+  if (my_tiles == 0) return;
+  const int n0 = nb * 64;
+
+  // ---- one-time: this workgroup's weight block (row permutation as in the kernel above)
+  auto chan_of_row = [](int n) { const int m = n & 31; return (n & 32) + ((m >> 4) & 1) * 16 + ((m >> 2) & 1) * 8 + ((m >> 3) & 1) * 4 + (m & 3); };
+  for (int i = tid; i < WS_W_BYTES / 16; i += WR_THREADS) {
+    const int row = i >> 6, n = i & 63;          // row = (chunk*9 + tap)*2 + k-half
+    *reinterpret_cast<u32x4*>(smem + WR_W_OFF + i * 16) =
+        *reinterpret_cast<const u32x4*>(a.w + ((long long)row * a.CoutP + n0 + chan_of_row(n)) * 8);
+  }
+  __syncthreads();
+
+  const unsigned lds0 = (unsigned)(unsigned long long)(smem);
+  const unsigned plane = (unsigned)(H * W) * 32u;        // bytes of one 16-channel plane of one image
+  const int nbatch = my_tiles * 4;                       // chunk batches per group; the workgroup runs nbatch + WR_LAG steps
+  const int nsteps = nbatch + WR_LAG;
+  auto tile_coords = [&](int ord, int& b, int& oy0, int& ox0) {
+    const int t = band0 + q + ord * nq;
+    b = t / tiles;
+    const int tile = t - b * tiles, ty = tile / tiles_x;
+    oy0 = ty * (2 * WR_HT); ox0 = (tile - ty * tiles_x) * 32;
+  };
+
+  if (!consumer) {
+    // ================================================================================================ producers
+    const int pw = wave - WR_CONS;
+    const int grp = pw >> 1;                  // the consumer group this producer feeds
+    const int first = (pw & 1) ? 6 : 0;       // its pieces of the half-tile halo: 0-5 (six) or 6-10 (five)
+    const bool six = !(pw & 1);
+    const int lag = grp ? WR_LAG : 0;
+    int d_iy[6], d_ix[6], d_rel[6];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+      const int s = (first + j) * 64 + lane, p = s >> 1, half = (s & 1) ^ ((p >> 3) & 1);
+      const int iy = p / WR_IW, ix = p - iy * WR_IW;
+      d_iy[j] = (p < WR_NPIX && first + j < WR_PIECES) ? iy : 1 << 20;        // pad slots: never inside the image
+      d_ix[j] = ix;
+      d_rel[j] = (iy * W + ix) * 32 + half * 16;
+    }
+    i32x4 rsrc;
+    {
+      const unsigned long long p = reinterpret_cast<unsigned long long>(a.src);
+      rsrc[0] = (int)(unsigned)p; rsrc[1] = (int)(unsigned)(p >> 32); rsrc[2] = (int)a.src_bytes; rsrc[3] = 0x00020000;
+    }
+    int iu = 0, ic = 0, gi = 0;
+    unsigned voff[6], soff0 = 0;
+    auto issue_batch = [&]() {
+      if (ic == 0) {
+        int b, oy0, ox0;
+        tile_coords(iu, b, oy0, ox0);
+        oy0 += grp * WR_HT;
+        soff0 = (unsigned)b * 4u * plane;
+        const int base = ((oy0 - 1) * W + (ox0 - 1)) * 32;
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+          const int gy = oy0 - 1 + d_iy[j], gx = ox0 - 1 + d_ix[j];
+          const bool ok = gy >= 0 && gy < H && gx >= 0 && gx < W;
+          voff[j] = ok ? (unsigned)(base + d_rel[j]) : 0x80000000u;     // out of range => the DMA writes zeros
+        }
+      }
+      const unsigned soff = __builtin_amdgcn_readfirstlane(soff0 + (unsigned)ic * plane);
+      const unsigned dst = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)((grp * WR_NS + gi % WR_NS) * WR_ACT + first * 1024));
+      if (!(DBG & 2)) {
+        if (six) wr_dma6(voff, rsrc, soff, dst);
+        else wr_dma5(voff, rsrc, soff, dst);
+      }
+      ++gi;
+      if (++ic == 4) { ic = 0; ++iu; }
+    };
+#pragma unroll
+    for (int k = 0; k < WR_NS - 1; ++k)
+      if (k < nbatch) issue_batch();
+    for (int s = 0; s < nsteps; ++s) {
+      const int g = s - lag;                   // the batch my group consumes in this step (outside [0, nbatch): none)
+      // my pieces of batch g have landed: all but the newest (NS - 2) batches of mine (DMA pieces retire in issue order among
+      // themselves; a producer issues nothing else)
+      if (g >= 0 && g < nbatch) {
+        if (g + WR_NS - 2 >= nbatch) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else if (six) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+        static_assert(WR_NS - 2 == 2, "counted wait immediates");
+      }
+      __builtin_amdgcn_s_barrier();
+      if (g >= 0 && g + WR_NS - 1 < nbatch) issue_batch();      // into the stage of batch g-1: nobody reads it behind this barrier
+    }
+    return;
+  }
+
+  // ================================================================================================== consumers
+  const int grp = wave >> 2, cw = wave & 3;
+  const int lag = grp ? WR_LAG : 0;
+  int p_off[12];        // fragment offsets: halo rows 2cw + rr (rr = 0..3), column offset dx, this lane's pixel r
+#pragma unroll
+  for (int rr = 0; rr < 4; ++rr)
+#pragma unroll
+    for (int dx = 0; dx < 3; ++dx) {
+      const int p = (cw * 2 + rr) * WR_IW + dx + r;
+      p_off[rr * 3 + dx] = grp * WR_NS * WR_ACT + (2 * p + (h ^ ((p >> 3) & 1))) * 16;
+    }
+  const unsigned char* sWl = smem + WR_W_OFF + (h * 64 + r) * 16;
+  const float slope = a.act == CDFO_ACT_NONE ? 1.f : (a.act == CDFO_ACT_LRELU ? 0.1f : 0.f);
+  const int nck = a.Cout >> 4, hp = H >> 1;
+  // bias of this lane's accumulator rows: MFMA row 8j + 4h + k of block ni = channel chan_of_row(ni*32 + 8j + 4h + k)
+  f32x4 bias[2][4];
+#pragma unroll
+  for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) bias[ni][j][k] = a.bias ? a.bias[n0 + chan_of_row(ni * 32 + 8 * j + 4 * h + k)] : 0.f;
+
+  for (int s = 0; s < lag; ++s) {            // group B idles through its lag (the barriers are the workgroup's)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+  }
+  int g = 0;
+  for (int ord = 0; ord < my_tiles; ++ord) {
+    int cb, oy0, cx0;
+    tile_coords(ord, cb, oy0, cx0);
+    const int cy0 = oy0 + grp * WR_HT + cw * 2;
+    f32x16 acc[2][2];                            // [ni: 32-channel block][mi: image row]
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { acc[ni][0][4 * j + k] = bias[ni][j][k]; acc[ni][1][4 * j + k] = bias[ni][j][k]; }
+    // ---- epilogue pieces: act -> fp16 -> one 16-byte store.  acc[ni][mi][8jj + 4b + k] = channel ni*32 + jj*16 + h*8 + b*4 + k
+    // of pixel r in image row cy0 + mi, i.e. halves [h*8, h*8+8) of chunk nb*4 + ni*2 + jj.
+    _Float16* orow[2];         // row mi: address of (chunk plane nb*4, this lane's pixel, halves h*8..)
+    bool ook[2];
+    long long cstride;         // 16-half records between consecutive chunk planes
+    {
+      const int x = cx0 + r;
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi) {
+        const int y = cy0 + mi;
+        ook[mi] = y < H && x < W;
+        long long pos;
+        if (a.s2d) {
+          const int ph = (y & 1) * 2 + (x & 1);
+          cstride = (long long)hp * (W >> 1);
+          pos = ((long long)cb * 4 * nck + ph * nck + nb * 4) * cstride + (long long)(y >> 1) * (W >> 1) + (x >> 1);
+        } else {
+          cstride = (long long)H * W;
+          pos = ((long long)cb * nck + nb * 4) * cstride + (long long)y * W + x;
+        }
+        orow[mi] = a.out + pos * 16 + h * 8;
+      }
+    }
+    auto epilogue_piece = [&](int mi, int k) {       // k = ni*2 + jj
+      const int ni = k >> 1, jj = k & 1;
+      f16x8_t hv;
+#pragma unroll
+      for (int qq = 0; qq < 8; ++qq) {
+        const float v = acc[ni][mi][8 * jj + qq];
+        hv[qq] = (_Float16)fmaxf(v, slope * v);      // slope in [0, 1]: identity / LeakyReLU / ReLU
+      }
+      if (ook[mi]) *reinterpret_cast<f16x8_t*>(orow[mi] + (long long)k * cstride * 16) = hv;
+    };
+#pragma unroll
+    for (int c = 0; c < 4; ++c, ++g) {
+      unsigned long long ts[6] = {0, 0, 0, 0, 0, 0};      // dbg 32: step entry, barrier passed, after taps 2 / 5 / 8, step end
+      if (DBG & 32) asm volatile("s_memtime %0" : "=s"(ts[0]) : : "memory");
+      // my fragment reads of batch g-1 have returned (its stage is refilled behind the barrier)
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      // Issue priority.  A SIMD's two consumers do not share the matrix pipe evenly: the older wave (group A) takes its 36 MFMAs
+      // first, the younger one (group B) finishes ~1 200 cycles later (dbg 32 timeline).  That hides A's epilogue behind B's
+      // tail -- but B's own epilogue came after everything else in its step, with A already waiting at the barrier.  So a
+      // consumer raises its priority for the LAST chunk of its tile: it finishes first and converts / stores while the other
+      // group, half a tile away, computes.
+      if (WR_PRIO) {
+        if (c == 3) __builtin_amdgcn_s_setprio(3);
+        else __builtin_amdgcn_s_setprio(0);
+      }
+      if (DBG & 32) asm volatile("s_memtime %0" : "=s"(ts[1]) : : "memory");
+      const unsigned char* sA = smem + (g % WR_NS) * WR_ACT;
+      const unsigned char* sWc = sWl + c * (9 * 2 * 64 * 16);
+      f16x8_t fp[2][2], fw[2][2];                // [parity][mi / ni]: fragments are read one tap ahead
+      if (c < 3 || (DBG & 8) || !WR_ROWSPLIT) {
+        auto load_frags = [&](int t, int par) {
+          const int dy = t / 3, dx = t - dy * 3;
+#pragma unroll
+          for (int ni = 0; ni < 2; ++ni) fw[par][ni] = *reinterpret_cast<const f16x8_t*>(sWc + (t * 2 * 64 + ni * 32) * 16);
+#pragma unroll
+          for (int mi = 0; mi < 2; ++mi) fp[par][mi] = *reinterpret_cast<const f16x8_t*>(sA + p_off[(mi + dy) * 3 + dx]);
+        };
+        load_frags(0, 0);
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+          if (t < 8) load_frags(t + 1, (t & 1) ^ 1);
+          __builtin_amdgcn_sched_barrier(0);
+          const int par = t & 1;
+#pragma unroll
+          for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi) {
+              if (DBG & 1) acc[ni][mi][0] += (float)fw[par][ni][0] * (float)fp[par][mi][0];
+              else if (DBG & 4) {      // clock experiment: the 16x16x32 shape at equal FLOPs and fragment reads (results are NOT the convolution)
+                f32x4 lo = {acc[ni][mi][0], acc[ni][mi][1], acc[ni][mi][2], acc[ni][mi][3]};
+                f32x4 hi = {acc[ni][mi][4], acc[ni][mi][5], acc[ni][mi][6], acc[ni][mi][7]};
+                lo = __builtin_amdgcn_mfma_f32_16x16x32_f16(fw[par][ni], fp[par][mi], lo, 0, 0, 0);
+                hi = __builtin_amdgcn_mfma_f32_16x16x32_f16(fw[par][ni], fp[par][mi], hi, 0, 0, 0);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { acc[ni][mi][e] = lo[e]; acc[ni][mi][4 + e] = hi[e]; }
+              } else acc[ni][mi] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fw[par][ni], fp[par][mi], acc[ni][mi], 0, 0, 0);
+            }
+          __builtin_amdgcn_sched_barrier(0);
+          if ((DBG & 32) && (t == 2 || t == 5 || t == 8)) asm volatile("s_memtime %0" : "=s"(ts[2 + t / 3]) : : "memory");
+        }
+      } else {
+        // Last chunk of the tile, row by row: image row 0 through all nine taps first, then row 1 -- with row 0's four epilogue
+        // pieces (32 conversions + a store each) placed between row 1's taps, where they overlap this wave's own MFMAs (an MFMA
+        // holds the vector issue for 8 of its 32 cycles).  What is left after the last MFMA is row 1's half of the epilogue,
+        // short enough for the other group's tail to cover.  Cost: the weight fragments are read twice in this chunk.
+        auto load_row = [&](int t, int par, int mi) {
+          const int dy = t / 3, dx = t - dy * 3;
+#pragma unroll
+          for (int ni = 0; ni < 2; ++ni) fw[par][ni] = *reinterpret_cast<const f16x8_t*>(sWc + (t * 2 * 64 + ni * 32) * 16);
+          fp[par][0] = *reinterpret_cast<const f16x8_t*>(sA + p_off[(mi + dy) * 3 + dx]);
+        };
+        load_row(0, 0, 0);
+#pragma unroll
+        for (int u = 0; u < 18; ++u) {             // u = row * 9 + tap
+          const int mi = u / 9, t = u - mi * 9, par = u & 1;
+          if (u < 17) load_row((u + 1) % 9, par ^ 1, (u + 1) / 9);
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int ni = 0; ni < 2; ++ni) {
+            if (DBG & 1) acc[ni][mi][0] += (float)fw[par][ni][0] * (float)fp[par][0][0];
+            else acc[ni][mi] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fw[par][ni], fp[par][0], acc[ni][mi], 0, 0, 0);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+          if (mi == 1 && (t & 1) == 0 && t < 8) {
+            epilogue_piece(0, t >> 1);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+          if ((DBG & 32) && (u == 5 || u == 11 || u == 17)) asm volatile("s_memtime %0" : "=s"(ts[2 + u / 6]) : : "memory");
+        }
+      }
+      if (DBG & 32) {
+        asm volatile("s_memtime %0" : "=s"(ts[5]) : : "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (a.clk && ord == 2 && lane == 0) {
+          unsigned long long* cbuf = a.clk + (((long long)blockIdx.x * 12 + wave) * 4 + c) * 8;
+#pragma unroll
+          for (int i = 0; i < 6; ++i) cbuf[i] = ts[i];
+        }
+      }
+    }
+    if (DBG & 32) {
+      unsigned long long te = 0;
+      asm volatile("s_memtime %0" : "=s"(te) : : "memory");
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      if (a.clk && (ord == 3 || ord == 4) && lane == 0) a.clk[(((long long)blockIdx.x * 12 + wave) * 4 + (ord - 3)) * 8 + 6] = te;   // tile period, undisturbed
+    }
+    if (DBG & 8) {
+      float t = 0.f;
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) t += acc[ni][mi][e];
+      if (t == 123.456f) a.out[0] = (_Float16)t;
+      continue;
+    }
+    if (!WR_ROWSPLIT) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) epilogue_piece(0, k);
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) epilogue_piece(1, k);
+  }
+  for (int s = lag; s < WR_LAG; ++s) {       // group A waits out group B's lag: every wave runs nbatch + WR_LAG barriers
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The same ring-fed, wave-specialised kernel on v_mfma_f32_16x16x32_f16 (round 3).
+// Why another MFMA shape: every structure tried for this convolution -- private halos with three drifting waves per SIMD, the
+// shared-halo ring above in lock step, with lagged consumer groups, with the epilogue inside the last chunk -- delivers the
+// same 1.04-1.07 PFLOP/s, because the loop is POWER-limited: the chip holds 1.5-1.65 GHz under it and gives an in-kernel
+// cycle saving back as a lower clock (MI355X_MICROARCH.md, DVFS give-back).  What moves the number is energy per FLOP, and the
+// guide measures the 16x16x32 shape at ~1.13x the FLOP/s of 32x32x16 at equal cycles on random data; swapping the shape in the
+// kernel above at equal FLOPs and fragment reads (dbg 4, wrong arithmetic) ran 8-13 % faster.  So:
+//   * K = 32 per MFMA = both 16-channel planes of a 32-channel SUPERCHUNK at one tap: a step stages two planes per group
+//     (2 x 11 KiB), a tile is two steps, the rings are two stages deep (same bytes in flight as 4 x 11 KiB), group B runs one
+//     step = half a tile behind group A;
+//   * a consumer's 2 rows x 32 pixels x 64 channels are 4 x 4 accumulators of 16 x 16: per tap 4 weight fragments + 4 pixel
+//     fragments for 16 MFMAs (the same LDS bytes per FLOP as before); lane l holds k-group l >> 4 = (plane, 8-channel half) of
+//     pixel / output channel l & 15, which needs NO bank swizzle for ds_read_b128 with natural [pixel][16 ch] records and the
+//     weight image in natural channel order;
+//   * accumulator registers are 4 consecutive output channels of one pixel: the epilogue stores 8 bytes per lane and 16 x 16
+//     block, 512 contiguous bytes per wave-instruction.
+constexpr int WQ_PLANE = WR_PIECES * 1024, WQ_ACT = 2 * WQ_PLANE, WQ_NS = 2, WQ_LAG = 1;
+constexpr int WQ_W_OFF = 2 * WQ_NS * WQ_ACT;           // 90,112
+constexpr int WQ_TOTAL = WQ_W_OFF + WS_W_BYTES;        // 163,840 bytes
+static_assert(WQ_TOTAL <= 160 * 1024, "LDS budget");
+
+template <int DBG>
+__global__ __launch_bounds__(WR_THREADS) void conv3x3_c64_wsq_kernel(ws_args a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, l16 = lane & 15, kg = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const bool consumer = wave < WR_CONS;
+  const int H = a.H, W = a.W;
+  const int nco = a.Cout >> 6;
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, nslots = gridDim.x >> 3;
+  const int nq = nslots / nco, nb = slot % nco, q = slot / nco;
+  const int tiles_x = (W + 31) >> 5, tiles_y = (H + 2 * WR_HT - 1) / (2 * WR_HT), tiles = tiles_x * tiles_y;
+  const int all_tiles = a.B * tiles;
+  const int band = (all_tiles + 7) >> 3, band0 = xcd * band;
+  const int band_n = min(band, all_tiles - band0);
+  const int my_tiles = (q < nq && band_n > q) ? (band_n - q + nq - 1) / nq : 0;
+  if (my_tiles == 0) return;
+  const int n0 = nb * 64;
+
+  // ---- one-time: this workgroup's weight block: row = (chunk*9 + tap)*2 + k-half, 64 x 16 bytes.  MFMA row i of 16-row block mb
+  // holds output channel (mb>>1)*32 + (i>>2)*8 + (mb&1)*4 + (i&3): a lane's accumulators of blocks 2e and 2e+1 (rows 4 kg ..
+  // 4 kg + 3 each) are then 8 CONSECUTIVE channels e*32 + 8 kg .. + 7 -- one 16-byte store per lane, pixel block and block pair
+  auto chan_q = [](int n) { return (n >> 5) * 32 + ((n & 15) >> 2) * 8 + ((n >> 4) & 1) * 4 + (n & 3); };
+  for (int i = tid; i < WS_W_BYTES / 16; i += WR_THREADS) {
+    const int row = i >> 6, n = i & 63;
+    *reinterpret_cast<u32x4*>(smem + WQ_W_OFF + i * 16) =
+        *reinterpret_cast<const u32x4*>(a.w + ((long long)row * a.CoutP + n0 + chan_q(n)) * 8);
+  }
+  __syncthreads();
+
+  const unsigned lds0 = (unsigned)(unsigned long long)(smem);
+  const unsigned plane = (unsigned)(H * W) * 32u;        // bytes of one 16-channel plane of one image
+  const int nbatch = my_tiles * 2;                       // superchunk batches per group; the workgroup runs nbatch + WQ_LAG steps
+  const int nsteps = nbatch + WQ_LAG;
+  auto tile_coords = [&](int ord, int& b, int& oy0, int& ox0) {
+    const int t = band0 + q + ord * nq;
+    b = t / tiles;
+    const int tile = t - b * tiles, ty = tile / tiles_x;
+    oy0 = ty * (2 * WR_HT); ox0 = (tile - ty * tiles_x) * 32;
+  };
+
+  if (!consumer) {
+    // ================================================================================================ producers
+    const int pw = wave - WR_CONS;
+    const int grp = pw >> 1;
+    const int first = (pw & 1) ? 6 : 0;       // pieces 0-5 (six) or 6-10 (five) of BOTH planes of the half-tile halo
+    const bool six = !(pw & 1);
+    const int lag = grp ? WQ_LAG : 0;
+    int d_iy[6], d_ix[6], d_rel[6];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+      const int s = (first + j) * 64 + lane, p = s >> 1, half = s & 1;      // natural records: LDS byte 16 s = 32 p + 16 half
+      const int iy = p / WR_IW, ix = p - iy * WR_IW;
+      d_iy[j] = (p < WR_NPIX && first + j < WR_PIECES) ? iy : 1 << 20;
+      d_ix[j] = ix;
+      d_rel[j] = (iy * W + ix) * 32 + half * 16;
+    }
+    i32x4 rsrc;
+    {
+      const unsigned long long p = reinterpret_cast<unsigned long long>(a.src);
+      rsrc[0] = (int)(unsigned)p; rsrc[1] = (int)(unsigned)(p >> 32); rsrc[2] = (int)a.src_bytes; rsrc[3] = 0x00020000;
+    }
+    int iu = 0, ic = 0, gi = 0;
+    unsigned voff[6], soff0 = 0;
+    auto issue_batch = [&]() {
+      if (ic == 0) {
+        int b, oy0, ox0;
+        tile_coords(iu, b, oy0, ox0);
+        oy0 += grp * WR_HT;
+        soff0 = (unsigned)b * 4u * plane;
+        const int base = ((oy0 - 1) * W + (ox0 - 1)) * 32;
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+          const int gy = oy0 - 1 + d_iy[j], gx = ox0 - 1 + d_ix[j];
+          const bool ok = gy >= 0 && gy < H && gx >= 0 && gx < W;
+          voff[j] = ok ? (unsigned)(base + d_rel[j]) : 0x80000000u;
+        }
+      }
+      const unsigned dst = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)((grp * WQ_NS + gi % WQ_NS) * WQ_ACT + first * 1024));
+      if (!(DBG & 2)) {
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl) {
+          const unsigned soff = __builtin_amdgcn_readfirstlane(soff0 + (unsigned)(ic * 2 + pl) * plane);
+          if (six) wr_dma6(voff, rsrc, soff, dst + pl * WQ_PLANE);
+          else wr_dma5(voff, rsrc, soff, dst + pl * WQ_PLANE);
+        }
+      }
+      ++gi;
+      if (++ic == 2) { ic = 0; ++iu; }
+    };
+    if (nbatch > 0) issue_batch();
+    for (int s = 0; s < nsteps; ++s) {
+      const int g = s - lag;
+      // two stages: batch g is the only thing of mine in flight when I wait for it
+      if (g >= 0 && g < nbatch) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      if (g >= 0 && g + 1 < nbatch) issue_batch();      // into the stage of batch g-1: nobody reads it behind this barrier
+    }
+    return;
+  }
+
+  // ================================================================================================== consumers
+  const int grp = wave >> 2, cw = wave & 3;
+  const int lag = grp ? WQ_LAG : 0;
+  const int kplane = kg >> 1, khalf = kg & 1;
+  int p_off[12];        // pixel fragments: halo rows 2cw + rr (rr = 0..3), column offset dx, pixel l16 (+16: immediate), this lane's k-group
+#pragma unroll
+  for (int rr = 0; rr < 4; ++rr)
+#pragma unroll
+    for (int dx = 0; dx < 3; ++dx)
+      p_off[rr * 3 + dx] = grp * WQ_NS * WQ_ACT + kplane * WQ_PLANE + ((cw * 2 + rr) * WR_IW + dx + l16) * 32 + khalf * 16;
+  // weight fragments: row (superchunk*2 + kplane)*9*2 + tap*2 + khalf, output channel mb*16 + l16
+  const unsigned char* sWl = smem + WQ_W_OFF + (kplane * 9 * 2 + khalf) * 1024 + l16 * 16;
+  const float slope = a.act == CDFO_ACT_NONE ? 1.f : (a.act == CDFO_ACT_LRELU ? 0.1f : 0.f);
+  const int nck = a.Cout >> 4, hp = H >> 1;
+  f32x4 bias[4];        // accumulator rows 4 kg .. 4 kg + 3 of block mb
+#pragma unroll
+  for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) bias[mb][k] = a.bias ? a.bias[n0 + chan_q(mb * 16 + 4 * kg + k)] : 0.f;
+
+  for (int s = 0; s < lag; ++s) {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+  }
+  int g = 0;
+  for (int ord = 0; ord < my_tiles; ++ord) {
+    int cb, oy0, cx0;
+    tile_coords(ord, cb, oy0, cx0);
+    const int cy0 = oy0 + grp * WR_HT + cw * 2;
+    f32x4 acc[4][4];                             // [mb: 16 output channels][nbk = row*2 + pixel half]
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+      for (int nbk = 0; nbk < 4; ++nbk) acc[mb][nbk] = bias[mb];
+#pragma unroll
+    for (int c = 0; c < 2; ++c, ++g) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // my fragment reads of batch g-1 have returned
+      __builtin_amdgcn_s_barrier();
+      if (WR_PRIO) {      // last step of my tile: finish first, convert / store while the other group computes (see the kernel above)
+        if (c == 1) __builtin_amdgcn_s_setprio(3);
+        else __builtin_amdgcn_s_setprio(0);
+      }
+      const unsigned char* sA = smem + (g % WQ_NS) * WQ_ACT;
+      const unsigned char* sWc = sWl + c * (2 * 9 * 2 * 1024);
+      f16x8_t fp[2][4], fw[2][4];                // [parity][pixel block / channel block]: fragments are read one tap ahead
+      auto load_frags = [&](int t, int par) {
+        const int dy = t / 3, dx = t - dy * 3;
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb) fw[par][mb] = *reinterpret_cast<const f16x8_t*>(sWc + t * 2048 + mb * 256);
+#pragma unroll
+        for (int nbk = 0; nbk < 4; ++nbk)
+          fp[par][nbk] = *reinterpret_cast<const f16x8_t*>(sA + p_off[((nbk >> 1) + dy) * 3 + dx] + (nbk & 1) * 512);
+      };
+      load_frags(0, 0);
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        if (t < 8) load_frags(t + 1, (t & 1) ^ 1);
+        __builtin_amdgcn_sched_barrier(0);
+        const int par = t & 1;
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+          for (int nbk = 0; nbk < 4; ++nbk) {
+            if (DBG & 1) acc[mb][nbk][0] += (float)fw[par][mb][0] * (float)fp[par][nbk][0];
+            else acc[mb][nbk] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fw[par][mb], fp[par][nbk], acc[mb][nbk], 0, 0, 0);
+          }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    if (DBG & 8) {
+      float t = 0.f;
+#pragma unroll
+      for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+        for (int nbk = 0; nbk < 4; ++nbk)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) t += acc[mb][nbk][e];
+      if (t == 123.456f) a.out[0] = (_Float16)t;
+      continue;
+    }
+    // ---- epilogue: act -> fp16 -> 16-byte stores.  acc[2e][nbk][k], acc[2e+1][nbk][k] = channels e*32 + 8 kg + k, + 4 + k of
+    // pixel (row cy0 + (nbk >> 1), column cx0 + 16 (nbk & 1) + l16): halves [8 (kg & 1), + 8) of chunk nb*4 + 2e + (kg >> 1).
+#pragma unroll
+    for (int nbk = 0; nbk < 4; ++nbk) {
+      const int y = cy0 + (nbk >> 1), x = cx0 + (nbk & 1) * 16 + l16;
+      const bool ok = y < H && x < W;
+      long long pos, cstride;
+      if (a.s2d) {
+        const int ph = (y & 1) * 2 + (x & 1);
+        cstride = (long long)hp * (W >> 1);
+        pos = ((long long)cb * 4 * nck + ph * nck + nb * 4) * cstride + (long long)(y >> 1) * (W >> 1) + (x >> 1);
+      } else {
+        cstride = (long long)H * W;
+        pos = ((long long)cb * nck + nb * 4) * cstride + (long long)y * W + x;
+      }
+      _Float16* o = a.out + (pos + (kg >> 1) * cstride) * 16 + (kg & 1) * 8;
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        f16x8_t hv;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const float v0 = acc[2 * e][nbk][k], v1 = acc[2 * e + 1][nbk][k];
+          hv[k] = (_Float16)fmaxf(v0, slope * v0);
+          hv[4 + k] = (_Float16)fmaxf(v1, slope * v1);
+        }
+        if (ok) *reinterpret_cast<f16x8_t*>(o + (long long)(2 * e) * cstride * 16) = hv;
+      }
+    }
+  }
+  for (int s = lag; s < WQ_LAG; ++s) {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+  }
+}
+
 int ws_num_cus() { return cdfo_num_cus(); }
+
+// CDFO_WS_RING=0 selects the private-halo form above for the non-residual calls; default: the ring-fed wave-specialised form
+bool ws_ring_form() {
+  static const bool v = [] { const char* s = getenv("CDFO_WS_RING"); return !(s && s[0] == '0'); }();
+  return v;
+}
+
+// CDFO_WS_MFMA16=0 keeps the 32x32x16 ring-fed form; default: the 16x16x32 one
+bool ws_mfma16() {
+  static const bool v = [] { const char* s = getenv("CDFO_WS_MFMA16"); return !(s && s[0] == '0'); }();
+  return v;
+}
+
+template <int DBG>
+int wsr_launch(const ws_args& a, hipStream_t st) {
+  if constexpr ((DBG & ~11) == 0) {
+    if (ws_mfma16()) {
+      static CdfoAttrOnce onceq;
+      const hipError_t e = cdfo_set_max_lds(onceq, reinterpret_cast<const void*>(conv3x3_c64_wsq_kernel<DBG>), WQ_TOTAL);
+      if (e != hipSuccess) return (int)e;
+      const int grid = ws_num_cus() / 8 * 8;
+      hipLaunchKernelGGL((conv3x3_c64_wsq_kernel<DBG>), dim3(grid), dim3(WR_THREADS), WQ_TOTAL, st, a);
+      return 0;
+    }
+  }
+  static CdfoAttrOnce once;
+  const hipError_t e = cdfo_set_max_lds(once, reinterpret_cast<const void*>(conv3x3_c64_wsr_kernel<DBG>), WR_TOTAL);
+  if (e != hipSuccess) return (int)e;
+  const int grid = ws_num_cus() / 8 * 8;
+  hipLaunchKernelGGL((conv3x3_c64_wsr_kernel<DBG>), dim3(grid), dim3(WR_THREADS), WR_TOTAL, st, a);
+  return 0;
+}
 
 template <int DBG, bool RES = false>
 int ws_launch(const ws_args& a, int grid, hipStream_t st) {
+  if constexpr (!RES && (DBG & ~47) == 0) {        // ablation bits 1, 2, 8 exist in both forms; 32 = this form's timeline probe
+    if (ws_ring_form() && (a.Cout >> 6) <= (ws_num_cus() / 8)) return wsr_launch<DBG>(a, st);
+  }
   // three waves per SIMD by default (same-box A/B: 1.21 -> 1.18 ms at 64 -> 256 on 8 x 544 x 960, 0.295 -> 0.286 at 272 x 480):
   // with two, the matrix pipe idles whenever both are outside their MFMA runs at once (counters: pipe busy 67 %);
   // CDFO_WS_WAVES=8 selects the two-per-SIMD form with its 2-deep staging rings (developer A/B switch)
@@ -457,10 +1089,13 @@ extern "C" int cdfo_conv3x3_c64_ws(const void* src_cp16, int B, int H, int W, co
     case 1: rc = ws_launch<1>(a, grid, st); break;
     case 2: rc = ws_launch<2>(a, grid, st); break;
     case 3: rc = ws_launch<3>(a, grid, st); break;
+    case 4: rc = ws_launch<4>(a, grid, st); break;
+    case 12: rc = ws_launch<12>(a, grid, st); break;
     case 8: rc = ws_launch<8>(a, grid, st); break;
     case 9: rc = ws_launch<9>(a, grid, st); break;
     case 11: rc = ws_launch<11>(a, grid, st); break;
     case 16: rc = ws_launch<16>(a, grid, st); break;
+    case 32: rc = ws_launch<32>(a, grid, st); break;
     case 64: rc = ws_launch<64>(a, grid, st); break;
     case 72: rc = ws_launch<72>(a, grid, st); break;
     case 128: rc = ws_launch<128>(a, grid, st); break;

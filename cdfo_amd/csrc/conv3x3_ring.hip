@@ -95,7 +95,8 @@ template <int V> struct IntC { static constexpr int value = V; };
 template <int N> __device__ __forceinline__ void rg_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 template <int N> __device__ __forceinline__ void rg_wait_vm_lgkm0() { asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(N) : "memory"); }
 
-// DBG (developer ablations, tools/bench_ring.py): 1 = skip the MFMAs, 2 = skip the DMA, 8 = skip the epilogue, 16 = timeline
+// DBG (developer ablations, tools/bench_ring.py): 1 = skip the MFMAs, 2 = skip the DMA, 4 = MFMA-shape clock experiment (wrong
+// arithmetic), 8 = skip the epilogue, 16 = timeline
 // probe: a.res2 is NOT a residual but a u64 buffer [workgroup][wave][4 chunks][10 stamps] that receives s_memtime stamps of
 // chunks 8..11 of each workgroup's fourth tile (entry, after the counted wait, after the barrier, before the first tap, after
 // each of four tap groups, chunk end)
@@ -320,7 +321,14 @@ __global__ __launch_bounds__(RG_THREADS) void conv3x3_ring_kernel(cdfo_conv_args
 #pragma unroll
           for (int mi = 0; mi < 2; ++mi) {
             if (DBG & 1) acc[ni][mi][0] += (float)fa[par][mi][0] * (float)fb[par][ni][0];
-            else acc[ni][mi] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fb[par][ni], fa[par][mi], acc[ni][mi], 0, 0, 0);
+            else if (DBG & 4) {      // clock experiment: the 16x16x32 shape at equal FLOPs and fragment reads (NOT the convolution)
+              f32x4 lo = {acc[ni][mi][0], acc[ni][mi][1], acc[ni][mi][2], acc[ni][mi][3]};
+              f32x4 hi = {acc[ni][mi][4], acc[ni][mi][5], acc[ni][mi][6], acc[ni][mi][7]};
+              lo = __builtin_amdgcn_mfma_f32_16x16x32_f16(fb[par][ni], fa[par][mi], lo, 0, 0, 0);
+              hi = __builtin_amdgcn_mfma_f32_16x16x32_f16(fb[par][ni], fa[par][mi], hi, 0, 0, 0);
+#pragma unroll
+              for (int q = 0; q < 4; ++q) { acc[ni][mi][q] = lo[q]; acc[ni][mi][4 + q] = hi[q]; }
+            } else acc[ni][mi] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fb[par][ni], fa[par][mi], acc[ni][mi], 0, 0, 0);
           }
       };
       if (SPARSE) {
@@ -536,8 +544,14 @@ __global__ __launch_bounds__(RG_THREADS) void conv3x3_ring_kernel(cdfo_conv_args
 // One workgroup barrier per chunk, as before: producers arrive once THEIR pieces of batch g have landed (counted vmcnt),
 // consumers once their fragment reads of batch g-1 have returned; behind it the producers refill the stage of batch g-1.
 // Both role loops execute exactly my_units * nc barriers.
-template <bool SPARSE, int DBG>
+// MF16 (four-tap form only): the consumers run v_mfma_f32_16x16x32_f16 instead of 32x32x16 -- the loop is power-limited and the
+// chip holds a higher clock under that shape (see conv3x3_ws.hip, conv3x3_c64_wsq_kernel): K = 32 = the two taps of a window row
+// x 16 channels; a lane holds k-group l >> 4 = (tap of the pair, 8-channel half) of pixel / output channel l & 15; natural
+// [pixel][16 ch] records (no half swizzle: this read pattern is conflict-free without it) and a weight-row order in which a
+// lane's accumulators of channel blocks 2e, 2e+1 are 8 consecutive channels (the epilogue keeps its 32-byte granularity).
+template <bool SPARSE, int DBG, bool MF16 = false>
 __global__ __launch_bounds__(RG_THREADS) void conv3x3_ring_split_kernel(cdfo_conv_args a, ring_extra e) {
+  static_assert(!MF16 || SPARSE, "the 16x16x32 consumer exists for the four-tap form");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int TAPS = SPARSE ? 4 : 9;
   using L = RingLds<SPARSE>;
@@ -587,7 +601,7 @@ __global__ __launch_bounds__(RG_THREADS) void conv3x3_ring_split_kernel(cdfo_con
       if (!loader_w) {
         const int q = pw * ACT_PER + j;
         const bool real = j < ACT_PER && q < 20;
-        const int s = q * 64 + lane, p = s >> 1, half = (s & 1) ^ ((p >> 3) & 1);
+        const int s = q * 64 + lane, p = s >> 1, half = MF16 ? (s & 1) : (s & 1) ^ ((p >> 3) & 1);
         const int iy = p / RG_IW, ix = p - iy * RG_IW;
         d_iy[j] = (real && p < RG_NPIX) ? iy : 1 << 20;
         d_ix[j] = ix;
@@ -599,7 +613,8 @@ __global__ __launch_bounds__(RG_THREADS) void conv3x3_ring_split_kernel(cdfo_con
         d_iy[j] = real ? 0 : 1 << 20;
         d_ix[j] = 0;
         const int m = lane & 31;      // slab row position `lane` = MFMA row m of block (lane >> 5), see the kernel above
-        const int chan = (lane & 32) + ((m >> 4) & 1) * 16 + ((m >> 2) & 1) * 8 + ((m >> 3) & 1) * 4 + (m & 3);
+        const int chan = MF16 ? (lane >> 5) * 32 + ((lane & 15) >> 2) * 8 + ((lane >> 4) & 1) * 4 + (lane & 3)
+                              : (lane & 32) + ((m >> 4) & 1) * 16 + ((m >> 2) & 1) * 8 + ((m >> 3) & 1) * 4 + (m & 3);
         d_rel[j] = (q * e.CoutP + chan) * 16;
         dst_off[j] = real ? RG_ACT + q * 1024 : -1;
       }
@@ -757,6 +772,177 @@ __global__ __launch_bounds__(RG_THREADS) void conv3x3_ring_split_kernel(cdfo_con
 
   // ================================================================================================== consumers
   const float slope = a.act == CDFO_ACT_NONE ? 1.f : (a.act == CDFO_ACT_LRELU ? 0.1f : 0.f);
+  if constexpr (MF16) {
+    const int l16 = lane & 15, kg = lane >> 4, ktap = kg >> 1, khalf = kg & 1;
+    // weight fragment of (tap pair, channel block mb): slab row (pair*2 + ktap)*2 + khalf, position mb*16 + l16
+    const int w16 = RG_ACT + (ktap * 2 + khalf) * 1024 + l16 * 16;
+    // pixel fragments of the chunk about to be consumed (stage base included): halo rows 4w + rr + y0 (rr = row + pair = 0..4),
+    // column x0 + ktap + l16 (+16: immediate); computed one chunk ahead
+    int f16a[5] = {0, 0, 0, 0, 0};
+    auto frag16 = [&](int win, int stage_base) {
+      const int y0 = win >> 1, x0 = win & 1;
+#pragma unroll
+      for (int rr = 0; rr < 5; ++rr)
+        f16a[rr] = stage_base + ((wave * CR + rr + y0) * RG_IW + x0 + ktap + l16) * 32 + khalf * 16;
+    };
+    frag16(__builtin_amdgcn_readfirstlane(win_of(e.tap_mask[0])), 0);
+    int g = 0;
+    for (int ord = 0; ord < my_units; ++ord) {
+      // acc[mb][nbk][k]: block mb row 4 kg + k = channel (mb>>1)*32 + 8 kg + (mb&1)*4 + k; nbk = row*2 + pixel half
+      f32x4 acc[4][2 * CR];
+#pragma unroll
+      for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+        for (int nbk = 0; nbk < 2 * CR; ++nbk) acc[mb][nbk] = f32x4{0.f, 0.f, 0.f, 0.f};
+      int b, oy0, ox0, n0;
+      unit_coords(ord, b, oy0, ox0, n0);
+      const int oyw = oy0 + wave * CR;
+      auto chunk = [&](int c) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // my fragment reads of batch g-1 have returned
+        __builtin_amdgcn_s_barrier();
+        const unsigned char* sW = smem + (g % RG_NS) * STAGE + w16;
+        // four sub-steps: (tap pair, rows 0-1), (pair, rows 2-3); the weight fragments of a pair serve both
+        f16x8_t fw[2][4], fp[2][4];                 // [pair parity / sub-step parity][channel block / (row, pixel half)]
+        auto load_w = [&](int pair) {
+#pragma unroll
+          for (int mb = 0; mb < 4; ++mb) fw[pair & 1][mb] = *reinterpret_cast<const f16x8_t*>(sW + pair * 4096 + mb * 256);
+        };
+        auto load_p = [&](int ss) {
+          const int pair = ss >> 1, hr = ss & 1;
+#pragma unroll
+          for (int q = 0; q < 4; ++q)              // q = (row within the half)*2 + pixel half
+            fp[ss & 1][q] = *reinterpret_cast<const f16x8_t*>(smem + f16a[2 * hr + (q >> 1) + pair] + (q & 1) * 512);
+        };
+        load_w(0);
+        load_p(0);
+        const int win_n = smem[L::WINTAB + (c + 1 == nc ? 0 : c + 1)];
+#pragma unroll
+        for (int ss = 0; ss < 4; ++ss) {
+          if (ss < 3) load_p(ss + 1);
+          if (ss == 1) load_w(1);
+          __builtin_amdgcn_sched_barrier(0);
+          const int pair = ss >> 1, hr = ss & 1;
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb) {
+              if (DBG & 1) acc[mb][hr * 4 + q][0] += (float)fw[pair & 1][mb][0] * (float)fp[ss & 1][q][0];
+              else acc[mb][hr * 4 + q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fw[pair & 1][mb], fp[ss & 1][q], acc[mb][hr * 4 + q], 0, 0, 0);
+            }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        frag16(__builtin_amdgcn_readfirstlane(win_n), ((g + 1) % RG_NS) * STAGE);
+      };
+      // residual values of one tile row: [pixel half][e][4-channel half] -- 32 contiguous bytes per (pixel, e)
+      const bool has_res = a.res1 != nullptr && !(DBG & 8);
+      auto px_ok = [&](int mi, int nh) { return oyw + mi < H && ox0 + nh * 16 + l16 < W; };
+      auto load_res_row = [&](int mi, f32x4 (&rv)[2][2][2]) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) (&rv[0][0][0])[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (!has_res) return;
+#pragma unroll
+        for (int nh = 0; nh < 2; ++nh) {
+          if (!px_ok(mi, nh)) continue;
+          const float* rp = a.res1 + ((long long)(b * H + oyw + mi) * W + ox0 + nh * 16 + l16) * a.ldr1 + n0 + kg * 8;
+#pragma unroll
+          for (int ee = 0; ee < 2; ++ee)
+            if (n0 + ee * 32 + kg * 8 < a.Cout) {
+              rv[nh][ee][0] = *reinterpret_cast<const f32x4*>(rp + ee * 32);
+              rv[nh][ee][1] = *reinterpret_cast<const f32x4*>(rp + ee * 32 + 4);
+            }
+        }
+      };
+      for (int c = 0; c < nc - 1; ++c, ++g) chunk(c);
+      f32x4 rva[2][2][2], rvb[2][2][2];
+      load_res_row(0, rva);
+      chunk(nc - 1);
+      ++g;
+      if (DBG & 8) {
+        float t = 0.f;
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+          for (int nbk = 0; nbk < 2 * CR; ++nbk)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) t += acc[mb][nbk][k] + rva[nbk & 1][mb & 1][0][k];
+        if (t == 123.456f) a.out[0] = t;
+        continue;
+      }
+      auto epilogue_row = [&](int mi, const f32x4 (&rv)[2][2][2]) {
+        const int oy = oyw + mi;
+#pragma unroll
+        for (int nh = 0; nh < 2; ++nh) {
+          const int X = ox0 + nh * 16 + l16;
+          const bool ok = px_ok(mi, nh);
+          const long long pix = (long long)(b * H + oy) * W + X;
+#pragma unroll
+          for (int ee = 0; ee < 2; ++ee) {
+            const int n = n0 + ee * 32 + kg * 8;
+            const f32x4 b0 = *reinterpret_cast<const f32x4*>(smem + L::BIAS + n * 4);
+            const f32x4 b1 = *reinterpret_cast<const f32x4*>(smem + L::BIAS + n * 4 + 16);
+            f32x4 v0, v1;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+              const float t0 = acc[2 * ee][mi * 2 + nh][k] + b0[k], t1 = acc[2 * ee + 1][mi * 2 + nh][k] + b1[k];
+              v0[k] = fmaxf(t0, slope * t0);
+              v1[k] = fmaxf(t1, slope * t1);
+            }
+            v0 += rv[nh][ee][0];
+            v1 += rv[nh][ee][1];
+            if (!ok || n >= a.Cout) continue;
+            if (a.res2) {
+              const float* p2 = a.res2 + pix * a.ldr2 + n;
+              v0 += *reinterpret_cast<const f32x4*>(p2);
+              v1 += *reinterpret_cast<const f32x4*>(p2 + 4);
+            }
+            if (a.res_up2) {      // + bilinear x2 of the half-resolution tensor, from the staged tile (see the form above)
+              const float ly = (oy & 1) ? 0.25f : 0.75f, lx = (X & 1) ? 0.25f : 0.75f;
+              const int li = ((oy + 1) >> 1) - (oy0 >> 1), lj = ((X + 1) >> 1) - (ox0 >> 1);
+              const unsigned char* et = smem + L::ETILE;
+              const int cq = (ee * 32 + kg * 8) >> 2;
+#pragma unroll
+              for (int hf = 0; hf < 2; ++hf) {
+                auto tap = [&](int i, int j) {
+                  const int px = i * RG_ET_COLS + j;
+                  return *reinterpret_cast<const f32x4*>(et + px * 256 + (((cq + hf) ^ (px & 15)) << 4));
+                };
+                (hf ? v1 : v0) += (1.f - ly) * ((1.f - lx) * tap(li, lj) + lx * tap(li, lj + 1)) +
+                                  ly * ((1.f - lx) * tap(li + 1, lj) + lx * tap(li + 1, lj + 1));
+              }
+            }
+            f16x8_t hv;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { hv[k] = (_Float16)v0[k]; hv[4 + k] = (_Float16)v1[k]; }
+            if (a.out_f16) {
+              *reinterpret_cast<f16x8_t*>(reinterpret_cast<_Float16*>(a.out) + pix * a.ldo + n) = hv;
+            } else {
+              *reinterpret_cast<f32x4*>(a.out + pix * a.ldo + n) = v0;
+              *reinterpret_cast<f32x4*>(a.out + pix * a.ldo + n + 4) = v1;
+            }
+            if (a.out2_cp16) {
+              const int npl = a.out2_lo ? (a.Cout >> 3) : (a.Cout >> 4);
+              _Float16* o2 = static_cast<_Float16*>(a.out2_cp16) + (((long long)b * npl + (n >> 4)) * H * W + (long long)oy * W + X) * 16 + (n & 15);
+              *reinterpret_cast<f16x8_t*>(o2) = hv;
+              if (a.out2_lo) {
+                f16x8_t lv;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { lv[k] = (_Float16)(v0[k] - (float)hv[k]); lv[4 + k] = (_Float16)(v1[k] - (float)hv[4 + k]); }
+                *reinterpret_cast<f16x8_t*>(o2 + (long long)(a.Cout >> 4) * H * W * 16) = lv;
+              }
+            }
+          }
+        }
+      };
+      load_res_row(1, rvb);
+      epilogue_row(0, rva);
+      load_res_row(2, rva);
+      epilogue_row(1, rvb);
+      load_res_row(3, rvb);
+      epilogue_row(2, rva);
+      epilogue_row(3, rvb);
+    }
+    return;
+  }
   const int w_off = RG_ACT + (h * 64 + r) * 16;
   // dense: fragment offsets of halo rows 4w + rr (rr = 0..5), column offset dx, this lane's pixel r
   int p_off[SPARSE ? 1 : 18];
@@ -824,7 +1010,14 @@ __global__ __launch_bounds__(RG_THREADS) void conv3x3_ring_split_kernel(cdfo_con
 #pragma unroll
           for (int ni = 0; ni < 2; ++ni) {
             if (DBG & 1) acc[ni][mi][0] += (float)fa[par][mi][0] * (float)fb[par][ni][0];
-            else acc[ni][mi] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fb[par][ni], fa[par][mi], acc[ni][mi], 0, 0, 0);
+            else if (DBG & 4) {      // clock experiment: the 16x16x32 shape at equal FLOPs and fragment reads (NOT the convolution)
+              f32x4 lo = {acc[ni][mi][0], acc[ni][mi][1], acc[ni][mi][2], acc[ni][mi][3]};
+              f32x4 hi = {acc[ni][mi][4], acc[ni][mi][5], acc[ni][mi][6], acc[ni][mi][7]};
+              lo = __builtin_amdgcn_mfma_f32_16x16x32_f16(fb[par][ni], fa[par][mi], lo, 0, 0, 0);
+              hi = __builtin_amdgcn_mfma_f32_16x16x32_f16(fb[par][ni], fa[par][mi], hi, 0, 0, 0);
+#pragma unroll
+              for (int q = 0; q < 4; ++q) { acc[ni][mi][q] = lo[q]; acc[ni][mi][4 + q] = hi[q]; }
+            } else acc[ni][mi] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fb[par][ni], fa[par][mi], acc[ni][mi], 0, 0, 0);
           }
       };
       if (SPARSE) {
@@ -1033,6 +1226,14 @@ int rg_launch(const cdfo_conv_args& a, const ring_extra& e, int grid, hipStream_
   // (with a half-resolution residual the producers spread its 48 tile pieces over a tile's first six chunks: nc >= 8)
   if constexpr (SPARSE) {
     if (rg_split() && !(a.res_up2 && e.nc < 8)) {
+      static const bool mf16 = [] { const char* v = getenv("CDFO_RING_MFMA16"); return !(v && v[0] == '0'); }();
+      if (mf16 && !(DBG & (4 | 16))) {
+        static CdfoAttrOnce once16;
+        const hipError_t err = cdfo_set_max_lds(once16, reinterpret_cast<const void*>(conv3x3_ring_split_kernel<SPARSE, DBG, true>), RingLds<SPARSE>::TOTAL);
+        if (err != hipSuccess) return (int)err;
+        hipLaunchKernelGGL((conv3x3_ring_split_kernel<SPARSE, DBG, true>), dim3(grid), dim3(RG_THREADS), RingLds<SPARSE>::TOTAL, st, a, e);
+        return 0;
+      }
       const hipError_t err = cdfo_set_max_lds(once_split, reinterpret_cast<const void*>(conv3x3_ring_split_kernel<SPARSE, DBG>), RingLds<SPARSE>::TOTAL);
       if (err != hipSuccess) return (int)err;
       hipLaunchKernelGGL((conv3x3_ring_split_kernel<SPARSE, DBG>), dim3(grid), dim3(RG_THREADS), RingLds<SPARSE>::TOTAL, st, a, e);
@@ -1084,6 +1285,7 @@ extern "C" int cdfo_conv3x3_ring(const cdfo_conv_args* pa, void* stream) {
     case 0: rc = a.tap_mask ? rg_launch<true, 0>(a, e, grid, st) : rg_launch<false, 0>(a, e, grid, st); break;
     case 1: rc = a.tap_mask ? rg_launch<true, 1>(a, e, grid, st) : rg_launch<false, 1>(a, e, grid, st); break;
     case 2: rc = a.tap_mask ? rg_launch<true, 2>(a, e, grid, st) : rg_launch<false, 2>(a, e, grid, st); break;
+    case 4: rc = a.tap_mask ? rg_launch<true, 4>(a, e, grid, st) : rg_launch<false, 4>(a, e, grid, st); break;
     case 8: rc = a.tap_mask ? rg_launch<true, 8>(a, e, grid, st) : rg_launch<false, 8>(a, e, grid, st); break;
     case 9: rc = a.tap_mask ? rg_launch<true, 9>(a, e, grid, st) : rg_launch<false, 9>(a, e, grid, st); break;
     case 10: rc = a.tap_mask ? rg_launch<true, 10>(a, e, grid, st) : rg_launch<false, 10>(a, e, grid, st); break;

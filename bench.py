@@ -43,7 +43,7 @@ KID_NAMES = ["conv3x3_wide", "conv3x3_narrow", "conv1x1", "conv3x3_s2", "stem", 
              "colconv9", "attn_row", "attn_col", "attn_win", "layout", "pack", "dcn", "conv3x3_ws", "conv3x3_ring", "conv3x3_ring4", "conv3x3_ws_res", "dcn_bwd"]
 # kernel families on the 16-bit matrix cores -> (kernel symbol in the rocprofv3 stats, MFMA passes per algorithmic MAC)
 # conv3x3_wide (the tiled kernel) runs the --precision mode's passes: fp16x2 = 2 (3 for the split-bf16 feature cache)
-MFMA16 = {"conv3x3_wide": ("conv3x3_mma16_kernel", None), "conv3x3_ws": ("conv3x3_c64_ws_kernel<0, false, 12>", 1),
+MFMA16 = {"conv3x3_wide": ("conv3x3_mma16_kernel", None), "conv3x3_ws": ("conv3x3_c64_wsq_kernel", 1),
           "conv3x3_ws_res": ("conv3x3_c64_ws_kernel<0, true, 8>", 1),
           "conv3x3_ring": ("conv3x3_ring_kernel<false", 1), "conv3x3_ring4": ("conv3x3_ring_split_kernel<true", 1)}
 

@@ -1272,7 +1272,9 @@ extern "C" int cdfo_conv3x3_ring(const cdfo_conv_args* pa, void* stream) {
   ring_extra e;
   e.src = a.src[0]; e.nc = nc; e.w = a.w; e.CoutP = a.CoutP; e.tap_mask = a.tap_mask; e.w_bytes = (int)w_bytes;
   e.plane_wrap = a.src_plane_wrap;
-  static const int touch = [] { const char* v = getenv("CDFO_RING_TOUCH"); return (v && v[0] == '0') ? 0 : 1; }();
+  // (off by default: the touched lines do not survive until the epilogue -- FETCH_SIZE of the launch rose by exactly the res1
+  // tile bytes, 3.10 -> 3.44 GB, i.e. the epilogue fetched them again -- and the epilogue got 7 % shorter at best; CDFO_RING_TOUCH=1)
+  static const int touch = [] { const char* v = getenv("CDFO_RING_TOUCH"); return (v && v[0] == '1') ? 1 : 0; }();
   e.touch = (touch && a.res1 && (long long)a.H * a.W * a.ldr1 * 4 < (1ll << 31)) ? 1 : 0;
   e.src_planes = a.src_plane_wrap ? a.src_plane_wrap : nc;
   if (a.src_plane_wrap < 0 || a.src_plane_wrap > nc) return CDFO_EINVAL;

@@ -898,8 +898,11 @@ __global__ __launch_bounds__(WR_THREADS) void conv3x3_c64_wsq_kernel(ws_args a) 
       for (int nbk = 0; nbk < 4; ++nbk) acc[mb][nbk] = bias[mb];
 #pragma unroll
     for (int c = 0; c < 2; ++c, ++g) {
+      unsigned long long ts[6] = {0, 0, 0, 0, 0, 0};      // dbg 32: step entry, barrier passed, after taps 2 / 5 / 8, step end
+      if (DBG & 32) asm volatile("s_memtime %0" : "=s"(ts[0]) : : "memory");
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // my fragment reads of batch g-1 have returned
       __builtin_amdgcn_s_barrier();
+      if (DBG & 32) asm volatile("s_memtime %0" : "=s"(ts[1]) : : "memory");
       if (WR_PRIO) {      // last step of my tile: finish first, convert / store while the other group computes (see the kernel above)
         if (c == 1) __builtin_amdgcn_s_setprio(3);
         else __builtin_amdgcn_s_setprio(0);
@@ -929,7 +932,24 @@ __global__ __launch_bounds__(WR_THREADS) void conv3x3_c64_wsq_kernel(ws_args a) 
             else acc[mb][nbk] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fw[par][mb], fp[par][nbk], acc[mb][nbk], 0, 0, 0);
           }
         __builtin_amdgcn_sched_barrier(0);
+        if ((DBG & 32) && (t == 2 || t == 5 || t == 8)) asm volatile("s_memtime %0" : "=s"(ts[2 + t / 3]) : : "memory");
       }
+      if (DBG & 32) {
+        asm volatile("s_memtime %0" : "=s"(ts[5]) : : "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (a.clk && ord == 2 && lane == 0) {
+          unsigned long long* cbuf = a.clk + (((long long)blockIdx.x * 12 + wave) * 4 + c) * 8;
+#pragma unroll
+          for (int i = 0; i < 6; ++i) cbuf[i] = ts[i];
+        }
+      }
+    }
+    if (DBG & 32) {
+      unsigned long long te = 0;
+      asm volatile("s_memtime %0" : "=s"(te) : : "memory");
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      if (a.clk && (ord == 3 || ord == 4 || ord == 24) && lane == 0)       // epilogue-start times: undisturbed tile period(s)
+        a.clk[(((long long)blockIdx.x * 12 + wave) * 4 + (ord == 24 ? 2 : ord - 3)) * 8 + 6] = te;
     }
     if (DBG & 8) {
       float t = 0.f;
@@ -993,7 +1013,7 @@ bool ws_mfma16() {
 
 template <int DBG>
 int wsr_launch(const ws_args& a, hipStream_t st) {
-  if constexpr ((DBG & ~11) == 0) {
+  if constexpr ((DBG & ~43) == 0) {
     if (ws_mfma16()) {
       static CdfoAttrOnce onceq;
       const hipError_t e = cdfo_set_max_lds(onceq, reinterpret_cast<const void*>(conv3x3_c64_wsq_kernel<DBG>), WQ_TOTAL);

@@ -21,19 +21,23 @@ def main():
         K.conv3x3_ws(src, pc, act=1, s2d=s2d, out=out, dbg=32, clk=clk)
     torch.cuda.synchronize()
     t = clk.cpu().double()[:, :8]                  # consumers
-    ok = (t[..., 0] > 0).all(dim=-1).all(dim=-1)
+    nst = 4 if (t[:, :, 3, 0] > 0).any() else 2    # steps per tile: 4 chunks (32x32x16 form) or 2 superchunks (16x16x32 form)
+    ok = (t[:, :, :nst, 0] > 0).all(dim=-1).all(dim=-1)
     t = t[ok]
     print(f"# 64->256 {H}x{W} B{B}: {int(ok.sum())} workgroups; ticks = shader cycles")
-    d = t[..., 1:6] - t[..., 0:5]
+    d = t[:, :, :nst, 1:6] - t[:, :, :nst, 0:5]
     for i in range(5):
         print(f"   {NAMES[i]:8s} -> {NAMES[i + 1]:8s} {d[..., i].mean():7.1f}   (group A {d[:, :4, :, i].mean():7.1f}, group B {d[:, 4:, :, i].mean():7.1f})")
     period = (t[:, :, 1, 6] - t[:, :, 0, 6])
-    print(f"# undisturbed tile period (epilogue start of tile 4 -> tile 5): {period[period > 0].mean():.0f} ticks = {period[period > 0].mean() / 4:.0f} per chunk")
+    print(f"# undisturbed tile period (epilogue start of tile 4 -> tile 5): {period[period > 0].mean():.0f} ticks")
+    long = (t[:, :, 2, 6] - t[:, :, 1, 6])
+    if (long > 0).any():
+        print(f"# mean tile period over tiles 5..25: {long[long > 0].mean() / 20:.0f} ticks")
     g = t[0]
     base = g[:, 0, 0].min()
     for wv in range(8):
-        for c in range(4):
-            print(f"   wave {wv} chunk {c}: " + " ".join(f"{int(v - base):6d}" for v in g[wv, c, :6]))
+        for c in range(nst):
+            print(f"   wave {wv} step {c}: " + " ".join(f"{int(v - base):6d}" for v in g[wv, c, :6]))
 
 
 if __name__ == "__main__":

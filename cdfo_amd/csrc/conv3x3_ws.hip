@@ -405,9 +405,6 @@ constexpr int WR_CONS = 8, WR_THREADS = 12 * 64, WR_LAG = 2;      // group B run
 #ifndef WR_PRIO
 #define WR_PRIO 1
 #endif
-#ifndef WR_ROWSPLIT
-#define WR_ROWSPLIT 0      // last chunk row by row with the first row's epilogue between the second row's taps: measured no gain
-#endif
 constexpr int WR_W_OFF = 2 * WR_NS * WR_ACT;           // 90,112
 constexpr int WR_TOTAL = WR_W_OFF + WS_W_BYTES;        // 163,840 bytes
 static_assert(WR_TOTAL <= 160 * 1024, "LDS budget");
@@ -639,7 +636,7 @@ __global__ __launch_bounds__(WR_THREADS) void conv3x3_c64_wsr_kernel(ws_args a) 
       const unsigned char* sA = smem + (g % WR_NS) * WR_ACT;
       const unsigned char* sWc = sWl + c * (9 * 2 * 64 * 16);
       f16x8_t fp[2][2], fw[2][2];                // [parity][mi / ni]: fragments are read one tap ahead
-      if (c < 3 || (DBG & 8) || !WR_ROWSPLIT) {
+      {
         auto load_frags = [&](int t, int par) {
           const int dy = t / 3, dx = t - dy * 3;
 #pragma unroll
@@ -670,35 +667,6 @@ __global__ __launch_bounds__(WR_THREADS) void conv3x3_c64_wsr_kernel(ws_args a) 
           __builtin_amdgcn_sched_barrier(0);
           if ((DBG & 32) && (t == 2 || t == 5 || t == 8)) asm volatile("s_memtime %0" : "=s"(ts[2 + t / 3]) : : "memory");
         }
-      } else {
-        // Last chunk of the tile, row by row: image row 0 through all nine taps first, then row 1 -- with row 0's four epilogue
-        // pieces (32 conversions + a store each) placed between row 1's taps, where they overlap this wave's own MFMAs (an MFMA
-        // holds the vector issue for 8 of its 32 cycles).  What is left after the last MFMA is row 1's half of the epilogue,
-        // short enough for the other group's tail to cover.  Cost: the weight fragments are read twice in this chunk.
-        auto load_row = [&](int t, int par, int mi) {
-          const int dy = t / 3, dx = t - dy * 3;
-#pragma unroll
-          for (int ni = 0; ni < 2; ++ni) fw[par][ni] = *reinterpret_cast<const f16x8_t*>(sWc + (t * 2 * 64 + ni * 32) * 16);
-          fp[par][0] = *reinterpret_cast<const f16x8_t*>(sA + p_off[(mi + dy) * 3 + dx]);
-        };
-        load_row(0, 0, 0);
-#pragma unroll
-        for (int u = 0; u < 18; ++u) {             // u = row * 9 + tap
-          const int mi = u / 9, t = u - mi * 9, par = u & 1;
-          if (u < 17) load_row((u + 1) % 9, par ^ 1, (u + 1) / 9);
-          __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-          for (int ni = 0; ni < 2; ++ni) {
-            if (DBG & 1) acc[ni][mi][0] += (float)fw[par][ni][0] * (float)fp[par][0][0];
-            else acc[ni][mi] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fw[par][ni], fp[par][0], acc[ni][mi], 0, 0, 0);
-          }
-          __builtin_amdgcn_sched_barrier(0);
-          if (mi == 1 && (t & 1) == 0 && t < 8) {
-            epilogue_piece(0, t >> 1);
-            __builtin_amdgcn_sched_barrier(0);
-          }
-          if ((DBG & 32) && (u == 5 || u == 11 || u == 17)) asm volatile("s_memtime %0" : "=s"(ts[2 + u / 6]) : : "memory");
-        }
       }
       if (DBG & 32) {
         asm volatile("s_memtime %0" : "=s"(ts[5]) : : "memory");
@@ -727,12 +695,11 @@ __global__ __launch_bounds__(WR_THREADS) void conv3x3_c64_wsr_kernel(ws_args a) 
       if (t == 123.456f) a.out[0] = (_Float16)t;
       continue;
     }
-    if (!WR_ROWSPLIT) {
+    // (tried: the last chunk row by row with row 0's epilogue pieces between row 1's taps -- tile period 12 870 -> 13 440 cycles, removed)
 #pragma unroll
-      for (int k = 0; k < 4; ++k) epilogue_piece(0, k);
-    }
+    for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-    for (int k = 0; k < 4; ++k) epilogue_piece(1, k);
+      for (int k = 0; k < 4; ++k) epilogue_piece(mi, k);
   }
   for (int s = lag; s < WR_LAG; ++s) {       // group A waits out group B's lag: every wave runs nbatch + WR_LAG barriers
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");

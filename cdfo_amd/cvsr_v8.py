@@ -150,6 +150,8 @@ class CVSR_V8(nn.Module):
         # stream (tools/bench_streaming.py, 24 frames 270x480, eager / HIP graph: 65.4 / 67.1 frames/s without the overlap,
         # 66.7 / 67.6 with it, 66.9 / 68.0 with the new frame alone)
         self.new_frame_alone = os.environ.get("CDFO_NEW_ALONE", "1") not in ("", "0")
+        # Block_: the half-resolution branch on a side stream beside the other two (see _block)
+        self.trunk_side_stream = os.environ.get("CDFO_TRUNK_SIDE", "1") not in ("", "0")
         # fp16x2 mode, the feature extractor's two 3x3 convolutions on the ring kernel: True = activations fp16 hi + lo x
         # weights fp16 hi + lo (three terms, fp32-grade: L1_fea 1.3e-5 max-abs); False = weights rounded once to fp16 (two
         # terms): measured 1.7e-3 on the RETURNED feature cache (|L1_fea| up to 7), outside the 1e-3 bound, for 1.3 ms per
@@ -465,9 +467,23 @@ class CVSR_V8(nn.Module):
                 u16, d16, x16 = K.block_prologue(x, w[p + "pro"], want_x16=True)
             else:
                 u16, d16 = K.block_prologue(x, w[p + "pro"])
-            out = K.conv_ring(c1(x16), b2, res1=x)
-            d = K.conv_ring(c1(d16), w[p + "body.2_up"])      # = up.0(body.2(.)) of the x1/2 branch
-            t = c1(u16, s2d=True)
+            # The x1/2 branch (two launches on a quarter of the pixels: 72 tiles per clip at 272x480, a fraction of the GPU for one
+            # or two clips and a ragged last round for eight) runs on a side stream beside the x1 and x2 branches; the last
+            # convolution joins the three.
+            side = self._trunk_side(x.device) if self.trunk_side_stream else None
+            if side is not None:
+                main = torch.cuda.current_stream(x.device)
+                side.wait_stream(main)
+                with torch.cuda.stream(side):
+                    d = K.conv_ring(c1(d16), w[p + "body.2_up"])      # = up.0(body.2(.)) of the x1/2 branch
+                out = K.conv_ring(c1(x16), b2, res1=x)
+                t = c1(u16, s2d=True)
+                main.wait_stream(side)
+                d.record_stream(main)
+            else:
+                out = K.conv_ring(c1(x16), b2, res1=x)
+                d = K.conv_ring(c1(d16), w[p + "body.2_up"])      # = up.0(body.2(.)) of the x1/2 branch
+                t = c1(u16, s2d=True)
             # want16: the next block's fp16 source; want_hl (a group's last block): fp16 hi | lo planes for the group convolution
             y16 = torch.empty_like(x16) if want16 else None
             if want_hl:
@@ -486,6 +502,13 @@ class CVSR_V8(nn.Module):
         t = self._conv(u, b0, pad=1, act=K.ACT_LRELU, s2d=True, out_f16=t16, inner=True)
         y = self._conv(t, w[p + "down_fused"], pad=1, res1=out)
         return (y, None) if want16 else y
+
+    def _trunk_side(self, device):
+        cache = self.__dict__.setdefault("_trunk_side_streams", {})
+        st = cache.get(device)
+        if st is None:
+            st = cache[device] = torch.cuda.Stream(device)
+        return st
 
     def _trunk(self, w, fused):
         y = fused

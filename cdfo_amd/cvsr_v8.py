@@ -585,6 +585,31 @@ class CVSR_V8(nn.Module):
 
     FP16_WINDOW = (2.0 ** -6, 2.0 ** 11)
 
+    # -- the forward in two halves (inference only, no range guard: the caller owns the schedule) -------------------
+    def forward_front(self, x, mvs0, mvs1, pms, rms, ufs, pre_L1_fea=None, gumbel_uniform=None):
+        """Feature extraction + neighbour pipelines + temporal fusion on the CURRENT stream.  Returns (state, L1_fea):
+        `state` goes to `forward_back`, `L1_fea` is what `forward` returns as its second output (the next call's
+        `pre_L1_fea`).  A caller may run `forward_back(state)` on another stream (after making it wait for this one) while the
+        next frame's `forward_front` is already running here: cdfo_amd.streaming.StreamingSR.run_pipelined does."""
+        if not x.is_cuda:
+            raise NotImplementedError("CVSR_V8 (HIP): CPU tensors are not supported; there is no CPU fallback")
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            raise NotImplementedError("CVSR_V8 (HIP): forward_front / forward_back are inference calls -- wrap them in torch.no_grad()")
+        with K.on_device(x):
+            noise = gumbel_uniform if gumbel_uniform is not None else self.gumbel_uniform
+            if noise is None:
+                self._noise_seed = K.next_noise_seed(x.device)
+            self._probe = None
+            fused, L1, xf = self._front(x, mvs0, mvs1, pms, rms, ufs, pre_L1_fea, noise)
+        return (fused, xf), L1.permute(0, 3, 1, 2)
+
+    def forward_back(self, state):
+        """Reconstruction trunk + upsampling + skip of a `forward_front` state, on the CURRENT stream."""
+        fused, xf = state
+        with K.on_device(fused):
+            self._probe = None
+            return self._back(fused, xf)
+
     def refresh_noise_key(self, device=None) -> int:
         """Write a fresh Philox key (advancing torch's default generator like an eager forward does) into the device word that
         CAPTURED forwards read: call before capturing and before every replay of a HIP graph of this model, so that each
@@ -599,6 +624,14 @@ class CVSR_V8(nn.Module):
         return seed
 
     def _forward(self, x, mvs0, mvs1, pms, rms, ufs, pre_L1_fea=None, gumbel_uniform=None):
+        fused, L1, xf = self._front(x, mvs0, mvs1, pms, rms, ufs, pre_L1_fea, gumbel_uniform)
+        return self._back(fused, xf, L1), L1.permute(0, 3, 1, 2)
+
+    def _front(self, x, mvs0, mvs1, pms, rms, ufs, pre_L1_fea=None, gumbel_uniform=None):
+        """Steps 1-3 of the forward: feature extraction, the six neighbour pipelines, temporal fusion.  Returns (fused
+        [B,H,W,64], L1 [B*7,H,W,64] clip-major, x as the contiguous fp32 tensor the skip connection reads).  `_back` is the
+        rest; the split exists for callers that run the two halves of consecutive frames beside each other
+        (StreamingSR.run_pipelined)."""
         B, N, C, H, W = x.shape
         if N != NFRAMES or C != 1:
             raise ValueError(f"expected x of shape [B,7,1,H,W], got {tuple(x.shape)}")
@@ -691,10 +724,18 @@ class CVSR_V8(nn.Module):
             main.wait_stream(st)
         aligned: List[torch.Tensor] = [Lf[ctr] if i == ctr else aligned_by_frame[i] for i in range(N)]
 
-        # 3. temporal fusion, 4. reconstruction trunk, 5. upsampling + skip (arch.py:4463-4481)
+        # 3. temporal fusion (arch.py:4463)
         fused = self._conv(aligned, w["tsa_fusion"], act=K.ACT_LRELU)
         if self._probe is not None:
             K.range_probe(fused, self._probe[0:2])
+        return fused, L1, x
+
+    def _back(self, fused, x, L1=None):
+        """Steps 4-5: reconstruction trunk, upsampling + skip (arch.py:4464-4481).  x: the fp32 input clip of `_front`."""
+        B, N, C, H, W = x.shape
+        w = self._weights()
+        raw = w["raw"]
+        ctr, P = self.center, H * W
         t = self._trunk(w, fused)
         if self.debug_taps is not None:
             self.debug_taps.update(L1_fea=L1, fused=fused, trunk=t)
@@ -706,7 +747,7 @@ class CVSR_V8(nn.Module):
             out = K.upconv_last(t, w["upconv2"], raw["conv_last.weight"], raw["conv_last.bias"], x[:, ctr], N * P)
         if self._probe is not None:
             K.range_probe(out, self._probe[2:4])
-        return out, L1.permute(0, 3, 1, 2)
+        return out
 
     def _neighbour_group(self, w, raw, Lf, idxs, xcG, ufs, rms, mvs1, noise, draw0, B, H, W, P, N, keep):
         """Neighbour frames `idxs` (consecutive) together: prior stems, RDAB compensation, conv_expand_fea_r, MV alignment

@@ -163,6 +163,50 @@ class StreamingSR:
         self.fea = fea.clone()                                       # the static output buffer is overwritten next step
         return out[..., :4 * self.H, :4 * self.W].clone()
 
+    def _inputs(self, i: int):
+        o = generate_input_index(i, NFRAMES, self.T - 1).to(self.dev)
+        po = o.clamp_min(1) if self.T > 1 else o
+        win = lambda t, idx: t.index_select(0, idx)[None, :, None]            # [1,7,1,H,W]
+        return (win(self.lr, o), self._mvs(self.mvl0, i), self._mvs(self.mvl1, i), win(self.pms, po), win(self.rms, po),
+                win(self.ufs, po))
+
+    def run_pipelined(self) -> List[torch.Tensor]:
+        """All frames in order, software-pipelined over two streams: frame i + 1's front half (the new frame's feature
+        extraction, the six neighbour pipelines, temporal fusion -- launches on one to three frames that leave much of the GPU
+        idle at one clip) runs beside frame i's reconstruction trunk (matrix-core bound).  Frame i + 1 only needs frame i's
+        feature cache, which its front half produced.  Same kernels, same arithmetic, same noise keys in the same order as
+        `run()`: the outputs are identical.  `self.fps` afterwards = frames / wall time of the whole loop (a THROUGHPUT; the
+        per-frame latency is that of `run()`).  The fp16 range guard of `forward` (one host readback per call) is not part
+        of this schedule, as in the graph mode."""
+        if not hasattr(self.model, "forward_front"):
+            raise NotImplementedError("run_pipelined needs a model with forward_front / forward_back (CVSR_V8)")
+        front, back = torch.cuda.Stream(self.dev), torch.cuda.Stream(self.dev)
+        cur = torch.cuda.current_stream(self.dev)
+        front.wait_stream(cur)
+        back.wait_stream(cur)
+        outs, fea = [], None
+        torch.cuda.synchronize(self.dev)
+        t0 = time.perf_counter()
+        with torch.no_grad():
+            for i in range(self.T):
+                with torch.cuda.stream(front):
+                    x, m0, m1, p, r, u = self._inputs(i)
+                    noise = None if self.noise is None else self.noise[i]
+                    state, fea = self.model.forward_front(x, m0, m1, p, r, u, fea, gumbel_uniform=noise)
+                    ready = torch.cuda.Event()
+                    ready.record(front)
+                with torch.cuda.stream(back):
+                    back.wait_event(ready)
+                    for t in state:
+                        t.record_stream(back)
+                    out = self.model.forward_back(state)
+                    outs.append(out[..., :4 * self.H, :4 * self.W])
+        torch.cuda.synchronize(self.dev)
+        self.seconds = time.perf_counter() - t0
+        self.fea = fea
+        cur.wait_stream(back)
+        return outs
+
     def run(self) -> List[torch.Tensor]:
         """All frames in order; ``self.fps`` afterwards = frames / summed forward time (test_LD_22_FPS.py:192)."""
         self.fea, self.seconds = None, 0.0

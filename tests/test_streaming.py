@@ -111,6 +111,33 @@ def test_graph_replays_draw_fresh_noise_per_frame():
     assert not torch.equal(o1, o2) and (o1 - o2).abs().max().item() < 1e-2
 
 
+@pytest.mark.gpu
+def test_pipelined_loop_gives_the_sequential_frames():
+    """run_pipelined (frame i + 1's front half beside frame i's trunk, two streams) = run(): injected noise -> identical
+    frames against the oracle-checked sequential loop; default noise -> the same frames for the same generator state."""
+    from arch.SIDECVSR_our import CVSR_V8
+    from cdfo_amd.streaming import StreamingSR
+    from oracle.cvsr_v8_ref import make_inputs, make_state_dict
+    T, H, W = 6, 16, 24
+    lr, pms, rms, ufs, mvl0, mvl1 = _sequence(T, H, W, 11)
+    model = CVSR_V8()
+    model.load_state_dict(make_state_dict(23, perturb=True), strict=True)
+    model = model.cuda().eval()
+    noise = [[u.cuda() for u in make_inputs(1, H, W, 400 + i)["gumbel_u"]] for i in range(T)]
+    seq = StreamingSR(model, lr, pms, rms, ufs, mvl0, mvl1, gumbel_uniform=noise).run()
+    sp = StreamingSR(model, lr, pms, rms, ufs, mvl0, mvl1, gumbel_uniform=noise)
+    pip = sp.run_pipelined()
+    assert len(pip) == T and sp.fps > 0
+    for i, (a, b) in enumerate(zip(seq, pip)):
+        assert torch.equal(a, b), f"frame {i}: pipelined differs by {(a - b).abs().max().item()}"
+    torch.manual_seed(77)
+    d_seq = StreamingSR(model, lr, pms, rms, ufs, mvl0, mvl1).run()
+    torch.manual_seed(77)
+    d_pip = StreamingSR(model, lr, pms, rms, ufs, mvl0, mvl1).run_pipelined()
+    for a, b in zip(d_seq, d_pip):
+        assert torch.equal(a, b)
+
+
 def _fresh_step(s, i):
     from cdfo_amd.streaming import NFRAMES, generate_input_index
     o = generate_input_index(i, NFRAMES, s.T - 1).to(s.dev)

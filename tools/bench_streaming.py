@@ -31,5 +31,31 @@ def main():
               f"{s.fps:.2f} frames/s ({1e3 * s.seconds / T:.1f} ms per frame, forward only, B=1)", flush=True)
 
 
+def pipelined():
+    T, H, W = 48, 270, 480
+    if "--size" in sys.argv:
+        k = sys.argv.index("--size")
+        T, H, W = int(sys.argv[k + 1]), int(sys.argv[k + 2]), int(sys.argv[k + 3])
+    rs = np.random.RandomState(0)
+    u8 = lambda: rs.randint(0, 256, size=(T, H, W)).astype(np.uint8)
+    lr, pms, ufs = u8(), u8(), u8()
+    rms = np.clip(np.round(rs.randn(T, H, W) * 6), -128, 127).astype(np.float32)
+    mv = rs.randint(-64, 64, size=(2, T, (H + 7) // 8, (W + 7) // 8, 3)).astype(np.float32)
+    mv[..., 2] = rs.choice([-2.0, -1.0, 1.0], size=mv.shape[:-1])
+    mv = np.repeat(np.repeat(mv, 8, axis=2), 8, axis=3)[:, :, :H, :W]
+    model = CVSR_V8().cuda().eval()
+    s = StreamingSR(model, lr, pms, rms, ufs, mv[0], mv[1])
+    s.run()
+    s.run()
+    print(f"streaming, sequential loop (per-frame timing), {T} frames {H}x{W}: {s.fps:.2f} frames/s", flush=True)
+    for _ in range(3):
+        s.run_pipelined()
+        print(f"streaming, PIPELINED over two streams (whole-loop wall time), {T} frames: {s.fps:.2f} frames/s "
+              f"({1e3 * s.seconds / T:.2f} ms per frame)", flush=True)
+
+
 if __name__ == "__main__":
+    if "--pipelined" in sys.argv:
+        pipelined()
+        sys.exit(0)
     main()

@@ -90,9 +90,12 @@ int cdfo_pack_conv3x3_f16(const float* w_oihw, void* packed, int Cout, int Cin, 
  * cdfo_resample2 with out_f16 = 2); w_f16/CoutP: cdfo_pack_conv3x3_f16 packing and its padded channel count;
  * out_cp16: fp16 chunk-planar [B][Cout/16][H][W][16] (CDFO_STORE_PLAIN) or its space-to-depth form
  * [B][4*Cout/16][H/2][W/2][16], chunk = ((y&1)*2+(x&1))*Cout/16 + channel/16 (CDFO_STORE_S2D).
- * H even, Cout % 64 == 0, the source smaller than 2 GiB.  dbg: 0 (developer ablation flags otherwise; with dbg 128
- * clk_probe receives, per wave of the grid, {shader-clock cycles, start, end in 100 MHz real-time ticks}: 3 x 8 x 256
- * 64-bit words; else pass NULL).  */
+ * H even, Cout % 64 == 0, the source smaller than 2 GiB.  Since round 3 the call runs the ring-fed, wave-specialised form
+ * (four producer waves feed two groups of four consumer waves, v_mfma_f32_16x16x32_f16); same operands, same result layout.
+ * dbg: 0 (developer ablation flags otherwise: 1 / 2 / 8 skip the MFMAs / the DMA / the epilogue, 4 = MFMA-shape clock
+ * experiment with WRONG arithmetic; with dbg 32 clk_probe receives s_memtime stamps of the consumer waves, 256 x 12 x 4 x 8
+ * 64-bit words; with dbg 128 -- private-halo form only -- per wave of the grid {shader-clock cycles, start, end in 100 MHz
+ * real-time ticks}: 3 x 8 x 256 words; else pass NULL).  */
 int cdfo_conv3x3_c64_ws(const void* src_cp16, int B, int H, int W, const void* w_f16, int CoutP, const float* bias,
                         int Cout, int act, void* out_cp16, int store_mode, int dbg, void* clk_probe, void* stream);
 /* Residual form of cdfo_conv3x3_c64_ws (ResidualBlock_noBN's second convolution, arch.py:261-262):

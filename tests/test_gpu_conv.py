@@ -240,6 +240,8 @@ WS_CASES = [
     (256, 272, 480, 2, True, 1),
     (64, 2, 8, 1, False, 1),       # a single tile row, narrower than a tile
     (64, 8, 200, 3, False, 0),
+    (192, 20, 70, 2, False, 1),    # three 64-channel blocks: the XCD's 32 workgroup slots do not divide evenly
+    (320, 34, 36, 1, True, 2),     # five blocks, a ragged last tile row (34 = 2 x 16 + 2), space-to-depth store
 ]
 
 

@@ -61,6 +61,7 @@ __device__ __forceinline__ float c1_row16_sum(float v) {  // sum over the 16 lan
 template <int NCB, bool TAPS = false>
 __global__ __launch_bounds__(256, 2) void conv1x1_bf16x3_kernel(cdfo_conv_args a) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[A_BYTES + W_BYTES];
+  static_assert(EPI_BYTES <= A_BYTES + W_BYTES, "the epilogue transpose reuses the staging buffers");
   unsigned char* sA = smem;
   unsigned char* sW = smem + A_BYTES;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, h = lane >> 5, r = lane & 31;

@@ -50,7 +50,7 @@ MFMA16 = {"conv3x3_wide": ("conv3x3_mma16_kernel", None), "conv3x3_ws": ("conv3x
 
 # HBM-bound kernel families of the event profiler -> substrings of the kernel symbols they launch (rocprofv3 names); used to
 # pair a family's algorithmic bytes with the PMC traffic of the same launches (tools/pmc_summary.py --families)
-HBM_FAMILIES = {"conv1x1": ["conv1x1_stream_kernel", "conv1x1_bf16x3_kernel"], "dwconv": ["qkv_dw_kernel", "dwconv3x3_kernel"],
+HBM_FAMILIES = {"conv1x1": ["conv1x1_stream_kernel", "conv1x1_bf16x3_kernel"], "dwconv": ["qkv_dw_kernel", "qkv_dw2_kernel", "dwconv3x3_kernel"],
                 "attn_row": ["seq_attn_mfma_kernel<0"], "attn_col": ["seq_attn_mfma_kernel<1"], "attn_win": ["seq_attn_mfma_kernel<2"],
                 "rdab_prep": ["rdab_prep_kernel"], "resample": ["block_pro_kernel", "resample2_kernel"], "stem": ["stem_conv"],
                 "flow_warp": ["flow_warp_kernel"], "colconv9": ["colconv9_kernel"], "chan_sum": ["chan_sum_partial_kernel"],
@@ -121,7 +121,8 @@ def parse_args(argv=None):
     ap.add_argument("--breakdown", type=str, default="", help="write the per-kernel-family event timings to this file")
     ap.add_argument("--injected-noise", action="store_true", help="time the forward with pre-made Gumbel noise tensors (the parity tests' path) instead of the default in-kernel draws")
     ap.add_argument("--no-full-size-parity", action="store_true", help="N > 1: skip rank 0's clip-0 check at the timed size (every rank still checks c1)")
-    ap.add_argument("--no-extra-modes", action="store_true", help="skip the extra measurements (bf16x3 mode, injected-noise path, DCN / V7 lines)")
+    ap.add_argument("--no-extra-modes", action="store_true", help="skip the extra measurements (bf16x3 mode, injected-noise path, DCN / V7 / streaming / training lines)")
+    ap.add_argument("--process-group", action="store_true", help="N = 1: still initialise the process group (RCCL, world size 1) so that the barriers and the metric all_gather of the N > 1 path run over RCCL; automatic under torchrun")
     return ap.parse_args(argv)
 
 
@@ -146,8 +147,17 @@ def main():
         local %= max(1, torch.cuda.device_count())
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
-        import torch.distributed as dist
+    # The process group exists whenever there is a rendezvous to join: always at N > 1, and at N = 1 under torchrun
+    # (`torchrun --nproc-per-node 1 bench.py`) or with --process-group -- the one-rank run then takes the same barriers and
+    # the same all_gather over RCCL as the multi-GPU run (the way to prove that line on a one-GPU box).
+    import torch.distributed as dist
+    under_torchrun = all(k in os.environ for k in ("RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"))
+    use_pg = world > 1 or under_torchrun or args.process_group
+    if use_pg:
+        if not under_torchrun:                               # --process-group outside torchrun: a one-rank rendezvous on localhost
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(sk.getsockname()[1]), RANK="0", WORLD_SIZE="1")
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:
@@ -186,7 +196,7 @@ def main():
             return model(d["x"], d["mvs0"], d["mvs1"], d["pms"], d["rms"], d["ufs"], pre, gumbel_uniform=noise)
 
     def barrier():
-        if world > 1:
+        if use_pg:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -307,13 +317,17 @@ def main():
 
     # ---- the single collective: all_gather of per-rank metrics (time, checksum, parity)
     from cdfo_amd.dist import gather_metrics
-    ident = device_identity(local)               # 8 numbers: which physical GPU this rank drove (checked for duplicates below)
+    ident = device_identity(local)               # 8 numbers: which physical GPU this rank drove (duplicates fail the run below)
     allm = gather_metrics([elapsed, out.double().mean().item(), max_abs, psnr if math.isfinite(psnr) or psnr != psnr else 999.0,
                            elapsed_prof, max_abs_full, float(local), *ident], dev if backend == "nccl" else None)
     t_max = allm[:, 0].max().item()
     # parity gate: a numerically broken build must not print a valid-looking line
     parity_ok = args.no_parity or (all(math.isfinite(v) and v <= PARITY_BOUND for v in allm[:, 2].tolist())
                                    and all(v != v or v <= PARITY_BOUND for v in allm[:, 5].tolist()))
+    # one GPU per rank is what "n_gpus" claims: two ranks on one physical device (a wrong LOCAL_RANK / HIP_VISIBLE_DEVICES
+    # mapping) would print a valid-looking scaling line.  Only the explicit gloo rehearsal may share devices.
+    distinct = len({tuple(allm[r, 7:15].tolist()) for r in range(world)})
+    devices_ok = backend != "nccl" or distinct == world
 
     if rank == 0:
         clips_total = B * world * args.steps
@@ -385,10 +399,10 @@ def main():
                        "verified": bool(parity_ok and not args.no_parity),
                        "per_rank_max_abs": [float(v) for v in allm[:, 2]],
                        "full_size_max_abs": (None if max_abs_full != max_abs_full else max_abs_full)},
-            "world": world, "backend": (dist.get_backend() if world > 1 else None),
+            "world": world, "backend": (dist.get_backend() if use_pg else None),
             "ranks": [{"rank": r, "ms_per_step": round(1e3 * allm[r, 0].item() / args.steps, 3), "local_device": int(allm[r, 6].item()),
                        "device": format_identity(allm[r, 7:15].tolist())} for r in range(world)],
-            "distinct_devices": len({tuple(allm[r, 7:15].tolist()) for r in range(world)}),
+            "distinct_devices": distinct,
             "roofline": roofline, "cpu_baseline": cpu, "fp16_range_guard": range_info, **extra,
         }
         if world == 1 and not args.no_parity and not args.no_extra_modes:
@@ -397,6 +411,11 @@ def main():
             res["dcn_forward"] = dcn_forward_line(dev, Hp, Wp, B)
             # SURVEY section 8f n3, also outside the timed region: the DCN-aligned CVSR_V7 on the same synthetic clips
             res["cvsr_v7"] = cvsr_v7_line(dev, d, Hp, Wp, B)
+            torch.cuda.empty_cache()
+            # SURVEY section 8f n1 / n2, outside the timed region: the reference's real evaluation loop (one sequence, one new
+            # frame per forward, test_LD_22_FPS.py:183-192) and its training step (train_LD_37.py:376-381)
+            res["streaming_b1"] = streaming_b1_line(dev, args.height, args.width)
+            res["train_step"] = train_step_line(dev)
         print(json.dumps(res))
         if args.breakdown:
             with open(args.breakdown, "w") as f:
@@ -408,11 +427,76 @@ def main():
                         continue
                     f.write(f"{KID_NAMES[k]} {launches[k]} {ms[k]:.3f} {ms[k]/tot:.4f} {ms[k]/launches[k]:.4f} "
                             f"{fl[k]/ms[k]/1e9:.2f} {by[k]/ms[k]/1e6:.1f}\n")
-    if world > 1:
+    if use_pg:
         dist.destroy_process_group()
+    if not devices_ok:
+        sys.stderr.write(f"bench.py: {world} ranks drove only {distinct} distinct GPU(s) over backend {backend}: not a {world}-GPU measurement\n")
+        sys.exit(4)
     if not parity_ok:
         sys.stderr.write(f"bench.py: PARITY FAILED: max-abs vs the CPU oracle {allm[:, 2].tolist()} (bound {PARITY_BOUND})\n")
         sys.exit(3)
+
+
+def streaming_b1_line(device, H, W, T=24):
+    """One sequence of T frames HxW through cdfo_amd.streaming.StreamingSR (B = 1, feature cache, noise drawn per frame):
+    frames/s = T / summed per-frame forward time, as test_LD_22_FPS.py:192 computes it (here with device syncs)."""
+    import numpy as np
+    from arch.SIDECVSR_our import CVSR_V8
+    from cdfo_amd.streaming import StreamingSR
+    rs = np.random.RandomState(0)
+    u8 = lambda: rs.randint(0, 256, size=(T, H, W)).astype(np.uint8)  # noqa: E731
+    lr, pms, ufs = u8(), u8(), u8()
+    rms = np.clip(np.round(rs.randn(T, H, W) * 6), -128, 127).astype(np.float32)
+    mv = rs.randint(-64, 64, size=(2, T, (H + 7) // 8, (W + 7) // 8, 3)).astype(np.float32)
+    mv[..., 2] = rs.choice([-2.0, -1.0, 1.0], size=mv.shape[:-1])
+    mv = np.repeat(np.repeat(mv, 8, axis=2), 8, axis=3)[:, :, :H, :W]
+    torch.manual_seed(0)
+    model = CVSR_V8().to(device).eval()
+    out = {}
+    for key, use_graph in (("eager", False), ("hip_graph", True)):
+        s = StreamingSR(model, lr, pms, rms, ufs, mv[0], mv[1], use_graph=use_graph)
+        s.run()                               # warm-up: weight packing, first-touch allocations, graph capture
+        s.run()
+        out[key] = {"frames_per_s": round(s.fps, 2), "ms_per_frame": round(1e3 * s.seconds / T, 3)}
+        del s
+    del model
+    torch.cuda.empty_cache()
+    return {"workload": f"one sequence of {T} frames {H}x{W} -> {4 * H}x{4 * W}, B = 1, one new frame per forward with the feature "
+                        "cache (test_LD_22_FPS.py:183-192), random init, synthetic priors; frames / summed synced forward time",
+            **out}
+
+
+def train_step_line(device, B=20, H=64, W=64, iters=3):
+    """The training script's step (train_LD_37.py:376-381: 20 crops of 64x64, Charbonnier loss) through the HIP autograd path."""
+    from arch.SIDECVSR_our import CVSR_V8
+    from oracle.cvsr_v8_ref import make_inputs
+    torch.manual_seed(0)
+    m = CVSR_V8().to(device).train()
+    inp = make_inputs(B, H, W, 7)
+    d = {k: v.to(device) for k, v in inp.items() if k != "gumbel_u"}
+    hr = torch.rand(B, 1, 4 * H, 4 * W, device=device)
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+    fw, bw = [], []
+    for it in range(iters + 1):
+        m.zero_grad(set_to_none=True)
+        ev[0].record()
+        out, _ = m(d["x"], d["mvs0"], d["mvs1"], d["pms"], d["rms"], d["ufs"])
+        loss = torch.sum(torch.sqrt((out - hr) ** 2 + 1e-4))
+        ev[1].record()
+        loss.backward()
+        ev[2].record()
+        torch.cuda.synchronize()
+        if it:
+            fw.append(ev[0].elapsed_time(ev[1]))
+            bw.append(ev[1].elapsed_time(ev[2]))
+    from cdfo_amd import autograd as A
+    res = {"workload": f"CVSR_V8 training step, {B} crops of 7x1x{H}x{W}, Charbonnier loss, forward + backward through the HIP "
+                       "autograd path (no optimizer step), random init",
+           "forward_ms": round(min(fw), 2), "backward_ms": round(min(bw), 2), "step_ms": round(min(f + b for f, b in zip(fw, bw)), 2),
+           "conv_arithmetic": A.conv_precision_name()}
+    del m, d, hr
+    torch.cuda.empty_cache()
+    return res
 
 
 def cvsr_v7_line(device, d, H, W, B, steps=2):

@@ -2,7 +2,8 @@
 ``model(...)`` then ``loss.backward()``).
 
 Every operator that touches pixels is a ``torch.autograd.Function`` whose forward AND backward run in libcdfo_hip.so:
-the forward through the exact-fp32 entry points the inference path's ``precision="f32"`` mode uses, the backward through
+the forward through the entry points of the inference path's ``precision="f32"`` / ``"bf16x3"`` modes (which of the two the
+convolutions use: ``CONV_PREC`` below; everything that is not a convolution is exact fp32), the backward through
 the same entry points with adjoint operands (flipped / transposed weights, swapped roles) or the kernels of
 ``csrc/train_ops.hip``.  torch itself is used for what it is here for -- the autograd graph, device memory, views /
 permutes -- and for arithmetic on *parameter-sized or per-image* tensors only (weight flips, the 8x8 / 16x16 attention
@@ -23,13 +24,28 @@ from ._lib import check
 from .kernels import ACT_LRELU, ACT_NONE, ACT_RELU, ACT_SIGMOID, PackedConv, _stream, _vp
 
 F32 = K.PREC_F32
-# Arithmetic of the training path's convolutions (forward and input gradient; the weight gradient is a separate exact-fp32
-# kernel).  PREC_BF16X3 (default since round 3): 3x3 / stride 1 / pad 1 convolutions with Cin % 16 == 0 run on the split-bf16
-# three-pass MFMA kernel (fp32-grade: ~1e-6 relative per product; everything else stays exact fp32 -- kernels.conv falls back by
-# itself where the 16-bit packing does not exist); PREC_F32 (or CDFO_TRAIN_EXACT=1): the exact-fp32 MFMA everywhere, 1 / 16 of
-# the 16-bit matrix rate: 127 of the 419 ms of a training step at 20 x 64 x 64 were these convolutions.
+# Arithmetic of the training path's convolutions -- `CONV_PREC`, read at every call.
+#   PREC_BF16X3 (default since round 3): split-bf16 three-pass MFMA, fp32 accumulate (each operand is carried as bf16 hi + lo,
+#     ~16 significant bits; products are fp32-grade, ~1e-6 relative).  It applies to exactly three kernel families:
+#       (1) 3x3 / stride 1 / pad 1 convolutions with Cin % 16 == 0 -- forward AND input gradient (the adjoint is such a
+#           convolution) -- on the tiled 16-bit kernel (cdfo_conv3x3_bf16);
+#       (2) 1x1 convolutions whose sources are multiples of 64 channels and whose padded Cout is a multiple of 64 (<= 256):
+#           kernels.conv routes them to cdfo_conv1x1_bf16x3 (qkv, project_out, input_conv, fuse, fusion_out, down.0 / up.0,
+#           tsa_fusion, upconv1 / 2 -- forward and input gradient);
+#       (3) the weight gradient of 3x3 convolutions with both channel counts >= 16 (cdfo_conv_wgrad_prec, conv_wgrad below).
+#     Everything else -- stems, the 16-channel prior U-net, per-image attention applications (prec=F32 below), depthwise,
+#     LayerNorm, attention, warp, resampling, every bias / 1x1 / depthwise weight gradient -- is exact fp32.
+#     Gradient accuracy against the reference's own gradients: median 1e-5 - 4e-5 of max|g| per tensor, forward `out` <= 3e-5.
+#   PREC_F32 (CDFO_TRAIN_EXACT=1 in the environment, or `autograd.CONV_PREC = kernels.PREC_F32`): exact-fp32 MFMA everywhere
+#     (median 3e-7 - 1e-6, forward <= 1e-5), at 1/16 of the 16-bit matrix rate: 425 ms instead of 195 ms per step at 20 x 64 x 64.
+#   tests/test_gpu_train.py gates BOTH modes, each with its own tolerances.
 import os as _os
 CONV_PREC = K.PREC_F32 if _os.environ.get("CDFO_TRAIN_EXACT", "0") not in ("", "0") else K.PREC_BF16X3
+
+
+def conv_precision_name() -> str:
+    """What the training path's convolutions compute in right now (reported by bench.py's train_step line)."""
+    return "exact fp32 MFMA" if CONV_PREC == K.PREC_F32 else "split-bf16 3-pass MFMA, fp32 accumulate (fp32-grade products)"
 
 
 def _c(t: torch.Tensor) -> torch.Tensor:

@@ -9,7 +9,8 @@ Differences, all deliberate:
   * forward needs CUDA (ROCm) tensors: there is NO CPU fallback -- it raises ``NotImplementedError`` like the reference's
     own CUDA-only operator does (ops/dcn/deform_conv.py:136).  Under ``torch.no_grad()`` the fused inference schedule of
     this file runs; with gradients enabled (``train_LD_37.py:376-381``) the call goes to ``cvsr_v8_train.forward_train``:
-    the plain operator graph under torch autograd, exact-fp32 HIP kernels forward and backward.
+    the plain operator graph under torch autograd, HIP kernels forward and backward (convolutions as split-bf16 3-pass MFMA
+    products by default, exact fp32 with ``CDFO_TRAIN_EXACT=1``; everything else exact fp32: ``cdfo_amd/autograd.py``).
   * ``gumbel_uniform=`` (kwarg or attribute): the six uniform draws of ``LLongRangAttention.gumbel_softmax``
     (arch.py:2169) may be injected as six ``[B,64,H,W]`` tensors; by default they are drawn like the reference does
     (fresh uniforms per call, never 0), by a Philox4x32-10 generator inside the mask kernel, keyed per forward from
@@ -24,6 +25,8 @@ Differences, all deliberate:
     pixel-major buffer); feeding it back as ``pre_L1_fea`` needs no conversion.  Plain NCHW tensors are accepted too.
 """
 from __future__ import annotations
+
+import threading
 
 import contextlib
 import os
@@ -138,7 +141,7 @@ class CVSR_V8(nn.Module):
         #            256-channel intermediates also live in HBM as fp16; the returned feature cache stays split-bf16
         #            (2-4e-4 max-abs: inside the 1e-3 parity bound; default);
         #   "bf16"   plain bf16 MFMA with fp32 accumulation (BASELINE's bf16 configuration, ~6e-3: outside the bound).
-        self.precision = "fp16x2"
+        self._precision = "fp16x2"      # read through the `precision` property (a per-thread override serves the range guard's retry)
         # HIP side streams for the two independent neighbour groups (frames 0-2 and 4-6): 1 = everything on the caller's
         # stream, 0 = auto = 2 (one side stream per group)
         self.neighbour_streams = 0
@@ -528,26 +531,51 @@ class CVSR_V8(nn.Module):
                 y = self._conv(r, w[f"recon_trunk.body.{g}.conv"], pad=1, res1=y, res2=fused if g == 6 else None)
         return y
 
+    # -- arithmetic mode ---------------------------------------------------------------------------------------------
+    _tls = threading.local()
+
+    @property
+    def precision(self) -> str:
+        ov = getattr(CVSR_V8._tls, "override", None)
+        if ov is not None and ov[0] is self:
+            return ov[1]
+        return self._precision
+
+    @precision.setter
+    def precision(self, value: str):
+        if value not in self.PRECISIONS:
+            raise ValueError(f"precision must be one of {sorted(self.PRECISIONS)}, got {value!r}")
+        self._precision = value
+
+    def _resolve_noise(self, x, gumbel_uniform):
+        """The noise source of one inference forward and, if it is the in-kernel generator, its Philox key: an integer launch
+        argument for an eager forward; the DEVICE word of refresh_noise_key() for a forward that is being captured into a HIP
+        graph (a launch argument would freeze into the graph and every replay would draw the same uniforms; the reference draws
+        per call, arch.py:2169).  Shared by forward() and forward_front()."""
+        noise = gumbel_uniform if gumbel_uniform is not None else self.gumbel_uniform
+        if noise is None:
+            if torch.cuda.is_current_stream_capturing():
+                if self._noise_key is None or self._noise_key.device != x.device:
+                    raise RuntimeError("CVSR_V8 (HIP): call model.refresh_noise_key(device) before capturing a forward "
+                                       "that draws its own Gumbel noise")
+                self._noise_seed = self._noise_key
+            else:
+                self._noise_seed = K.next_noise_seed(x.device)
+        return noise
+
     # -- forward ---------------------------------------------------------------------------------------------------
     def forward(self, x, mvs0, mvs1, pms, rms, ufs, pre_L1_fea=None, gumbel_uniform=None):
         if not x.is_cuda:
             raise NotImplementedError("CVSR_V8 (HIP): CPU tensors are not supported; there is no CPU fallback")
         with K.on_device(x):     # the operands' device becomes the current one: streams, per-device caches of the library
-            noise = gumbel_uniform if gumbel_uniform is not None else self.gumbel_uniform
-            if noise is None:
-                if torch.cuda.is_current_stream_capturing():
-                    # a captured forward must not freeze its Philox key into the graph: the mask kernels read it from device
-                    # memory, and the owner of the graph calls refresh_noise_key() before every replay (arch.py:2169 draws
-                    # fresh uniforms per forward)
-                    if self._noise_key is None or self._noise_key.device != x.device:
-                        raise RuntimeError("CVSR_V8 (HIP): call model.refresh_noise_key(device) before capturing a forward "
-                                           "that draws its own Gumbel noise")
-                    self._noise_seed = self._noise_key
-                else:
-                    self._noise_seed = K.next_noise_seed(x.device)
-            if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
-                # training call (train_LD_37.py:376-381): the operator graph under autograd, exact-fp32 HIP kernels in both
-                # directions (cdfo_amd/cvsr_v8_train.py); the fused inference schedule below is forward-only
+            training = torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
+            if training and torch.cuda.is_current_stream_capturing():
+                raise RuntimeError("CVSR_V8 (HIP): the autograd path cannot be captured into a HIP graph (its mask kernel takes the "
+                                   "Philox key as a launch argument); capture inference forwards under torch.no_grad()")
+            noise = self._resolve_noise(x, gumbel_uniform)
+            if training:
+                # training call (train_LD_37.py:376-381): the operator graph under autograd, HIP kernels in both directions
+                # (cdfo_amd/cvsr_v8_train.py; convolution arithmetic = autograd.CONV_PREC); the fused schedule below is forward-only
                 if pre_L1_fea is not None:
                     raise NotImplementedError("CVSR_V8 (HIP): the cached-feature path is an inference path; training uses fresh clips")
                 for prm in self.parameters():
@@ -577,11 +605,13 @@ class CVSR_V8(nn.Module):
                               "precision='bf16x3'.  Set model.precision = 'bf16x3' to avoid the repeated work.")
                 self._warned_range = True
             self.last_range["fallback"] = True
-            self.precision = "bf16x3"
+            # the retry's mode is an override visible to THIS thread only: another thread / stream sharing the module keeps
+            # reading the attribute the user set
+            CVSR_V8._tls.override = (self, "bf16x3")
             try:
                 return self._forward(x, mvs0, mvs1, pms, rms, ufs, pre_L1_fea, noise)
             finally:
-                self.precision = "fp16x2"
+                CVSR_V8._tls.override = None
 
     FP16_WINDOW = (2.0 ** -6, 2.0 ** 11)
 
@@ -596,9 +626,7 @@ class CVSR_V8(nn.Module):
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
             raise NotImplementedError("CVSR_V8 (HIP): forward_front / forward_back are inference calls -- wrap them in torch.no_grad()")
         with K.on_device(x):
-            noise = gumbel_uniform if gumbel_uniform is not None else self.gumbel_uniform
-            if noise is None:
-                self._noise_seed = K.next_noise_seed(x.device)
+            noise = self._resolve_noise(x, gumbel_uniform)
             self._probe = None
             fused, L1, xf = self._front(x, mvs0, mvs1, pms, rms, ufs, pre_L1_fea, noise)
         return (fused, xf), L1.permute(0, 3, 1, 2)
@@ -609,6 +637,14 @@ class CVSR_V8(nn.Module):
         with K.on_device(fused):
             self._probe = None
             return self._back(fused, xf)
+
+    def capture(self, x, mvs0, mvs1, pms, rms, ufs, pre_L1_fea=None, gumbel_uniform=None, check_range: bool = True):
+        """Capture one inference forward at these operands' shapes into a HIP graph (opt-in; fixed shapes).  Returns a
+        ``cdfo_amd.graph.CapturedForward``: ``cap(x, mvs0, ...)`` copies the operands into the graph's input buffers, refreshes
+        the device-side Philox key (fresh Gumbel noise per replay, arch.py:2169) and replays; it returns graph-owned
+        ``(out, L1_fea)`` buffers that the next replay overwrites.  Same launches as the eager path: bit-identical outputs."""
+        from .graph import CapturedForward
+        return CapturedForward(self, x, mvs0, mvs1, pms, rms, ufs, pre_L1_fea, gumbel_uniform, check_range)
 
     def refresh_noise_key(self, device=None) -> int:
         """Write a fresh Philox key (advancing torch's default generator like an eager forward does) into the device word that

@@ -1,8 +1,10 @@
 """Training-mode forward of ``CVSR_V8`` (arch/SIDECVSR_our.py:4406-4481) under torch autograd.
 
 ``CVSR_V8.forward`` dispatches here whenever gradients are enabled and a parameter requires them (train_LD_37.py:376-381:
-``sr, _ = model(...)``; ``loss.backward()``).  The computation is the reference's, operator by operator, in exact-fp32
-arithmetic (the forward kernels of the ``precision="f32"`` inference mode: <= 1e-6 against the reference), composed from the
+``sr, _ = model(...)``; ``loss.backward()``).  The computation is the reference's, operator by operator; its convolutions run in
+``cdfo_amd.autograd.CONV_PREC`` -- split-bf16 three-pass MFMA products by default (forward <= 3e-5 against the reference), exact
+fp32 with ``CDFO_TRAIN_EXACT=1`` (the kernels of the ``precision="f32"`` inference mode: <= 1e-5) -- and everything else in exact
+fp32 (which kernel families the switch reaches is listed next to ``CONV_PREC``), composed from the
 ``torch.autograd.Function`` objects of ``cdfo_amd/autograd.py`` -- HIP kernels in both directions, no CPU or ATen fallback
 for anything pixel-sized.  The inference path's algebraic fusions (folded attention weights, composed stride-2 convolution,
 fp16 tensors) are not used here: gradients are taken of the plain operator graph.

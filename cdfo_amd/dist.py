@@ -21,7 +21,7 @@ def shard_range(n_items: int, rank: int, world: int) -> Tuple[int, int]:
 def gather_metrics(values: Sequence[float], device=None) -> torch.Tensor:
     """all_gather a short vector of float64 metrics; returns [world, len(values)] on the CPU (on every rank)."""
     mine = torch.tensor(list(values), dtype=torch.float64, device=device)
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    if dist.is_available() and dist.is_initialized():        # also at world size 1: the collective then runs over the real backend
         out: List[torch.Tensor] = [torch.empty_like(mine) for _ in range(dist.get_world_size())]
         dist.all_gather(out, mine)
         return torch.stack(out).cpu()

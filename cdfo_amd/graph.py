@@ -1,0 +1,94 @@
+"""Whole-forward HIP graphs for fixed shapes: ``CVSR_V8.capture(...)`` -> :class:`CapturedForward`.
+
+One inference forward is ~270 kernel launches at eight clips and ~700 at one clip (three HIP streams); at small shapes the
+inter-kernel gaps and the host-side launch cost are a visible share of the step (c2: 15.1 ms for ~270 launches).  A captured
+forward replays the same launches, on the same streams' fork / join structure, from one ``hipGraphLaunch``.
+
+What makes a capture of THIS model correct (the pieces were built for ``StreamingSR`` in round 3):
+
+* the Gumbel noise of ``LLongRangAttention`` is drawn per call in the reference (arch/SIDECVSR_our.py:2169).  A captured mask
+  kernel therefore reads its Philox key from a device word (``cdfo_rdab_prep_rng_dev``) that ``refresh_noise_key`` rewrites
+  before every replay -- torch's default generator advances once per forward exactly as in the eager loop, so a run under
+  ``torch.manual_seed`` produces the same frames eagerly and from the graph;
+* the fp16 range guard is a host readback and cannot live inside a graph: ``capture`` runs ONE eager, guarded forward on the
+  example inputs first and refuses to capture a workload whose activations leave the fp16 window (use ``precision="bf16x3"``);
+* the caller sees graph-owned buffers: ``inputs`` (write the next batch there, or pass tensors to ``__call__`` and they are
+  copied in) and the returned ``(out, L1_fea)``, which the NEXT replay overwrites -- ``clone()`` what must outlive it.
+"""
+from __future__ import annotations
+
+from typing import List, Optional, Sequence
+
+import torch
+
+
+class CapturedForward:
+    """A HIP graph of ``model(x, mvs0, mvs1, pms, rms, ufs, pre_L1_fea, gumbel_uniform=...)`` at the example's shapes."""
+
+    def __init__(self, model, x, mvs0, mvs1, pms, rms, ufs, pre_L1_fea=None, gumbel_uniform: Optional[Sequence] = None,
+                 check_range: bool = True):
+        if not x.is_cuda:
+            raise NotImplementedError("CapturedForward (HIP): CUDA tensors expected")
+        # Graphs are an inference tool: warm-up, capture and every replay are the torch.no_grad() schedule whatever the
+        # caller's grad mode is (the autograd path cannot be captured -- CVSR_V8.forward says why).
+        self.model, self.dev = model, x.device
+        self.draws_noise = gumbel_uniform is None and getattr(model, "gumbel_uniform", None) is None
+        fixed = [x, mvs0, mvs1, pms, rms, ufs]
+        self._nnoise = 0 if gumbel_uniform is None else len(gumbel_uniform)
+        ins: List[Optional[torch.Tensor]] = [None if t is None else t.clone() for t in fixed]
+        ins.append(None if pre_L1_fea is None else pre_L1_fea.contiguous().clone())
+        ins += [] if gumbel_uniform is None else [u.clone() for u in gumbel_uniform]
+        self.inputs = ins
+
+        def call(guard: bool):
+            old = getattr(model, "range_guard", False)
+            model.range_guard = guard
+            try:
+                return model(ins[0], ins[1], ins[2], ins[3], ins[4], ins[5], ins[6],
+                             gumbel_uniform=None if self._nnoise == 0 else ins[7:])
+            finally:
+                model.range_guard = old
+
+        # Warm-up and capture must not consume the generator: replay k then draws the key the k-th eager forward would have
+        rng_state = torch.cuda.get_rng_state(self.dev)
+        cur = torch.cuda.current_stream(self.dev)
+        side = torch.cuda.Stream(self.dev)
+        side.wait_stream(cur)
+        model.last_range = None
+        with torch.cuda.stream(side), torch.no_grad():          # warm-up on a side stream, as graph capture requires
+            call(guard=check_range)
+            if check_range and (getattr(model, "last_range", None) or {}).get("fallback"):
+                raise RuntimeError("CapturedForward: the example's activations leave the fp16 range (the eager forward fell back to "
+                                   "bf16x3); a captured forward has no range guard -- set model.precision = 'bf16x3' and capture again")
+        cur.wait_stream(side)
+        if self.draws_noise:
+            model.refresh_noise_key(self.dev)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph), torch.no_grad():
+            self.out, self.L1_fea = call(guard=False)
+        torch.cuda.set_rng_state(rng_state, self.dev)
+
+    def load(self, x=None, mvs0=None, mvs1=None, pms=None, rms=None, ufs=None, pre_L1_fea=None, gumbel_uniform=None) -> None:
+        """Copy new operands into the graph's input buffers (None = keep what is there; tensors that ARE the buffers are skipped)."""
+        new = [x, mvs0, mvs1, pms, rms, ufs, pre_L1_fea] + ([None] * self._nnoise if gumbel_uniform is None else list(gumbel_uniform))
+        if len(new) != len(self.inputs):
+            raise ValueError(f"captured with {self._nnoise} noise tensors, got {len(new) - 7}")
+        for dst, src in zip(self.inputs, new):
+            if src is None or src is dst:
+                continue
+            if dst is None:
+                raise ValueError("an operand that was None at capture time cannot be supplied at replay")
+            if tuple(src.shape) != tuple(dst.shape):
+                raise ValueError(f"captured for shape {tuple(dst.shape)}, got {tuple(src.shape)}")
+            dst.copy_(src)
+
+    def replay(self):
+        """One forward on whatever the input buffers hold.  Returns the graph-owned (out, L1_fea)."""
+        if self.draws_noise:
+            self.model.refresh_noise_key(self.dev)
+        self.graph.replay()
+        return self.out, self.L1_fea
+
+    def __call__(self, x=None, mvs0=None, mvs1=None, pms=None, rms=None, ufs=None, pre_L1_fea=None, gumbel_uniform=None):
+        self.load(x, mvs0, mvs1, pms, rms, ufs, pre_L1_fea, gumbel_uniform)
+        return self.replay()

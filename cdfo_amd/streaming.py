@@ -92,7 +92,6 @@ class StreamingSR:
         # microseconds each at one clip) is captured once into a HIP graph and replayed from static buffers
         self.use_graph = use_graph
         self._graph = None
-        self._static = None
 
     def _mvs(self, mvl: torch.Tensor, i: int) -> torch.Tensor:
         m = torch.zeros((NFRAMES, 2, self.Hp, self.Wp), dtype=torch.float32, device=self.dev)
@@ -120,47 +119,18 @@ class StreamingSR:
         return out[..., :4 * self.H, :4 * self.W]
 
     def _graph_step(self, x, m0, m1, p, r, u, noise):
-        ins = [x, m0, m1, p, r, u, self.fea.contiguous()] + ([] if noise is None else list(noise))
+        """Frames >= 1 from a HIP graph of the cached-path forward (cdfo_amd.graph.CapturedForward: device-side Philox key
+        refreshed per replay, no range guard inside the graph -- the eager first frame of the sequence ran with it)."""
+        fea = self.fea.contiguous()
         if self._graph is None:
-            st = [t.clone() for t in ins]
-            # no host synchronisation may happen inside a captured forward: the fp16 range guard (a readback) is off for the
-            # captured step (the eager first frame of the sequence ran with it).  With noise=None the mask kernels read their
-            # Philox key from a device word that is rewritten before every replay (model.refresh_noise_key), so each frame draws
-            # fresh uniforms like the reference's per-call torch.rand_like (arch.py:2169).
-            def call():
-                guard = getattr(self.model, "range_guard", False)
-                self.model.range_guard = False
-                try:
-                    return self.model(st[0], st[1], st[2], st[3], st[4], st[5], st[6],
-                                      gumbel_uniform=None if noise is None else st[7:])
-                finally:
-                    self.model.range_guard = guard
-            # the warm-up and capture runs below must not consume the generator: frame i's key is then the same whether the
-            # loop runs eagerly or from the graph (one advance per frame, by refresh_noise_key before the replay)
-            rng_state = torch.cuda.get_rng_state(self.dev)
-            side = torch.cuda.Stream(self.dev)
-            side.wait_stream(torch.cuda.current_stream(self.dev))
-            with torch.cuda.stream(side), torch.no_grad():          # warm-up on a side stream, as graph capture requires
-                call()
-            torch.cuda.current_stream(self.dev).wait_stream(side)
-            if noise is None:
-                self.model.refresh_noise_key(self.dev)
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g), torch.no_grad():
-                out, fea = call()
-            self._graph, self._static = g, (st, out, fea)
-            torch.cuda.set_rng_state(rng_state, self.dev)
-        st, out, fea = self._static
+            from .graph import CapturedForward
+            self._graph = CapturedForward(self.model, x, m0, m1, p, r, u, fea, noise, check_range=False)
         torch.cuda.synchronize(self.dev)
         t0 = time.perf_counter()
-        for dst, src in zip(st, ins):
-            dst.copy_(src)
-        if noise is None:
-            self.model.refresh_noise_key(self.dev)
-        self._graph.replay()
+        out, new_fea = self._graph(x, m0, m1, p, r, u, fea, noise)
         torch.cuda.synchronize(self.dev)
         self.seconds += time.perf_counter() - t0
-        self.fea = fea.clone()                                       # the static output buffer is overwritten next step
+        self.fea = new_fea.clone()                                   # the graph's output buffers are overwritten next step
         return out[..., :4 * self.H, :4 * self.W].clone()
 
     def _inputs(self, i: int):

@@ -13,9 +13,11 @@ def pytest_configure(config):
     # On a GPU box: start multiprocessing's fork server NOW, while this process has not touched the GPU.  Tests that must start
     # another GPU program (bench.py's multi-rank launcher) ask the server for a child: that child is forked from a GPU-free
     # process, so no process that has initialised the GPU ever forks or execs (see clean_process_run below).
+    # The test is "is there a GPU device node", not a torch.cuda call: on ROCm without amdsmi torch.cuda.device_count() falls
+    # through to hipGetDeviceCount, which initialises the runtime -- the fork server would then be started by a process that
+    # already holds the GPU.
     try:
-        import torch
-        if torch.cuda.device_count() > 0:
+        if os.path.exists("/dev/kfd") or os.environ.get("CDFO_FORKSERVER", "0") not in ("", "0"):
             import multiprocessing.forkserver as fs
             fs.ensure_running()
     except Exception:

@@ -25,7 +25,11 @@ def test_args_plumbing():
     a = bench.parse_args(["--gpus", "2", "--steps", "5", "--warmup", "1", "--batch", "4"])
     assert (a.gpus, a.steps, a.warmup, a.batch) == (2, 5, 1, 4)
     d = bench.parse_args([])
-    assert d.gpus == 1 and d.precision == "fp16x2" and not d.injected_noise
+    assert d.gpus == 1 and d.precision == "fp16x2" and not d.injected_noise and not d.process_group
+    assert bench.parse_args(["--process-group"]).process_group
+    # the driver reads these keys from the default line: they must be wired into main()
+    src = open(bench.__file__).read()
+    assert 'res["streaming_b1"] = streaming_b1_line(' in src and 'res["train_step"] = train_step_line(' in src
 
 
 def test_bare_multi_gpu_invocation_becomes_the_launcher(monkeypatch):

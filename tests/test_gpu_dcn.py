@@ -457,7 +457,7 @@ def test_dcn_fast_path_full_size_matches_exact_kernel_and_is_reproducible():
     against the exact-fp32 kernel of the same library (which the cases above tie to the C oracle) and against itself run
     to run.  (Round 2 found a build whose fast kernel was right at every small test shape and wrong in ~3 % of the tiles
     here: the full-size case is the one that can see such a thing.)"""
-    from cdfo_amd import deform_conv_cuda as ext
+    from cdfo_amd import dcn as ext
     from cdfo_amd.dcn import modulated_deform_conv
     B, C, Co, H, W, dg = 2, 64, 64, 272, 480, 16
     g = torch.Generator(device="cuda").manual_seed(3)

@@ -1,0 +1,92 @@
+"""`CVSR_V8.capture` (cdfo_amd/graph.py): a whole inference forward replayed from a HIP graph is the eager forward --
+same launches, bit-identical outputs -- with fresh Gumbel noise per replay (arch/SIDECVSR_our.py:2169 draws per call),
+reproducible under torch.manual_seed, for the fresh and the cached-feature path."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _model(wseed=21):
+    from arch.SIDECVSR_our import CVSR_V8
+    from oracle.cvsr_v8_ref import make_state_dict
+    m = CVSR_V8()
+    m.load_state_dict(make_state_dict(wseed), strict=True)
+    return m.cuda().eval()
+
+
+def _inputs(B, H, W, seed):
+    from oracle.cvsr_v8_ref import make_inputs
+    a = make_inputs(B, H, W, seed)
+    return {k: v.cuda() for k, v in a.items() if k != "gumbel_u"}, [u.cuda() for u in a["gumbel_u"]]
+
+
+@pytest.mark.parametrize("B,H,W", [(2, 24, 40), (4, 32, 48)])
+def test_replay_with_injected_noise_is_bit_identical_to_eager(B, H, W):
+    m = _model()
+    d0, n0 = _inputs(B, H, W, 500)
+    d1, n1 = _inputs(B, H, W, 501)
+    with torch.no_grad():
+        cap = m.capture(d0["x"], d0["mvs0"], d0["mvs1"], d0["pms"], d0["rms"], d0["ufs"], gumbel_uniform=n0)
+        for d, n in ((d0, n0), (d1, n1), (d0, n0)):
+            want, want_l1 = m(d["x"], d["mvs0"], d["mvs1"], d["pms"], d["rms"], d["ufs"], gumbel_uniform=n)
+            got, got_l1 = cap(d["x"], d["mvs0"], d["mvs1"], d["pms"], d["rms"], d["ufs"], gumbel_uniform=n)
+            torch.cuda.synchronize()
+            assert torch.equal(got, want) and torch.equal(got_l1, want_l1)
+    assert got.shape == (B, 1, 4 * H, 4 * W) and got_l1.shape == (B * 7, 64, H, W)
+
+
+def test_replays_draw_fresh_noise_and_follow_the_generator_like_the_eager_path():
+    m = _model(22)
+    d, _ = _inputs(2, 16, 24, 510)
+    args = (d["x"], d["mvs0"], d["mvs1"], d["pms"], d["rms"], d["ufs"])
+    with torch.no_grad():
+        torch.manual_seed(77)
+        eager = [m(*args)[0].clone() for _ in range(3)]
+        torch.manual_seed(123)                      # capture itself must not disturb the generator's sequence
+        cap = m.capture(*args)
+        torch.manual_seed(77)
+        replayed = [cap(*args)[0].clone() for _ in range(3)]
+    torch.cuda.synchronize()
+    for e, r in zip(eager, replayed):
+        assert torch.equal(e, r)
+    assert not torch.equal(replayed[0], replayed[1])        # per-replay noise (the key is a device word, not a frozen argument)
+
+
+def test_cached_feature_path_and_input_buffers():
+    m = _model(23)
+    d0, n0 = _inputs(1, 16, 16, 520)
+    d1, n1 = _inputs(1, 16, 16, 521)
+    with torch.no_grad():
+        _, fea = m(d0["x"], None, d0["mvs1"], d0["pms"], d0["rms"], d0["ufs"], gumbel_uniform=n0)
+        want, want_l1 = m(d1["x"], None, d1["mvs1"], d1["pms"], d1["rms"], d1["ufs"], fea, gumbel_uniform=n1)
+        cap = m.capture(d0["x"], None, d0["mvs1"], d0["pms"], d0["rms"], d0["ufs"], fea, gumbel_uniform=n0)
+        # write the next frame's operands straight into the graph's buffers, then replay without arguments
+        for dst, src in zip(cap.inputs, [d1["x"], None, d1["mvs1"], d1["pms"], d1["rms"], d1["ufs"], fea, *n1]):
+            if dst is not None:
+                dst.copy_(src)
+        got, got_l1 = cap.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(got, want) and torch.equal(got_l1, want_l1)
+    with pytest.raises(ValueError):
+        cap(torch.zeros(1, 7, 1, 24, 16, device="cuda"))
+
+
+def test_capture_is_the_inference_schedule_and_refuses_out_of_range_examples():
+    m = _model(24)
+    d, n = _inputs(1, 16, 16, 530)
+    args = (d["x"], None, d["mvs1"], d["pms"], d["rms"], d["ufs"])
+    cap = m.capture(*args, gumbel_uniform=n)               # grad mode on, parameters require grad: still the no_grad schedule
+    out, _ = cap.replay()
+    assert not out.requires_grad
+    with torch.no_grad():
+        want, _ = m(*args, gumbel_uniform=n)
+    assert torch.equal(out, want)
+    m.FP16_WINDOW = (1e-30, 1e-29)                          # every workload now "leaves the fp16 range": the eager forward falls back
+    with pytest.warns(UserWarning), pytest.raises(RuntimeError):
+        m.capture(*args, gumbel_uniform=n)
+    m.precision = "bf16x3"                                  # ... and the advice of the error message works
+    cap = m.capture(*args, gumbel_uniform=n)
+    with torch.no_grad():
+        want, _ = m(*args, gumbel_uniform=n)
+    assert torch.equal(cap.replay()[0], want)

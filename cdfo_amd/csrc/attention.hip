@@ -272,6 +272,26 @@ __global__ __launch_bounds__(64) void seq_attn_kernel(const float* __restrict__ 
 //                     8-byte runs of 4 keys; no data movement between the two products.
 typedef _Float16 attn_f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 attn_f16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned attn_u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned attn_u32x4 __attribute__((ext_vector_type(4)));
+
+// Two fp32 values -> packed fp16 hi (round to nearest) and packed fp16 lo = fp16(v - hi), four instructions per pair:
+// v_cvt_pk_f16_f32, two v_fma_mix_f32 (f32 * 1.0 - f16 -> f32: the exact remainder, the fp16 operand read straight from its
+// half of the packed register), v_cvt_pk_f16_f32.  hipcc emits cvt_f32_f16 + sub per element for the plain C expression (six
+// per pair) and folds a source-level fma back into it; the kernel is bound by its vector instructions, so
+// the form is spelled out.  Full-register results only: the three-instruction form through v_fma_mixlo_f16 / v_fma_mixhi_f16
+// writes half registers, and gfx950 needs a wait state between such a write and the next vector read of the register, which
+// hipcc cannot insert around inline assembly (measured: wrong window-attention results where the consumer followed directly).
+__device__ __forceinline__ void split_pair_f16(float a, float b, unsigned& hi, unsigned& lo) {
+  typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+  const h2 hv = {(_Float16)a, (_Float16)b};
+  hi = __builtin_bit_cast(unsigned, hv);
+  float ra, rb;
+  asm("v_fma_mix_f32 %0, %1, 1.0, -%2 op_sel_hi:[0,0,1]" : "=v"(ra) : "v"(a), "v"(hi));
+  asm("v_fma_mix_f32 %0, %1, 1.0, -%2 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "=v"(rb) : "v"(b), "v"(hi));
+  const h2 lv = {(_Float16)ra, (_Float16)rb};
+  lo = __builtin_bit_cast(unsigned, lv);
+}
 
 // NW waves per workgroup = 32*NW queries of one sequence at most; a stage is 8*NW keys (NW/4 sub-tiles of 32), staged by
 // all NW*64 threads with one 4-key x 4-channel unit each -- the larger the workgroup, the less staging work (loads,
@@ -362,21 +382,23 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 3 : 2) void seq_attn_mfma_kernel
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const int ch = 4 * sc4 + e, swz = (ch >> 1) & 7;
-        attn_f16x4 vh, vl;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) { vh[k] = (_Float16)rs[k][e]; vl[k] = (_Float16)(rs[k][e] - (float)vh[k]); }
-        *reinterpret_cast<attn_f16x4*>(vb + ch * 128 + ((c ^ swz) * 16)) = vh;
-        *reinterpret_cast<attn_f16x4*>(vb + ch * 128 + (((4 + c) ^ swz) * 16)) = vl;
+        unsigned h0, l0, h1, l1;                            // keys 4m .. 4m+3 of channel ch
+        split_pair_f16(rs[0][e], rs[1][e], h0, l0);
+        split_pair_f16(rs[2][e], rs[3][e], h1, l1);
+        const attn_u32x2 vh = {h0, h1}, vl = {l0, l1};
+        *reinterpret_cast<attn_u32x2*>(vb + ch * 128 + ((c ^ swz) * 16)) = vh;
+        *reinterpret_cast<attn_u32x2*>(vb + ch * 128 + (((4 + c) ^ swz) * 16)) = vl;
       }
     } else {
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
-        attn_f16x4 kh, kl;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) { kh[e] = (_Float16)rs[s][e]; kl[e] = (_Float16)(rs[s][e] - (float)kh[e]); }
+        unsigned h0, l0, h1, l1;
+        split_pair_f16(rs[s][0], rs[s][1], h0, l0);
+        split_pair_f16(rs[s][2], rs[s][3], h1, l1);
+        const attn_u32x2 kh = {h0, h1}, kl = {l0, l1};
         unsigned char* row = sK + buf * K_BYTES + (sm + KQ * s) * KROW + sc4 * 8;
-        *reinterpret_cast<attn_f16x4*>(row) = kh;
-        *reinterpret_cast<attn_f16x4*>(row + 128) = kl;
+        *reinterpret_cast<attn_u32x2*>(row) = kh;
+        *reinterpret_cast<attn_u32x2*>(row + 128) = kl;
       }
     }
   };
@@ -449,9 +471,11 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 3 : 2) void seq_attn_mfma_kernel
         const unsigned char* const vb = sV + buf * V_BYTES + sub * 8192;
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
-          attn_f16x8 ph, pl;
+          unsigned hh[4], ll[4];
 #pragma unroll
-          for (int j = 0; j < 8; ++j) { ph[j] = (_Float16)sacc[sub][8 * u + j]; pl[j] = (_Float16)(sacc[sub][8 * u + j] - (float)ph[j]); }
+          for (int j = 0; j < 4; ++j) split_pair_f16(sacc[sub][8 * u + 2 * j], sacc[sub][8 * u + 2 * j + 1], hh[j], ll[j]);
+          const attn_u32x4 phu = {hh[0], hh[1], hh[2], hh[3]}, plu = {ll[0], ll[1], ll[2], ll[3]};
+          const attn_f16x8 ph = __builtin_bit_cast(attn_f16x8, phu), pl = __builtin_bit_cast(attn_f16x8, plu);
 #pragma unroll
           for (int half = 0; half < 2; ++half) {            // channels 0-31 -> o0, 32-63 -> o1
             const int ch = 32 * half + r, swz = (ch >> 1) & 7, c = 2 * u + h;

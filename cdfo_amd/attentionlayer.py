@@ -1,13 +1,16 @@
 """``DSTA`` -- the deformable spatial attention gate of the reference (ops/attentionlayer.py:86-156; the class is defined
 twice there, byte-identically), with the same constructor, parameter names and ``forward(x) -> x * m * y``.
 Every operator runs in libcdfo_hip.so: the thin 16-channel convs / pooling / resizing through the NCHW helpers of
-csrc/nchw_ops.hip, the DCNv2 through the fused ``cdfo_dcn_forward`` (no CPU fallback; forward only)."""
+csrc/nchw_ops.hip, the DCNv2 through the fused ``cdfo_dcn_forward`` (no CPU fallback).  With gradients enabled the same
+operator graph runs as ``torch.autograd.Function``s (``cdfo_amd/nchw_autograd.py``: the gather kernels of csrc/nchw_bwd.hip,
+``cdfo_dcn_backward`` for the deformable convolution), so the module trains like the reference's."""
 from __future__ import annotations
 
 import torch
 import torch.nn as nn
 
 from . import nchw as N
+from . import nchw_autograd as G
 from .dcn import ModulatedDeformConv
 from .kernels import ACT_NONE, ACT_RELU, ACT_SIGMOID, on_device
 
@@ -41,10 +44,33 @@ class DSTA(nn.Module):
     def forward(self, x):
         if not x.is_cuda:
             raise NotImplementedError("DSTA (HIP): CPU tensors are not supported")
-        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
-            raise NotImplementedError("DSTA (HIP): forward only -- wrap the call in torch.no_grad()")
         with on_device(x):
+            if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
+                return self._forward_train(x)
             return self._forward(x)
+
+    def _forward_train(self, x):
+        """ops/attentionlayer.py:117-156 operator by operator under autograd (HIP kernels in both directions)."""
+        cv = lambda m, t, act=ACT_NONE: G.conv2d(t, m.weight, m.bias, m.stride[0], m.padding[0], act)  # noqa: E731
+        c1_ = cv(self.conv1, x)
+        c1 = cv(self.conv2, c1_)
+        v_max = G.maxpool(c1, 7, 3)
+        v_range = cv(self.conv_max, v_max, ACT_RELU)
+        c3 = cv(self.conv3, v_range, ACT_RELU)
+        c3 = cv(self.conv3_, c3, ACT_RELU)
+        dc3 = cv(self.down_conv2[0], c3, ACT_RELU)
+        off_mask2 = cv(self.mask2, dc3)
+        off_msk = cv(self.mask, c3)
+        off_msk = G.add(off_msk, G.resize_bilinear(off_mask2, off_msk.size(2), off_msk.size(3)))
+        k2 = self.f * 2 * 3 * 3
+        off, msk = off_msk[:, :k2], G.sigmoid(off_msk[:, k2:])
+        c3 = G.relu(self.dcn(v_max, off, msk))
+        y = G.plane_mean(c3)                                        # [B, f, 1, 1]: the gate MLP is parameter-sized torch arithmetic
+        y = torch.sigmoid(torch.nn.functional.conv2d(torch.relu(torch.nn.functional.conv2d(y, self.conv_du[0].weight, self.conv_du[0].bias)),
+                                                     self.conv_du[2].weight, self.conv_du[2].bias))
+        c3 = G.resize_bilinear(c3, x.size(2), x.size(3))
+        c4 = cv(self.conv4, G.add(c3, cv(self.conv_f, c1_)))
+        return G.gate(c4, x, y)
 
     def _forward(self, x):
         c1_ = self._c(self.conv1, x)

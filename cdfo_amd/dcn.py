@@ -223,7 +223,8 @@ class _DeformableConv(Function):
         for t in (x, offset, mask, weight, bias):
             if t is not None and not t.is_cuda:
                 raise NotImplementedError("deformable convolution (HIP): CPU tensors are not supported")
-        x, weight = x.contiguous(), weight.contiguous()
+        x, weight, offset = x.contiguous(), weight.contiguous(), offset.contiguous()
+        mask = None if mask is None else mask.contiguous()
         B, _, H, W = _check_shapes(x, offset, mask, weight, geo)[:4]
         out = x.new_empty((B, weight.shape[0], *geo.out_hw(H, W)))
         launch_forward(x, offset, mask, weight, bias, out, geo)

@@ -4,7 +4,10 @@ deformable_groups=16, max_residue_magnitude=10)``): same constructor, parameter 
 ``forward(x, extra_feat, pred_feat, flow_1)``; NCHW tensors in and out like the reference.  Everything runs in
 libcdfo_hip.so: MV warp, the shared 8-head channel attention folded into a per-image 64x64 matrix, the 64->64->432
 offset/mask head on the MFMA conv kernels, offset assembly (10*tanh + flipped MV) and the fused DCNv2
-(``torchvision.ops.deform_conv2d`` in the reference, arch.py:3352).  Forward only, no CPU fallback."""
+(``torchvision.ops.deform_conv2d`` in the reference, arch.py:3352).  No CPU fallback.  With gradients enabled the forward runs
+operator by operator as ``torch.autograd.Function``s (``forward_train``: the pixel-major Functions of ``cdfo_amd/autograd.py``,
+the layout / offset-assembly Functions of ``cdfo_amd/nchw_autograd.py`` and the DCN operator's own Function), so the module
+trains like the reference's; the folded inference schedule is used under ``torch.no_grad()``."""
 from __future__ import annotations
 
 import ctypes as C
@@ -59,14 +62,41 @@ class MVDualAttAlignment(ModulatedDeformConvPack):
     def forward(self, x, extra_feat, pred_feat, flow_1):
         if not x.is_cuda:
             raise NotImplementedError("MVDualAttAlignment (HIP): CPU tensors are not supported")
-        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
-            raise NotImplementedError("MVDualAttAlignment (HIP): forward only -- wrap the call in torch.no_grad()")
         if self.in_channels != 64 or self.out_channels != 64:
             raise NotImplementedError("MVDualAttAlignment (HIP): specialised for 64 channels (arch.py:4242)")
+        if torch.is_grad_enabled() and (any(t.requires_grad for t in (x, extra_feat, pred_feat))
+                                        or any(p.requires_grad for p in self.parameters())):
+            with K.on_device(x):
+                return self.forward_train(x, extra_feat, pred_feat, flow_1)
         x = x.contiguous().float()
         with K.on_device(x):
             return self.forward_pm(x, K.nchw_to_nhwc(x), K.nchw_to_nhwc(extra_feat.float()),
                                    K.nchw_to_nhwc(pred_feat.float()), flow_1.contiguous().float())
+
+    def forward_train(self, x, extra_feat, pred_feat, flow_1):
+        """arch.py:3303-3352 under autograd: NCHW tensors in and out; gradients reach x, extra_feat, pred_feat and every parameter
+        the reference's forward uses (the motion field is a network input).  Convolution arithmetic = autograd.CONV_PREC."""
+        import torch.nn.functional as F
+        from . import autograd as A
+        from . import nchw_autograd as G
+        from .dcn import modulated_deform_conv
+        x = x.float()
+        flow = flow_1.detach().contiguous().float()
+        B, _, H, W = x.shape
+        xq, extra, pred = G.to_pixel_major(x), G.to_pixel_major(extra_feat.float()), G.to_pixel_major(pred_feat.float())
+        warped = A.flow_warp(extra, flow, 2 * H * W)
+        fused = A.conv([warped, pred], self.fusion_out.weight)                     # no activation here (arch.py:3305)
+        w0, b0, w2, b2 = (self.conv_du[0].weight, self.conv_du[0].bias, self.conv_du[2].weight, self.conv_du[2].bias)
+        heads = []
+        for v in (warped, pred):
+            gate = torch.sigmoid(F.linear(F.relu(F.linear(A.chan_mean(v), w0.flatten(1), b0)), w2.flatten(1), b2))   # [B, 64]
+            att = A.channel_attention(xq, fused, A.scale_channels(v, gate), self.temperature, self.num_heads)
+            o = A.conv(att, self.project_out.weight)
+            o = A.conv(o, self.conv_offset[0].weight, self.conv_offset[0].bias, 1, 1, K.ACT_LRELU)
+            heads.append(A.conv(o, self.conv_offset[2].weight, self.conv_offset[2].bias, 1, 1))      # [B, H, W, 27 dg]
+        offset, mask = G.offset_mask(heads[0], heads[1], flow, 9 * self.deformable_groups, self.max_residue_magnitude)
+        return modulated_deform_conv(x, offset, mask, self.weight, self.bias, self.stride, self.padding, self.dilation,
+                                     self.groups, self.deformable_groups)
 
     def forward_pm(self, x, xq, extra, pred, flow):
         """The same computation for callers that already hold pixel-major tensors (``CVSR_V7``): ``x`` NCHW (the DCN's

@@ -403,6 +403,25 @@ int cdfo_ew_nchw(const float* a, const float* b, const float* x, const float* y,
 int cdfo_mv_offset_mask(const float* o1, const float* o2, int ld, const float* flow, long long flow_bstride, int B,
                         long long P, int third, float mag, float* offset, float* mask, void* stream);
 
+/* ---- backward of the same operators (nchw_bwd.hip): DSTA and MVDualAttAlignment under autograd, like their reference classes
+ * (ops/attentionlayer.py:117-156, arch/SIDECVSR_our.py:3303-3352).  Gather kernels, fixed summation order, no atomics.
+ * cdfo_conv2d_nchw_bwd: any of gin [B,C,H,W] (needs w), gw [Co,C,kh,kw] (+ optional gbias [Co]; needs in) may be NULL; all ASSIGNED.
+ * cdfo_maxpool_nchw_bwd: idx_scratch = BC*Ho*Wo ints (the windows' arg-max, first maximum in scan order).
+ * cdfo_ew_nchw_bwd modes: 1 g*(y>0) (y = relu output), 2 g*y*(1-y) (y = sigmoid output), 4 g[bc]/P (adjoint of the plane mean),
+ *   5 / 6: the DSTA gate out = x*sigmoid(a)*yv[bc] w.r.t. a / w.r.t. x; cdfo_gate_nchw_bwd_y: w.r.t. yv ([BC]).
+ * cdfo_mv_offset_mask_bwd: adjoint of cdfo_mv_offset_mask w.r.t. o1, o2 (g1, g2 pixel-major, pitch ld; the motion field is a
+ *   network input and receives no gradient). */
+int cdfo_conv2d_nchw_bwd(const float* in, const float* w, const float* gout, int B, int C, int H, int W, int Co, int kh, int kw,
+                         int stride, int pad, float* gin, float* gw, float* gbias, void* stream);
+int cdfo_maxpool_nchw_bwd(const float* in, const float* gout, int BC, int H, int W, int k, int stride, int* idx_scratch, float* gin,
+                          void* stream);
+int cdfo_resize_bilinear_nchw_bwd(const float* gout, int BC, int H, int W, int Ho, int Wo, float* gin, void* stream);
+int cdfo_ew_nchw_bwd(const float* g, const float* y, const float* a, const float* x, const float* yv, long long n, long long P,
+                     int mode, float* out, void* stream);
+int cdfo_gate_nchw_bwd_y(const float* g, const float* a, const float* x, int BC, long long P, float* gy, void* stream);
+int cdfo_mv_offset_mask_bwd(const float* o1, const float* o2, int ld, const float* goff, const float* gmask, int B, long long P,
+                            int third, float mag, float* g1, float* g2, void* stream);
+
 /* ---- optional per-launch HIP-event timing on the launch stream (bench.py's live roofline figures) ----------- */
 int cdfo_prof_begin(int max_records);
 int cdfo_prof_end(int* launches, double* ms, double* flops, double* bytes, int nkid);

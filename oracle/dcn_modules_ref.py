@@ -90,9 +90,34 @@ def dcn_backward_ref(x, offset, mask, weight, gout, stride=1, pad=0, dil=1, grou
     return g
 
 
+class _DcnRefFn(torch.autograd.Function):
+    """The C oracle's forward AND backward (oracle/dcn_ref.c: dcn_forward_ref / dcn_backward_ref, float or double build) as a
+    torch autograd node, so that torch autograd through the restated consumer modules is the gradient oracle of the HIP
+    training paths (tests/test_gpu_dcn_modules.py)."""
+
+    @staticmethod
+    def forward(ctx, x, offset, mask, weight, bias, stride, pad, dil, groups, dg):
+        dt = np.float64 if x.dtype == torch.float64 else np.float32
+        t = lambda a: None if a is None else a.detach().numpy()  # noqa: E731
+        ctx.meta = (stride, pad, dil, groups, dg, dt, bias is not None)
+        ctx.save_for_backward(x, offset, mask, weight)
+        return torch.from_numpy(dcn_forward_ref(t(x), t(offset), t(mask), t(weight), t(bias), stride, pad, dil, groups, dg, dtype=dt))
+
+    @staticmethod
+    def backward(ctx, g):
+        x, offset, mask, weight = ctx.saved_tensors
+        stride, pad, dil, groups, dg, dt, has_bias = ctx.meta
+        t = lambda a: None if a is None else a.detach().numpy()  # noqa: E731
+        r = dcn_backward_ref(t(x), t(offset), t(mask), t(weight), g.detach().contiguous().numpy(), stride, pad, dil, groups, dg,
+                             with_bias=has_bias, dtype=dt)
+        f = lambda k: torch.from_numpy(r[k]) if k in r else None  # noqa: E731
+        return f("grad_input"), f("grad_offset"), f("grad_mask"), f("grad_weight"), (f("grad_bias") if has_bias else None), None, None, None, None, None
+
+
 def dcn_torch(x, offset, mask, weight, bias, stride=1, pad=0, dil=1, groups=1, dg=1):
-    t = lambda a: None if a is None else a.detach().numpy()  # noqa: E731
-    return torch.from_numpy(dcn_forward_ref(t(x), t(offset), t(mask), t(weight), t(bias), stride, pad, dil, groups, dg))
+    """The C oracle on torch tensors (float32 or float64 by x.dtype); differentiable (see _DcnRefFn)."""
+    c = lambda a: None if a is None else a.contiguous()  # noqa: E731
+    return _DcnRefFn.apply(c(x), c(offset), c(mask), c(weight), c(bias), stride, pad, dil, groups, dg)
 
 
 def dsta_forward(sd, x):

@@ -32,3 +32,76 @@ def test_modules_reject_cpu():
     from ops.attentionlayer import DSTA
     with torch.no_grad(), pytest.raises(NotImplementedError):
         DSTA(64)(torch.zeros(1, 64, 40, 40))
+
+
+def _oracle_grads(kind, sd, inputs, cot, dtype):
+    """torch autograd through the oracle's restatement (its DCN step = the C oracle's forward / backward, oracle/dcn_ref.c)."""
+    from oracle.dcn_modules_ref import dsta_forward, mv_dual_att_alignment_forward
+    sdg = {k: v.to(dtype).clone().requires_grad_(True) for k, v in sd.items()}
+    ins = [t.to(dtype).clone() for t in inputs]
+    for t in ins[:3]:                      # DSTA: x; MVDualAttAlignment: x, extra, pred (the motion field gets no gradient)
+        t.requires_grad_(True)
+    out = dsta_forward(sdg, *ins) if kind == "dsta" else mv_dual_att_alignment_forward(sdg, *ins)
+    (out * cot.to(dtype)).sum().backward()
+    g = {k: v.grad for k, v in sdg.items()}
+    g.update({f"input{i}": t.grad for i, t in enumerate(ins[:3])})
+    return out.detach(), g
+
+
+@pytest.mark.parametrize("path", GOLD, ids=lambda p: p.split("/")[-1][:-4])
+def test_hip_modules_train_like_the_reference_classes(path):
+    """DSTA (ops/attentionlayer.py:117-156) and MVDualAttAlignment (arch.py:3303-3352) are trainable modules in the reference:
+    gradients of a random cotangent w.r.t. every parameter and every feature input, HIP autograd path against float64 torch
+    autograd through the oracle; the oracle's own float32 gradients are the yardstick of what fp32 arithmetic delivers."""
+    import numpy as np
+    kind, sd, inputs, gold = load_case(path)
+    if kind == "dsta":
+        from ops.attentionlayer import DSTA
+        m = DSTA(64)
+    else:
+        from cdfo_amd.mv_align import MVDualAttAlignment
+        m = MVDualAttAlignment(64, 64, 3, padding=1, deformable_groups=16, max_residue_magnitude=10)
+        # A deformable convolution's gradient w.r.t. its offsets is piecewise constant: it jumps wherever a sampling position crosses
+        # an integer coordinate.  With the golden case's weights the 138 240 sampling positions of this module (10 * tanh(.) + motion)
+        # land anywhere, and two correct fp32 implementations whose offsets differ by 1e-5 px put a few dozen samples on different
+        # sides of a jump -- per-tensor gradient differences of 1-6 % that say nothing about either (measured; the same effect as the
+        # ReLU kinks discussed in tests/test_gpu_train.py).  So the GRADIENT comparison runs on a configuration that stays clear of
+        # the jumps: a small offset head (|10 tanh| < ~0.1 px) around motion vectors at half-pixel positions.
+        sd = {k: v.clone() for k, v in sd.items()}
+        for k in ("conv_offset.2.weight", "conv_offset.2.bias"):
+            sd[k] *= 0.002
+        inputs = (*inputs[:3], torch.floor(inputs[3]) + 0.5)
+        gold = None
+    m.load_state_dict(sd, strict=True)
+    m = m.cuda().train()
+    oshape = tuple(inputs[0].shape) if kind == "dsta" else (inputs[0].shape[0], 64, *inputs[0].shape[2:])
+    cot = torch.from_numpy(np.random.RandomState(5).standard_normal(oshape).astype(np.float32))
+    ins = [t.cuda() for t in inputs]
+    for t in ins[:3]:
+        t.requires_grad_(True)
+    out = m(*ins)
+    assert out.requires_grad
+    (out * cot.cuda()).sum().backward()
+    torch.cuda.synchronize()
+    got = {k: p.grad for k, p in m.named_parameters()}
+    got.update({f"input{i}": t.grad for i, t in enumerate(ins[:3])})
+    o64, g64 = _oracle_grads(kind, sd, inputs, cot, torch.float64)
+    assert (out.detach().cpu().double() - o64).abs().max().item() <= 1e-4 * max(1.0, o64.abs().max().item())
+    if gold is not None:
+        assert (out.detach().cpu() - gold).abs().max().item() <= 1e-3 * max(1.0, gold.abs().max().item())
+    _, g32 = _oracle_grads(kind, sd, inputs, cot, torch.float32)
+    rows = []
+    for k, go in g64.items():
+        if go is None:                                  # a parameter the reference's forward never uses
+            assert got[k] is None or got[k].abs().max().item() == 0.0, k
+            continue
+        scale = go.abs().max().item()
+        if scale == 0.0:
+            continue
+        assert got[k] is not None, k
+        rows.append(((got[k].cpu().double() - go).abs().max().item() / scale, (g32[k].double() - go).abs().max().item() / scale, k))
+    rows.sort(reverse=True)
+    e_hip, e_cpu = np.array([r[0] for r in rows]), np.array([r[1] for r in rows])
+    print(f"{kind}: {len(rows)} gradient tensors vs float64 oracle autograd: HIP median {np.median(e_hip):.2e} (float32 CPU oracle "
+          f"{np.median(e_cpu):.2e}), worst {rows[0][0]:.2e} ({rows[0][2]}; float32 oracle there {rows[0][1]:.2e})")
+    assert np.median(e_hip) <= 1e-4 and e_hip.max() <= 5e-3, rows[:5]

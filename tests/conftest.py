@@ -24,6 +24,20 @@ def pytest_configure(config):
         pass
 
 
+def pytest_collection_finish(session):
+    """GPU session that includes the full-size parity tests: start their CPU-oracle forwards now, in background threads, so that
+    the minutes of host work overlap the GPU tests of the files that run first (tests/test_gpu_full_size.py::prefetch)."""
+    try:
+        if not os.path.exists("/dev/kfd"):
+            return
+        wanted = [it for it in session.items if "test_gpu_full_size.py" in it.nodeid and "oracle" in it.nodeid]
+        if len(wanted) >= 3:                     # a run of the whole file, not one selected case
+            import test_gpu_full_size as fs
+            fs.prefetch()
+    except Exception:
+        pass
+
+
 def _run_and_report(cmd, env, cwd, timeout, q):
     import subprocess
     try:

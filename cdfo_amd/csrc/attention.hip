@@ -299,7 +299,11 @@ __device__ __forceinline__ void split_pair_f16(float a, float b, unsigned& hi, u
 // (tpb tiles each; waves >= tpb only stage).  The kernel is VALU-bound (softmax + splits), not MFMA-bound, hence:
 // scores in the log2 domain (Q is scaled by log2 e once, p = v_exp_f32(s - m) -- one instruction instead of expf's ten),
 // key masking only in a sequence's last sub-tile, and the accumulator rescale skipped while no lane's running maximum moves.
-template <int MODE, int NW>   // MODE 0: sequence = image row, 1: image column, 2: 8x8 window (row-major inside the window)
+// PV1 (the default fp16x2 arithmetic of the forward): the SECOND product with single-fp16 operands -- probabilities p in [0, 1]
+// (sum 1) and values rounded once to fp16: |error of an output| <= 2^-11 * sum_j p_j |v_j| <= 4.9e-4 * max|v| in the worst case,
+// ~1e-5 * |v| measured (random signs average); the scores, whose error the exponential amplifies, keep all three passes.  8 of the
+// 24 MFMAs per 32 x 32 tile, the lo halves of V's staging and of P's conversion, and half of V's fragment reads go away.
+template <int MODE, int NW, bool PV1 = false>   // MODE 0: sequence = image row, 1: image column, 2: 8x8 window (row-major inside the window)
 __global__ __launch_bounds__(NW * 64, NW == 4 ? 3 : 2) void seq_attn_mfma_kernel(const float* __restrict__ q, int ldq,
                                                                 const float* __restrict__ v, int ldv,
                                                                 float* __restrict__ out, int ldo, int B, int H, int W,
@@ -382,12 +386,17 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 3 : 2) void seq_attn_mfma_kernel
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const int ch = 4 * sc4 + e, swz = (ch >> 1) & 7;
-        unsigned h0, l0, h1, l1;                            // keys 4m .. 4m+3 of channel ch
-        split_pair_f16(rs[0][e], rs[1][e], h0, l0);
-        split_pair_f16(rs[2][e], rs[3][e], h1, l1);
-        const attn_u32x2 vh = {h0, h1}, vl = {l0, l1};
-        *reinterpret_cast<attn_u32x2*>(vb + ch * 128 + ((c ^ swz) * 16)) = vh;
-        *reinterpret_cast<attn_u32x2*>(vb + ch * 128 + (((4 + c) ^ swz) * 16)) = vl;
+        if (PV1) {                                          // keys 4m .. 4m+3 of channel ch, rounded once
+          const attn_f16x4 vh = {(_Float16)rs[0][e], (_Float16)rs[1][e], (_Float16)rs[2][e], (_Float16)rs[3][e]};
+          *reinterpret_cast<attn_f16x4*>(vb + ch * 128 + ((c ^ swz) * 16)) = vh;
+        } else {
+          unsigned h0, l0, h1, l1;
+          split_pair_f16(rs[0][e], rs[1][e], h0, l0);
+          split_pair_f16(rs[2][e], rs[3][e], h1, l1);
+          const attn_u32x2 vh = {h0, h1}, vl = {l0, l1};
+          *reinterpret_cast<attn_u32x2*>(vb + ch * 128 + ((c ^ swz) * 16)) = vh;
+          *reinterpret_cast<attn_u32x2*>(vb + ch * 128 + (((4 + c) ^ swz) * 16)) = vl;
+        }
       }
     } else {
 #pragma unroll
@@ -471,19 +480,28 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 3 : 2) void seq_attn_mfma_kernel
         const unsigned char* const vb = sV + buf * V_BYTES + sub * 8192;
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
-          unsigned hh[4], ll[4];
+          attn_f16x8 ph, pl;
+          if (PV1) {
 #pragma unroll
-          for (int j = 0; j < 4; ++j) split_pair_f16(sacc[sub][8 * u + 2 * j], sacc[sub][8 * u + 2 * j + 1], hh[j], ll[j]);
-          const attn_u32x4 phu = {hh[0], hh[1], hh[2], hh[3]}, plu = {ll[0], ll[1], ll[2], ll[3]};
-          const attn_f16x8 ph = __builtin_bit_cast(attn_f16x8, phu), pl = __builtin_bit_cast(attn_f16x8, plu);
+            for (int j = 0; j < 8; ++j) ph[j] = (_Float16)sacc[sub][8 * u + j];
+          } else {
+            unsigned hh[4], ll[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) split_pair_f16(sacc[sub][8 * u + 2 * j], sacc[sub][8 * u + 2 * j + 1], hh[j], ll[j]);
+            const attn_u32x4 phu = {hh[0], hh[1], hh[2], hh[3]}, plu = {ll[0], ll[1], ll[2], ll[3]};
+            ph = __builtin_bit_cast(attn_f16x8, phu);
+            pl = __builtin_bit_cast(attn_f16x8, plu);
+          }
 #pragma unroll
           for (int half = 0; half < 2; ++half) {            // channels 0-31 -> o0, 32-63 -> o1
             const int ch = 32 * half + r, swz = (ch >> 1) & 7, c = 2 * u + h;
             const attn_f16x8 vh = *reinterpret_cast<const attn_f16x8*>(vb + ch * 128 + ((c ^ swz) * 16));
-            const attn_f16x8 vl = *reinterpret_cast<const attn_f16x8*>(vb + ch * 128 + (((4 + c) ^ swz) * 16));
             f32x16& o = half ? o1 : o0;
-            o = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl, ph, o, 0, 0, 0);
-            o = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, pl, o, 0, 0, 0);
+            if (!PV1) {
+              const attn_f16x8 vl = *reinterpret_cast<const attn_f16x8*>(vb + ch * 128 + (((4 + c) ^ swz) * 16));
+              o = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl, ph, o, 0, 0, 0);
+              o = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, pl, o, 0, 0, 0);
+            }
             o = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, ph, o, 0, 0, 0);
           }
         }
@@ -509,18 +527,18 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 3 : 2) void seq_attn_mfma_kernel
   }
 }
 
-template <int MODE, int NW>
+template <int MODE, int NW, bool PV1 = false>
 int seq_attn_launch(const float* q, int ldq, const float* v, int ldv, float* out, int ldo, int B, int H, int W, hipStream_t st) {
   static CdfoAttrOnce once;
   constexpr int SUB = NW / 4, LDSB = 2 * (32 * SUB * 272 + SUB * 64 * 128);
-  const hipError_t e = cdfo_set_max_lds(once, reinterpret_cast<const void*>(&seq_attn_mfma_kernel<MODE, NW>), LDSB);
+  const hipError_t e = cdfo_set_max_lds(once, reinterpret_cast<const void*>(&seq_attn_mfma_kernel<MODE, NW, PV1>), LDSB);
   if (e != hipSuccess) return (int)e;
   const int L = MODE == 0 ? W : (MODE == 1 ? H : 64);
   const int ntq = cdiv(L, 32), nb = cdiv(ntq, NW), tpb = cdiv(ntq, nb);
   const long long nseq = MODE == 0 ? (long long)B * H : (MODE == 1 ? (long long)B * W : (long long)B * (H / 8) * (W / 8));
   if (nseq * nb >= (1ll << 31)) return CDFO_EINVAL;
   static const int xcd_map = []() { const char* e = getenv("CDFO_ATTN_XCD"); return e ? atoi(e) : 1; }();   // developer A/B switch
-  hipLaunchKernelGGL((seq_attn_mfma_kernel<MODE, NW>), dim3((unsigned)(nseq * nb)), dim3(NW * 64), LDSB, st, q, ldq, v, ldv,
+  hipLaunchKernelGGL((seq_attn_mfma_kernel<MODE, NW, PV1>), dim3((unsigned)(nseq * nb)), dim3(NW * 64), LDSB, st, q, ldq, v, ldv,
                      out, ldo, B, H, W, nb, tpb, (nb > 1 && xcd_map) ? 1 : 0);
   return 0;
 }
@@ -587,6 +605,8 @@ extern "C" int cdfo_seq_attn(const float* q, int ldq, const float* v, int ldv, f
   if (!aligned16(q) || !aligned16(v) || !aligned16(out)) return CDFO_EALIGN;
   hipStream_t st = static_cast<hipStream_t>(stream);
   CdfoProfScope prof(static_cast<hipStream_t>(stream), (mode%10)==0?KID_ATTN_ROW:((mode%10)==1?KID_ATTN_COL:KID_ATTN_WIN), 4.0*64*(double)B*H*W*((mode%10)==0?W:((mode%10)==1?H:64)), 4.0*192*(double)B*H*W);
+  const bool pv1 = mode >= 20 && mode <= 22;           // modes 20 / 21 / 22: modes 0 / 1 / 2 with the single-fp16 second product (PV1)
+  if (pv1) mode -= 20;
   if (mode == 0 || mode == 1) {
     // 8-wave workgroups amortise the staging over twice the queries, but only if the sequence's 32-query tiles fill them:
     // 272 keys = 9 tiles = 2 x 8 waves at 56 % or 3 x 4 waves at 75 % (column attention at 24 x 272 x 480: 1.61 vs 1.35 ms;
@@ -598,8 +618,13 @@ extern "C" int cdfo_seq_attn(const float* q, int ldq, const float* v, int ldv, f
     const bool wide = force_nw ? force_nw == 8
                                : L > 128 && (double)ntq / (cdiv(ntq, 8) * 8) >= (double)ntq / (cdiv(ntq, 4) * 4) - 0.1;
     int rc;
-    if (mode == 0) rc = !wide ? seq_attn_launch<0, 4>(q, ldq, v, ldv, out, ldo, B, H, W, st)
-                              : seq_attn_launch<0, 8>(q, ldq, v, ldv, out, ldo, B, H, W, st);
+    if (pv1) {
+      if (mode == 0) rc = !wide ? seq_attn_launch<0, 4, true>(q, ldq, v, ldv, out, ldo, B, H, W, st)
+                                : seq_attn_launch<0, 8, true>(q, ldq, v, ldv, out, ldo, B, H, W, st);
+      else rc = !wide ? seq_attn_launch<1, 4, true>(q, ldq, v, ldv, out, ldo, B, H, W, st)
+                      : seq_attn_launch<1, 8, true>(q, ldq, v, ldv, out, ldo, B, H, W, st);
+    } else if (mode == 0) rc = !wide ? seq_attn_launch<0, 4>(q, ldq, v, ldv, out, ldo, B, H, W, st)
+                                     : seq_attn_launch<0, 8>(q, ldq, v, ldv, out, ldo, B, H, W, st);
     else rc = !wide ? seq_attn_launch<1, 4>(q, ldq, v, ldv, out, ldo, B, H, W, st)
                     : seq_attn_launch<1, 8>(q, ldq, v, ldv, out, ldo, B, H, W, st);
     if (rc) return rc;
@@ -611,7 +636,8 @@ extern "C" int cdfo_seq_attn(const float* q, int ldq, const float* v, int ldv, f
                        ldv, out, ldo, B, H, W);
   } else if (mode == 2) {
     if ((H & 7) || (W & 7)) return CDFO_EINVAL;
-    const int rc = seq_attn_launch<2, 4>(q, ldq, v, ldv, out, ldo, B, H, W, st);
+    const int rc = pv1 ? seq_attn_launch<2, 4, true>(q, ldq, v, ldv, out, ldo, B, H, W, st)
+                       : seq_attn_launch<2, 4>(q, ldq, v, ldv, out, ldo, B, H, W, st);
     if (rc) return rc;
   } else if (mode == 12) {   // VALU reference form of mode 2
     if ((H & 7) || (W & 7)) return CDFO_EINVAL;

@@ -42,12 +42,27 @@ __global__ void swap_outer_kernel(const f32x4* __restrict__ in, f32x4* __restric
 __global__ __launch_bounds__(256) void range_probe_kernel(const f32x4* __restrict__ x, long long n4, unsigned* __restrict__ slots) {
   float m = 0.f;
   bool bad = false;
-  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+  // four independent 16-byte loads in flight per thread (one per trip left the kernel latency-bound: 267 MB in 0.137 ms)
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  for (; i + 3 * stride < n4; i += 4 * stride) {
+    f32x4 v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) v[u] = x[i + u * stride];
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float a = fabsf(v[u][k]);
+        if (a < 3.0e38f) m = fmaxf(m, a); else bad = true;      // NaN compares false: counted as bad
+      }
+  }
+  for (; i < n4; i += stride) {
     const f32x4 v = x[i];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       const float a = fabsf(v[k]);
-      if (a < 3.0e38f) m = fmaxf(m, a); else bad = true;      // NaN compares false: counted as bad
+      if (a < 3.0e38f) m = fmaxf(m, a); else bad = true;
     }
   }
   m = wave_max(m);

@@ -145,6 +145,8 @@ class CVSR_V8(nn.Module):
         # HIP side streams for the two independent neighbour groups (frames 0-2 and 4-6): 1 = everything on the caller's
         # stream, 0 = auto = 2 (one side stream per group)
         self.neighbour_streams = 0
+        self.udsa_side_stream = os.environ.get("CDFO_UDSA_STREAM", "1") not in ("", "0")   # developer A/B, see _feature_extraction
+        self.attn_pv_single = os.environ.get("CDFO_ATTN_PV3", "0") in ("", "0")    # see _rdab (developer A/B: CDFO_ATTN_PV3=1 -> three passes)
         self.neighbour_group = 0        # frames per neighbour group: 0 = auto = 3
         # cached-feature call on one sequence (B = 1): the group of frames 0-2 (cached features only) starts beside the new
         # frame's feature extraction instead of behind it (see _forward)
@@ -348,13 +350,20 @@ class CVSR_V8(nn.Module):
         raw = w["raw"]
         p = "transformer_feature_extraction.path1."
         x2 = None
+        main = torch.cuda.current_stream(x1.device)
+        side = self._trunk_side(x1.device) if self.udsa_side_stream else None
         for rnd in range(3):
-            # (the prior U-net is independent of the MDTA chain below, but issuing it on a side stream made the
-            # forward 18 % slower: both chains are made of full-GPU launches that only get in each other's way)
-            if rnd == 0:
-                x2 = self._udsa(w, None, x1, head=K.udsa_head(prior, P, Bn, self.H, self.W, w["udsa_head"]))
-            else:
-                x2 = self._udsa(w, x2, x2)
+            # The prior U-net of a round is independent of its MDTA chain (they meet in the round's last convolution).  Round 1
+            # tried it on a side stream: 18 % slower with that round's kernels; measured again in round 4 (udsa_side_stream).
+            with (torch.cuda.stream(side) if side is not None else contextlib.nullcontext()):
+                if side is not None and rnd == 0:
+                    side.wait_stream(main)
+                if rnd == 0:
+                    x2 = self._udsa(w, None, x1, head=K.udsa_head(prior, P, Bn, self.H, self.W, w["udsa_head"]))
+                else:
+                    x2 = self._udsa(w, x2, x2)
+                if side is not None:
+                    x2.record_stream(main)
             if self.precision == "f32":
                 qkv = self._conv(x1, w[p + "attn.qkv"], ln=(raw[p + "norm1.body.weight"], raw[p + "norm1.body.bias"]))
                 qkv = K.dwconv3x3(qkv, raw[p + "attn.qkv_dwconv.weight"])
@@ -370,6 +379,8 @@ class CVSR_V8(nn.Module):
                 part, n = K.gram_partial(qkv[..., 0:64], qkv[..., 64:128], 8)
                 fold = K.mdta_fold(part, n, raw[p + "attn.temperature"], raw[p + "attn.project_out.weight"])
                 x1 = self._conv(qkv[..., 128:192], fold, res1=x1)
+            if side is not None:
+                main.wait_stream(side)
             if self.precision == "fp16x2":
                 # LayerNorm written as fp16 hi | lo planes; the 3x3 conv as a split-fp16 product (a_hi*w_hi + a_lo*w_hi +
                 # a_hi*w_lo, 22-bit operands: fp32-grade like the split-bf16 path it replaces) on the ring kernel
@@ -405,10 +416,13 @@ class CVSR_V8(nn.Module):
             else:
                 K.rdab_prep(xq[sl], vmax[sl], noise, raw["RDAB.directW1_conv.weight"], raw["RDAB.directW1_conv.bias"], outs=outs)
         cat = K.empty_act(GB, H, W, 128, x.device)
-        rowo = K.seq_attn(sq, vrow, 0)
+        # fp16x2 (default): the probabilities-times-values product of the three attentions on single-fp16 operands (modes 20-22:
+        # error <= 2^-11 max|v|, measured ~1e-5 |v|; the scores keep their three split-fp16 passes); fp32-grade modes: all three passes
+        am = 20 if self.precision == "fp16x2" and self.attn_pv_single else 0
+        rowo = K.seq_attn(sq, vrow, am)
         qc = K.colconv9(sq, raw["RDAB.directH1_conv.weight"], raw["RDAB.directH1_conv.bias"])
-        K.seq_attn(qc, rowo, 1, out=cat[..., 0:64])
-        K.seq_attn(qwin, xq[..., 64:128], 2, out=cat[..., 64:128])
+        K.seq_attn(qc, rowo, am + 1, out=cat[..., 0:64])
+        K.seq_attn(qwin, xq[..., 64:128], am + 2, out=cat[..., 64:128])
         return self._conv(cat, w["RDAB.fuse"], res1=x)
 
     def _align(self, w, xc, extra, pred, mvs, mv_bstride, out):

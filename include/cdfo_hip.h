@@ -251,7 +251,10 @@ int cdfo_qkv_dw(const float* x, int ldx, int B, int H, int W, const void* w_bf16
                 float eps, float* out, int ldo, float* gram, int gram_slots, void* stream);
 /* out = softmax(Q Q^T) V per row (mode 0), column (1) or 8x8 window (2) (arch.py:2179-2249), flash style on the matrix
  * cores: both products with fp16 hi + fp16 lo operands, three passes, fp32 accumulate (scores exact to ~1e-6 relative).
- * Modes 10 / 11 / 12: the plain-VALU forms of 0 / 1 / 2 (kept as A/B references for the tests). */
+ * Modes 10 / 11 / 12: the plain-VALU forms of 0 / 1 / 2 (kept as A/B references for the tests).
+ * Modes 20 / 21 / 22: modes 0 / 1 / 2 with the SECOND product (probabilities x values) on single-fp16 operands, one pass: an
+ * output's error is bounded by 2^-11 * max|v| (probabilities sum to 1), ~1e-5 * |v| in practice; the scores keep three passes.
+ * The forward's default fp16x2 arithmetic uses these (cdfo_amd/cvsr_v8.py); the fp32-grade modes and the training path do not. */
 int cdfo_seq_attn(const float* q, int ldq, const float* v, int ldv, float* out, int ldo, int B, int H, int W, int mode,
                   void* stream);
 

@@ -12,10 +12,10 @@ def main():
     g = torch.Generator(device="cuda").manual_seed(3)
     q = torch.randn(B, H, W, 64, device="cuda", generator=g) * 0.7
     v = torch.randn(B, H, W, 64, device="cuda", generator=g)
-    for mode in (0, 1, 2):
-        L = (W, H, 64)[mode]
+    for mode in (0, 1, 2, 20, 21, 22):
+        L = (W, H, 64)[mode % 10]
         out = K.seq_attn(q, v, mode)
-        ref = K.seq_attn(q[:2], v[:2], 10 + mode)
+        ref = K.seq_attn(q[:2], v[:2], 10 + mode % 10)
         err = (out[:2] - ref).abs().max().item()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         for _ in range(3):

@@ -9,8 +9,9 @@ neighbours -- resized priors, ``RDAB`` compensation, ``conv_expand_fea_r``, ``MV
 kernel) -- merged by ``fb_fusion`` / ``tsa_fusion``, the cross-scale ``SCNet`` trunk on the three-level list and the
 pyramid-merging upsampler.
 
-Same deliberate differences as ``CVSR_V8``: CUDA (ROCm) tensors and ``torch.no_grad()`` only (no CPU / autograd
-fallback), injectable Gumbel noise (``gumbel_uniform=`` : the 36 uniform draws of ``RDAB.gumbel_softmax`` in call order,
+Same deliberate differences as ``CVSR_V8``: CUDA (ROCm) tensors only (no CPU fallback); under ``torch.no_grad()`` the fused
+inference schedule of this file, with gradients enabled the operator graph under autograd (``cdfo_amd/cvsr_v7_train.py``: HIP
+kernels forward and backward, like the reference class the module is trainable); injectable Gumbel noise (``gumbel_uniform=`` : the 36 uniform draws of ``RDAB.gumbel_softmax`` in call order,
 each ``[B,64,H>>lv,W>>lv]``), ``L1_fea`` returned channels-last, no ``featuremap_visual`` side effects.  H and W must be
 multiples of 4 (two pyramid halvings; the reference's shapes only line up under the same condition).  Arithmetic:
 ``precision`` = "bf16x3" (split-bf16 matrix cores, fp32-grade; default), "f32" (exact), or "fp16x2" (fp16 weights,
@@ -241,13 +242,23 @@ class CVSR_V7(nn.Module):
             return self._forward(x, mvs0, mvs1, pms, rms, ufs, pre_L1_fea, gumbel_uniform)
 
     def _forward(self, x, mvs0, mvs1, pms, rms, ufs, pre_L1_fea=None, gumbel_uniform=None):
-        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
-            raise NotImplementedError("CVSR_V7 (HIP): forward only -- wrap the call in torch.no_grad()")
         B, N, C, H, W = x.shape
         if N != NFRAMES or C != 1:
             raise ValueError(f"expected x of shape [B,7,1,H,W], got {tuple(x.shape)}")
         if H % 4 or W % 4:
             raise ValueError(f"H and W must be multiples of 4 (two pyramid halvings, arch.py:4268-4271); got {H}x{W}")
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            # training call: the operator graph under autograd, HIP kernels in both directions (cdfo_amd/cvsr_v7_train.py)
+            if pre_L1_fea is not None:
+                raise NotImplementedError("CVSR_V7 (HIP): the cached-feature path is an inference path; training uses fresh clips")
+            for prm in self.parameters():
+                if not prm.is_cuda or prm.dtype != torch.float32:
+                    raise NotImplementedError("CVSR_V7 (HIP): fp32 parameters on the GPU expected; call .cuda()")
+            noise = gumbel_uniform if gumbel_uniform is not None else self.gumbel_uniform
+            if noise is not None and len(noise) != N_DRAWS:
+                raise ValueError(f"gumbel_uniform must hold the {N_DRAWS} draws of one forward, got {len(noise)}")
+            from .cvsr_v7_train import forward_train
+            return forward_train(self, x, mvs0, mvs1, pms, rms, ufs, noise)
         w = self._weights()
         raw = w["raw"]
         ctr = self.center

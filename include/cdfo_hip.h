@@ -425,6 +425,17 @@ int cdfo_gate_nchw_bwd_y(const float* g, const float* a, const float* x, int BC,
 int cdfo_mv_offset_mask_bwd(const float* o1, const float* o2, int ld, const float* goff, const float* gmask, int B, long long P,
                             int third, float mag, float* g1, float* g2, void* stream);
 
+/* ---- backward-side kernels of CVSR_V7's own operators (v7_train.hip; cdfo_amd/cvsr_v7_train.py): fp32 pixel-major rows of 64
+ * channels.  cdfo_chan_pool_bwd: adjoint of cdfo_chan_pool (dpooled [npix][2] = d max, d mean; the first maximum in channel order
+ * receives d max).  cdfo_mul_plane: out[p][c] = x[p][c] * plane[p]; cdfo_dot_plane: out[p] = sum_c a[p][c] b[p][c].
+ * cdfo_gumbel_softmax: r = softmax_c(v[b][c] - log(-log u)) with u the reference's NCHW noise [B][64][P] (arch.py:2813-2822);
+ * cdfo_softmax64_bwd: dz = r * (dm - sum_c r dm). */
+int cdfo_chan_pool_bwd(const float* x, int ld, const float* dpooled, long long npix, float* dx, int ldo, void* stream);
+int cdfo_mul_plane(const float* x, int ld, const float* plane, long long npix, float* out, int ldo, void* stream);
+int cdfo_dot_plane(const float* a, int lda, const float* b, int ldb, long long npix, float* out, void* stream);
+int cdfo_gumbel_softmax(const float* v, const float* u, int B, long long P, float* out, int ldo, void* stream);
+int cdfo_softmax64_bwd(const float* r, int ldr, const float* dm, int ldm, long long npix, float* dz, int ldo, void* stream);
+
 /* ---- optional per-launch HIP-event timing on the launch stream (bench.py's live roofline figures) ----------- */
 int cdfo_prof_begin(int max_records);
 int cdfo_prof_end(int* launches, double* ms, double* flops, double* bytes, int nkid);

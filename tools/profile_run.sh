@@ -2,7 +2,7 @@
 # FETCH_SIZE, WRITE_SIZE).  R = round tag of the file names, COMMIT = the commit the snapshot was taken at (the box has no .git):
 #   gpurun -- "R=r03 COMMIT=$(git rev-parse --short HEAD) bash tools/profile_run.sh"
 set -o pipefail
-R=${R:-r03}; COMMIT=${COMMIT:-unknown}
+R=${R:-r04}; COMMIT=${COMMIT:-unknown}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT && O=gpurun_out/prof && mkdir -p $O
 B="python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-parity --no-extra-modes"
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- $B > $O/stats.log 2>&1 && \

@@ -45,10 +45,22 @@ __global__ __launch_bounds__(256) void rdab_prep_kernel(const float* __restrict_
   __shared__ float z[64 * ZS];
   __shared__ float mq[64 * QS];
   __shared__ float vv[64 * QS];
+  __shared__ float ev[64];
   const int tid = threadIdx.x;
   const long long p0 = (long long)blockIdx.x * 64;  // P % 64 == 0, so the 64 pixels share one image
   const long long b = p0 / P, pin = p0 - b * P;
-  // phase 1: logits z[i][c] = vmax[c] - log(-log(u))   (coalesced along pixels)
+  // softmax_c(v_c + g_c) with g = -log(-log u)  ==  (E_c / L_c) / sum_j (E_j / L_j),  E_c = exp(v_c - max v), L_c = -log u_c > 0:
+  // ONE logarithm per element instead of two logarithms and an exponential (the kernel is bound by exactly this arithmetic and by
+  // the Philox rounds), E is 64 values per image.  Same quantity as arch.py:2168-2177 up to fp32 rounding; the logarithm and the
+  // quotient are the hardware's v_log_f32 / v_rcp_f32 forms (1 ulp): the only consumer is the comparison w_c >= sum / 2, whose
+  // outcome can differ from the reference's only for a softmax within ~1e-6 of the 0.5 threshold, as with any other rounding.
+  if (tid < 64) {
+    float vm = vmax[b * 64];
+    for (int c = 1; c < 64; ++c) vm = fmaxf(vm, vmax[b * 64 + c]);
+    ev[tid] = expf(vmax[b * 64 + tid] - vm);
+  }
+  __syncthreads();
+  // phase 1: weights w[i][c] = E_c / (-log u)   (coalesced along pixels)
   if (RNG) {
     if (seed_dev) seed = *seed_dev;                // key in device memory (graph replays: rewritten between replays)
     const int i = tid & 63;
@@ -60,29 +72,24 @@ __global__ __launch_bounds__(256) void rdab_prep_kernel(const float* __restrict_
         const int c = 4 * j + k;
         const float u = ((float)(o[k] >> 8) + 0.5f) * (1.f / 16777216.f);
         if (noise_out) noise_out[(b * 64 + c) * P + pin + i] = u;
-        z[i * ZS + c] = vmax[b * 64 + c] + (-logf(-logf(u)));
+        z[i * ZS + c] = ev[c] / (-logf(u));
       }
     }
   } else {
     const int i = tid & 63;
     for (int c = tid >> 6; c < 64; c += 4) {
       const float u = noise[(b * 64 + c) * P + pin + i];
-      z[i * ZS + c] = vmax[b * 64 + c] + (-logf(-logf(u)));
+      z[i * ZS + c] = ev[c] / (-logf(u));
     }
   }
   for (int i = tid; i < 64 * QS; i += 256) { mq[i] = 0.f; vv[i] = 0.f; }
   __syncthreads();
-  // phase 2: hard mask = softmax_c(z) >= 0.5 ; 4 lanes per pixel, 16 channels each
+  // phase 2: hard mask = softmax_c >= 0.5  <=>  w_c >= 0.5 * sum_j w_j ; 4 lanes per pixel, 16 channels each
   const int i = tid >> 2, part = tid & 3;
   {
-    float m = -INFINITY;
-#pragma unroll
-    for (int c = 0; c < 16; ++c) m = fmaxf(m, z[i * ZS + part * 16 + c]);
-    m = fmaxf(m, __shfl_xor(m, 1, 64));
-    m = fmaxf(m, __shfl_xor(m, 2, 64));
     float e[16], s = 0.f;
 #pragma unroll
-    for (int c = 0; c < 16; ++c) { e[c] = expf(z[i * ZS + part * 16 + c] - m); s += e[c]; }
+    for (int c = 0; c < 16; ++c) { e[c] = z[i * ZS + part * 16 + c]; s += e[c]; }
     s += __shfl_xor(s, 1, 64);
     s += __shfl_xor(s, 2, 64);
     const float* px = xq + (p0 + i) * ldx + part * 16;
@@ -94,7 +101,7 @@ __global__ __launch_bounds__(256) void rdab_prep_kernel(const float* __restrict_
       f32x4 w4;
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
-        const float mk = (e[c4 * 4 + k] / s >= 0.5f) ? 1.f : 0.f;
+        const float mk = (e[c4 * 4 + k] >= 0.5f * s) ? 1.f : 0.f;
         mq[i * QS + 4 + part * 16 + c4 * 4 + k] = mk * q4[k];
         vv[i * QS + 4 + part * 16 + c4 * 4 + k] = v4[k];
         w4[k] = (1.f - mk) * q4[k];

@@ -145,6 +145,7 @@ class CVSR_V8(nn.Module):
         # HIP side streams for the two independent neighbour groups (frames 0-2 and 4-6): 1 = everything on the caller's
         # stream, 0 = auto = 2 (one side stream per group)
         self.neighbour_streams = 0
+        self.udsa_n16 = os.environ.get("CDFO_UDSA_N16", "1") not in ("", "0")       # developer A/B: the prior U-net's first layer, see _udsa
         self.udsa_side_stream = os.environ.get("CDFO_UDSA_STREAM", "1") not in ("", "0")   # developer A/B, see _feature_extraction
         self.attn_pv_single = os.environ.get("CDFO_ATTN_PV3", "0") in ("", "0")    # see _rdab (developer A/B: CDFO_ATTN_PV3=1 -> three passes)
         self.neighbour_group = 0        # frames per neighbour group: 0 = auto = 3
@@ -301,6 +302,7 @@ class CVSR_V8(nn.Module):
         pc2 = K.pack_conv(ws2d.view(64, 256, 3, 3).contiguous(), sd["RDAB.conv_du_re.2.bias"])
         pc2.tap_mask = torch.tensor(masks, dtype=torch.int32, device=w2.device)
         w["RDAB.conv_du_re.2_s2d"] = pc2
+        w[fe + "side_to_feaoneUDSA.body.0_n16"] = K.pack_conv_n16(sd[fe + "side_to_feaoneUDSA.body.0.weight"])
         w["udsa_head"] = K.pack_udsa_head(sd[fe + "side_to_feaoneUDSA.body.0.weight"], sd[fe + "side_to_feaoneUDSA.body.0.bias"],
                                           sd["conv_second.weight"], sd["conv_second.bias"])
         pc("upconv1", shuffle2=True)
@@ -329,7 +331,13 @@ class CVSR_V8(nn.Module):
         """head: body.0's activated output when it was computed elsewhere (round 0: straight from the prior image)."""
         raw = w["raw"]
         u = "transformer_feature_extraction.path1.side_to_feaoneUDSA.body."
-        t = head if head is not None else self._conv(x2, w[u + "0"], pad=1, act=K.ACT_LRELU, exact=True)
+        if head is not None:
+            t = head
+        elif self.precision != "f32" and self.udsa_n16:
+            # 64 -> 16 on its own streaming kernel (16 x 16 x 32 MFMA, every lane useful) instead of a quarter-filled 64-wide tile
+            t = K.conv3x3_n16(x2, w[u + "0_n16"], raw[u + "0.bias"], K.ACT_LRELU)
+        else:
+            t = self._conv(x2, w[u + "0"], pad=1, act=K.ACT_LRELU, exact=True)
         t = K.small_conv16(t, raw[u + "2.weight"], raw[u + "2.bias"], 2, 2, act=K.ACT_LRELU)
         t = K.small_conv16(t, raw[u + "4.weight"], raw[u + "4.bias"], 2, 2, act=K.ACT_LRELU)
         t = K.spatial_gate16(t, raw[u + "6.spatial.weight"], raw[u + "6.spatial.bias"])

@@ -228,6 +228,28 @@ def _vp(t):
     return C.c_void_p(None if t is None else t.data_ptr())
 
 
+def pack_conv_n16(weight: torch.Tensor) -> torch.Tensor:
+    """[16, 64, 3, 3] fp32 -> the bf16 hi | lo image of cdfo_conv3x3_c64_n16: [18 K steps = tap*2 + half][hi|lo][lane = kg*16 + m][8]
+    with element j = W[m][32 half + 8 kg + j][tap] (parameter-sized torch arithmetic, once per weight version)."""
+    if tuple(weight.shape) != (16, 64, 3, 3):
+        raise ValueError("pack_conv_n16: a [16, 64, 3, 3] weight expected")
+    w = weight.detach().float().permute(2, 3, 1, 0).reshape(9, 2, 4, 8, 16).permute(0, 1, 2, 4, 3).reshape(18, 64, 8)
+    hi = w.to(torch.bfloat16)
+    lo = (w - hi.float()).to(torch.bfloat16)
+    return torch.stack([hi, lo], 1).contiguous()              # [18, 2, 64, 8] bf16 = 36,864 bytes
+
+
+def conv3x3_n16(x: torch.Tensor, w_packed: torch.Tensor, bias: Optional[torch.Tensor], act: int = ACT_NONE) -> torch.Tensor:
+    """3x3 / stride 1 / pad 1 convolution 64 -> 16 (split-bf16, fp32-grade): x [B,H,W,64] (channel slices allowed) -> [B,H,W,16]."""
+    B, H, W, Cc, ld = _chk_act(x)
+    if Cc != 64 or w_packed.dtype != torch.bfloat16 or w_packed.numel() != 18 * 2 * 64 * 8:
+        raise ValueError("conv3x3_n16: 64 input channels and a pack_conv_n16 weight image expected")
+    out = empty_act(B, H, W, 16, x.device)
+    check(_lib.lib().cdfo_conv3x3_c64_n16(_vp(x), ld, B, H, W, _vp(w_packed), _vp(bias), act, _vp(out), 16, _stream()),
+          "cdfo_conv3x3_c64_n16")
+    return out
+
+
 def to_cp16(x: torch.Tensor) -> torch.Tensor:
     """fp32 pixel-major [B,H,W,C] -> fp16 chunk-planar [B, C/16, H, W, 16] (the source layout of conv3x3_ws)."""
     B, H, W, Cc, ld = _chk_act(x)

@@ -406,6 +406,15 @@ int cdfo_ew_nchw(const float* a, const float* b, const float* x, const float* y,
 int cdfo_mv_offset_mask(const float* o1, const float* o2, int ld, const float* flow, long long flow_bstride, int B,
                         long long P, int third, float mag, float* offset, float* mask, void* stream);
 
+/* ---- 3x3 / stride 1 / pad 1 convolution 64 -> 16 channels (conv3x3_n16.hip; round 4): the first layer of the feature extractor's prior
+ * U-net (arch/SIDECVSR_our.py:1815-1834, body.0: Conv2d(64, 16, 3, 1, 1) + LeakyReLU) as a persistent stream on
+ * v_mfma_f32_16x16x32_bf16, split-bf16 three-pass arithmetic (fp32-grade, as cdfo_conv3x3_bf16's "bf16x3").  x fp32 pixel-major
+ * [B,H,W,>=64] (pitch ldx), out fp32 pixel-major [B,H,W,16] (pitch ldo).  w_packed: 36,864 bytes = [18 K steps = tap*2 + 32-channel
+ * half][hi | lo][64 lanes][8 bf16], lane l = output channel l & 15, input channels 32 half + 8 (l >> 4) .. + 7
+ * (cdfo_amd/kernels.py::pack_conv_n16). */
+int cdfo_conv3x3_c64_n16(const float* x, int ldx, int B, int H, int W, const void* w_packed, const float* bias, int act, float* out,
+                         int ldo, void* stream);
+
 /* ---- backward of the same operators (nchw_bwd.hip): DSTA and MVDualAttAlignment under autograd, like their reference classes
  * (ops/attentionlayer.py:117-156, arch/SIDECVSR_our.py:3303-3352).  Gather kernels, fixed summation order, no atomics.
  * cdfo_conv2d_nchw_bwd: any of gin [B,C,H,W] (needs w), gw [Co,C,kh,kw] (+ optional gbias [Co]; needs in) may be NULL; all ASSIGNED.

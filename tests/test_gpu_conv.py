@@ -589,3 +589,25 @@ def test_conv1x1_with_layernorm_planes_of_the_result(B, H, W):
     ref_hl = ref_planes.float()[:, 0:4] + ref_planes.float()[:, 4:8]
     assert (hl - ref_hl).abs().max().item() <= 2e-5
     assert (planes[:, 0:4].float() - ref_planes[:, 0:4].float()).abs().max().item() <= 4e-3      # hi halves: within an fp16 ulp
+
+
+@pytest.mark.parametrize("B,H,W", [(2, 16, 32), (1, 13, 45), (3, 8, 8), (1, 272, 480)])
+@pytest.mark.parametrize("act", [0, 1])
+def test_conv3x3_n16_matches_fp64_conv(B, H, W, act):
+    """cdfo_conv3x3_c64_n16 (the prior U-net's first layer, arch.py:1815-1834: Conv2d(64, 16, 3, 1, 1) [+ LeakyReLU]) against a float64
+    convolution: split-bf16 three-pass arithmetic = fp32-grade; ragged tiles, a channel slice of a wider tensor as the source."""
+    import torch.nn.functional as F
+    from cdfo_amd import kernels as K
+    g = torch.Generator(device="cuda").manual_seed(B * 100 + H + W)
+    wide = torch.randn(B, H, W, 128, device="cuda", generator=g)
+    x = wide[..., 32:96]                                            # pitch 128, 64 channels
+    w = torch.randn(16, 64, 3, 3, device="cuda", generator=g) / 24
+    b = torch.randn(16, device="cuda", generator=g)
+    out = K.conv3x3_n16(x, K.pack_conv_n16(w), b, K.ACT_LRELU if act else K.ACT_NONE)
+    ref = F.conv2d(x.permute(0, 3, 1, 2).double(), w.double(), b.double(), padding=1)
+    if act:
+        ref = F.leaky_relu(ref, 0.1)
+    torch.cuda.synchronize()
+    assert tuple(out.shape) == (B, H, W, 16)
+    err = (out.permute(0, 3, 1, 2).double() - ref).abs().max().item()
+    assert err <= 2e-5 * max(1.0, ref.abs().max().item()), err

@@ -305,7 +305,8 @@ extern "C" int cdfo_conv1x1_bf16x3(const cdfo_conv_args* pa, void* stream) {
   }
   {
     static const bool use_stream = [] { const char* e = getenv("CDFO_CONV1X1_STREAM"); return !(e && e[0] == '0'); }();   // developer A/B switch
-    if (use_stream && !taps) {
+    static const bool taps_stream = [] { const char* e = getenv("CDFO_TAPS_STREAM"); return !(e && e[0] == '0'); }();   // developer A/B switch
+    if (use_stream && (!taps || taps_stream)) {
       const int r = cdfo_conv1x1_stream_try(a, st);
       if (r == 1) return 0;
       if (r != 0) return r;

@@ -49,6 +49,11 @@ struct st_args {
   // the split-fp16 3x3 convolution that follows the attention in the feature extractor (arch.py:1470-1474): the values are in
   // the epilogue's registers, a separate LayerNorm pass would read the 64-channel result back from HBM
   _Float16* ln_hl; const float* ln_g; const float* ln_b;
+  // TAPS form (upconv2 of arch.py:4474-4476, Cout = 256 = 4 sub-pixels x 64): instead of the pixel-shuffled 64-channel HR map, out
+  // receives for every HR pixel the nine per-tap channel sums of the 3x3 conv_last that follows (see conv1x1_bf16x3.hip, TAPS):
+  // out[HR pixel][ldo], HR pixel = (b, 2 y + (cb >> 1), 2 x + (cb & 1)) of the W-pixel-wide input row (y, x)
+  const float* w_last;             // conv_last.weight as [64][9]
+  int W;                           // input image width (pixels per row) for the pixel shuffle
 };
 
 __device__ __forceinline__ unsigned st_pack_bf16(float a, float b) {
@@ -86,8 +91,21 @@ __device__ __forceinline__ void st_dma8(const unsigned (&voff)[8], i32x4 rsrc, u
       : "memory", "scc");
 }
 
-// NCB: 64-wide output-channel blocks (1 or 2)
-template <int NCB>
+// two fp32 -> packed fp16 hi and packed fp16 lo = fp16(v - hi): v_cvt_pk_f16_f32, two v_fma_mix_f32 (exact remainders, the fp16
+// operand read from its half of the packed register), v_cvt_pk_f16_f32 (see attention.hip: full-register results only)
+__device__ __forceinline__ void st_split_pair_f16(float x, float y, unsigned& hi, unsigned& lo) {
+  typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+  const h2 hv = {(_Float16)x, (_Float16)y};
+  hi = __builtin_bit_cast(unsigned, hv);
+  float rx, ry;
+  asm("v_fma_mix_f32 %0, %1, 1.0, -%2 op_sel_hi:[0,0,1]" : "=v"(rx) : "v"(x), "v"(hi));
+  asm("v_fma_mix_f32 %0, %1, 1.0, -%2 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "=v"(ry) : "v"(y), "v"(hi));
+  const h2 lv = {(_Float16)rx, (_Float16)ry};
+  lo = __builtin_bit_cast(unsigned, lv);
+}
+
+// NCB: 64-wide output-channel blocks (1, 2; 4 in the TAPS form)
+template <int NCB, bool TAPS = false>
 __global__ __launch_bounds__(ST_THREADS) void conv1x1_stream_kernel(st_args a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, r = lane & 31;
@@ -124,6 +142,22 @@ __global__ __launch_bounds__(ST_THREADS) void conv1x1_stream_kernel(st_args a) {
   }
   // fragment read offsets of this lane's pixel r: 16-byte part q lives at r*256 + ((q ^ (r & 15)) << 4)
   auto part_off = [&](int q) { return r * 256 + ((q ^ (r & 15)) << 4); };
+
+  // TAPS: A operand of the second product = w_last^T (row = tap, rows 9..31 zero), fp16 hi | lo, in registers for the whole launch:
+  // lane (r = tap, h) holds channels 16 s4 + 8 h .. + 7
+  typedef _Float16 st_h8 __attribute__((ext_vector_type(8)));
+  typedef unsigned st_u4 __attribute__((ext_vector_type(4)));
+  st_h8 twh[TAPS ? 4 : 1], twl[TAPS ? 4 : 1];
+  if (TAPS) {
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float wv = r < 9 ? a.w_last[(16 * s4 + 8 * h + j) * 9 + r] : 0.f;
+        twh[s4][j] = (_Float16)wv;
+        twl[s4][j] = (_Float16)(wv - (float)twh[s4][j]);
+      }
+  }
 
   for (long long img_t0 = t_lo; img_t0 < t_hi;) {
     const int b = (int)(img_t0 / a.tiles_per_image);
@@ -189,11 +223,16 @@ __global__ __launch_bounds__(ST_THREADS) void conv1x1_stream_kernel(st_args a) {
       const int k = (int)(it % items_per_tile);
       // item `it` has landed when at most the 8 * (younger items in flight) youngest DMA pieces are outstanding
       // (pieces retire in order among themselves; stores in flight only make the wait more conservative)
-      const long long younger = issued - it - 1;
+      const long long younger = TAPS ? 0 : issued - it - 1;
       if (younger >= 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
       else if (younger == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       const unsigned char* st = ring + (it % NS) * ST_STAGE;
+      if (TAPS) {
+        // two-stage ring (the 64 KB weight image leaves room for no more): the stage of item it - 1 was consumed in the previous
+        // trip, so item it + 1 is requested NOW and lands behind this tile's products and tap epilogue
+        if (issued < n_items) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); issue(issued); ++issued; }
+      }
       if (k == 0) {
 #pragma unroll
         for (int cb = 0; cb < NCB; ++cb)
@@ -258,7 +297,7 @@ __global__ __launch_bounds__(ST_THREADS) void conv1x1_stream_kernel(st_args a) {
       }
       // the stage may be overwritten once its reads have returned: the next DMA below targets the stage of item it-1... wait
       // for this item's own LDS reads too (they were consumed by the MFMAs / adds above, so they have returned)
-      if (issued < n_items) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); issue(issued); ++issued; }
+      if (!TAPS && issued < n_items) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); issue(issued); ++issued; }
       if (k == items_per_tile - 1) {
         // ---- store: 32 contiguous bytes per lane and 16-channel group
         const long long tile = img_t0 + it / items_per_tile;
@@ -301,7 +340,49 @@ __global__ __launch_bounds__(ST_THREADS) void conv1x1_stream_kernel(st_args a) {
               }
           }
         }
-        if (pin < a.P) {
+        if (TAPS) {
+          // Block cb = sub-pixel (cb >> 1, cb & 1) of the pixel-shuffled map.  acc[cb][ni][8 jj + q] = act(y)[channel 16 (2 ni + jj) +
+          // 8 h + q] of this lane's pixel: exactly the B fragment (k = 8 h + q of chunk 2 ni + jj) of taps[k][pixel] = sum_c
+          // w_last[c][k] act(y)[pixel][c] -- the accumulators feed the second product straight from registers.  Scaled per PIXEL by a
+          // power of two into fp16's range (a column of the product may carry its own scale), split hi | lo: hi*hi + lo*hi + hi*lo.
+          const int oy = (int)(pin / a.W), ox = (int)(pin - (long long)oy * a.W);
+#pragma unroll
+          for (int cb = 0; cb < NCB; ++cb) {
+            float amax = 0.f;
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+              for (int e = 0; e < 16; ++e) amax = fmaxf(amax, fabsf(acc[cb][ni][e]));
+            amax = fmaxf(amax, __shfl_xor(amax, 32, 64));              // the pixel's other 32 channels sit in lane ^ 32
+            int ex = 0;
+            if (amax > 0.f && amax < INFINITY) frexpf(amax, &ex);
+            ex = ex < -100 ? -100 : (ex > 100 ? 100 : ex);
+            const float sc = ldexpf(1.f, 14 - ex), inv = ldexpf(1.f, ex - 14);
+            f32x16 tacc;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) tacc[e] = 0.f;
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4) {
+              unsigned hh[4], ll[4];
+#pragma unroll
+              for (int j = 0; j < 4; ++j)
+                st_split_pair_f16(acc[cb][s4 >> 1][8 * (s4 & 1) + 2 * j] * sc, acc[cb][s4 >> 1][8 * (s4 & 1) + 2 * j + 1] * sc, hh[j], ll[j]);
+              const st_u4 hu = {hh[0], hh[1], hh[2], hh[3]}, lu = {ll[0], ll[1], ll[2], ll[3]};
+              const st_h8 yh = __builtin_bit_cast(st_h8, hu), yl = __builtin_bit_cast(st_h8, lu);
+              tacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(twl[s4], yh, tacc, 0, 0, 0);
+              tacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(twh[s4], yl, tacc, 0, 0, 0);
+              tacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(twh[s4], yh, tacc, 0, 0, 0);
+            }
+            // lane (pixel r, h): registers 0..3 = taps 4 h .. 4 h + 3, register 4 = tap 8 (h = 0)
+            if (pin < a.P) {
+              const long long opix = ((long long)b * 2 * (a.P / a.W) + 2 * oy + (cb >> 1)) * (2 * a.W) + 2 * ox + (cb & 1);
+              float* op = a.out + opix * a.ldo;
+              const f32x4 t4 = {tacc[0] * inv, tacc[1] * inv, tacc[2] * inv, tacc[3] * inv};
+              *reinterpret_cast<f32x4*>(op + 4 * h) = t4;
+              if (h == 0) op[8] = tacc[4] * inv;
+            }
+          }
+        } else if (pin < a.P) {
           float* op = a.out + ((long long)b * a.P + pin) * a.ldo;
 #pragma unroll
           for (int cb = 0; cb < NCB; ++cb)
@@ -331,6 +412,34 @@ __global__ __launch_bounds__(ST_THREADS) void conv1x1_stream_kernel(st_args a) {
 // cdfo_conv1x1_bf16x3), < 0 / hipError_t on errors.  Same argument block as cdfo_conv1x1_bf16x3.
 int cdfo_conv1x1_stream_try(const cdfo_conv_args& a, hipStream_t st) {
   const bool ln_out = a.out2_cp16 != nullptr;      // post-LayerNorm hi | lo second output (checked by the caller: Cout == 64)
+  const bool taps = a.store_mode == CDFO_STORE_TAPS9;
+  if (taps) {
+    // upconv2 + conv_last's tap sums (checked by the caller: Cout = CoutP = 256, res2 = conv_last.weight [64][9], no res1)
+    if (a.Cin != 64 || a.nsrc != 1 || a.ldo % 4 || a.ldo < 12 || a.ln_gamma || ln_out || (long long)a.ld[0] * 4 * 32 >= (1ll << 31)) return 0;
+    st_args s{};
+    s.act[0].base = a.src[0]; s.act[0].ld = a.ld[0]; s.act[0].ch0 = 0;
+    s.nkb = 1;
+    s.w = a.w; s.w_bstride = a.w_bstride; s.bias = a.bias;
+    s.Cin = 64; s.Cout = 256; s.CoutP = 256; s.act_fn = a.act;
+    s.out = a.out; s.ldo = a.ldo; s.B = a.B; s.P = (long long)a.H * a.W;
+    s.w_last = a.res2; s.W = a.W;
+    s.tiles_per_image = (int)((s.P + 127) / 128);
+    s.tiles = (long long)a.B * s.tiles_per_image;
+    s.ns = 2;
+    const int w_bytes = 2 * 1 * 4 * 2 * 4 * 64 * 16 + 4 * 64 * 4;
+    const int lds = w_bytes + 4 * s.ns * ST_STAGE;
+    const int cus = cdfo_num_cus();
+    if (cus <= 0) return CDFO_EINVAL;
+    const int grid = (int)(s.tiles < cus ? s.tiles : cus);
+    const double px = (double)a.B * s.P;
+    CdfoProfScope prof(st, KID_CONV1, 2.0 * px * 256 * 64 + 2.0 * px * 4 * 9 * 64, 4.0 * (px * 64 + px * 4 * a.ldo + 64.0 * 256));
+    static CdfoAttrOnce once;
+    const hipError_t e = cdfo_set_max_lds(once, reinterpret_cast<const void*>(conv1x1_stream_kernel<4, true>), 160 * 1024 - 256);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL((conv1x1_stream_kernel<4, true>), dim3(grid), dim3(ST_THREADS), lds, st, s);
+    const hipError_t e2 = hipGetLastError();
+    return e2 == hipSuccess ? 1 : (int)e2;
+  }
   if (a.store_mode != CDFO_STORE_PLAIN || (a.ln_gamma && !ln_out) || a.CoutP % 64 || a.CoutP > 128 || a.Cout % 8) return 0;
   if (ln_out && (a.CoutP != 64 || a.Cout != 64)) return 0;
   const int ncb = a.CoutP / 64, nkb = a.Cin / 64;

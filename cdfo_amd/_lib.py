@@ -42,6 +42,8 @@ class ConvArgs(C.Structure):
         ("src_plane_wrap", C.c_int),
         ("res_up2", C.c_void_p), ("ldru", C.c_int),
         ("out2_lo", C.c_int),
+        ("mask_out", C.c_void_p), ("flow", C.c_void_p), ("flow_bstride", C.c_longlong), ("off_mag", C.c_float),
+        ("off_accumulate", C.c_int),
     ]
 
 

@@ -2,6 +2,7 @@
 #include "common.h"
 
 extern "C" int cdfo_abi_version(void) { return 1; }
+extern "C" int cdfo_sizeof_conv_args(void) { return (int)sizeof(cdfo_conv_args); }
 extern "C" const char* cdfo_build_info(void) { return "libcdfo_hip gfx950 (CDNA4) " __DATE__ " " __TIME__; }
 
 #include "prof.h"

@@ -75,6 +75,68 @@ __device__ __forceinline__ unsigned pack16(float a, float b) {
 template <bool F16>
 __device__ __forceinline__ float round16(float a) { return F16 ? (float)(_Float16)a : (float)(__bf16)a; }
 
+// CDFO_STORE_OFFMASK: the epilogue of MVDualAttAlignment's conv_offset[2] = the module's offset / mask assembly (arch.py:3336-3350),
+// straight from the accumulators into the DCN operator's NCHW planes.  A lane of the 32x32 accumulator holds ONE output channel
+// and four runs of four consecutive pixels of an image row: each run is one 16-byte access to that channel's plane, no transpose.
+// tanh / sigmoid through v_exp_f32 + v_rcp_f32 (absolute error ~1e-7, i.e. 1e-6 px on a 10 px offset).
+__device__ __forceinline__ float fast_tanh(float x) {     // 1 - 2 / (1 + e^(2x)); saturates to +-1 through inf / 0
+  return 1.f - 2.f * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(x * 2.885390081777927f));
+}
+__device__ __forceinline__ float fast_sigmoid(float x) {
+  return __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(x * -1.4426950408889634f));
+}
+template <int NT>
+__device__ __forceinline__ void offmask_epilogue(const cdfo_conv_args& a, const f32x16 (*acc)[NT], int lane, int b, int oyb, int ox0,
+                                                 int n0) {
+  const int h = lane >> 5, r = lane & 31;
+  const int third = a.Cout / 3;
+  const long long P = (long long)a.Ho * a.Wo;
+  float* plane[NT];
+  const float* prior[NT];        // what a run starts from: the flipped motion field (first head) or the plane itself (second head)
+  float bias[NT];
+  bool live[NT], is_off[NT];
+#pragma unroll
+  for (int ni = 0; ni < NT; ++ni) {
+    const int c = n0 + ni * 32 + r;
+    live[ni] = c < a.Cout;
+    is_off[ni] = c < 2 * third;
+    bias[ni] = (a.bias && live[ni]) ? a.bias[c] : 0.f;
+    plane[ni] = is_off[ni] ? a.out + ((long long)b * 2 * third + c) * P : a.mask_out + ((long long)b * third + (c - 2 * third)) * P;
+    prior[ni] = a.off_accumulate ? plane[ni]
+                                 : (is_off[ni] ? a.flow + b * a.flow_bstride + (long long)(1 - (c & 1)) * P : nullptr);   // flip(1)
+  }
+  // every read of the epilogue is requested before the first store: the stores may alias the loads as far as the compiler knows,
+  // so a load -> tanh -> store loop would pay one memory latency per run (16 per lane)
+  f32x4 pv[NT][2][4];
+#pragma unroll
+  for (int ni = 0; ni < NT; ++ni)
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int oy = oyb + mi, x = ox0 + 8 * j + 4 * h;
+        pv[ni][mi][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (live[ni] && prior[ni] && oy < a.Ho && x < a.Wo) pv[ni][mi][j] = *reinterpret_cast<const f32x4*>(prior[ni] + oy * a.Wo + x);
+      }
+#pragma unroll
+  for (int ni = 0; ni < NT; ++ni)
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int oy = oyb + mi, x = ox0 + 8 * j + 4 * h;      // Wo % 4 == 0: a run of four pixels is inside the row or outside it
+        if (!live[ni] || oy >= a.Ho || x >= a.Wo) continue;
+        f32x4 res = pv[ni][mi][j];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const float v = acc[mi][ni][4 * j + k] + bias[ni];
+          if (is_off[ni]) res[k] += a.off_mag * fast_tanh(v);
+          else res[k] = a.off_accumulate ? fast_sigmoid(res[k] + v) : v;
+        }
+        *reinterpret_cast<f32x4*>(plane[ni] + oy * a.Wo + x) = res;
+      }
+}
+
 // DBG (developer ablations, never used by the product path): 1 = skip the MFMAs, 2 = skip the per-chunk global loads,
 // 4 = skip the per-chunk convert + LDS writes, 8 = skip the epilogue (store one value), 16 = skip the barriers
 // NT: 32-channel output tiles per workgroup (2 = 64 output channels; 1 for convolutions with <= 32 output channels, e.g.
@@ -287,6 +349,10 @@ __global__ __launch_bounds__(256, WAVES_PER_SIMD) void conv3x3_mma16_kernel(cdfo
     if (t == 123.456f) a.out[0] = t;
     return;
   }
+  if ((MODE == M_BF16X3 || MODE == M_FP16X2 || MODE == M_FP16X1) && NT == 2 && DBG == 0 && a.store_mode == CDFO_STORE_OFFMASK) {
+    offmask_epilogue<NT>(a, acc, lane, b, oy0 + wave * 2, ox0, n0);
+    return;
+  }
   float* wl = reinterpret_cast<float*>(smem) + wave * ConvEpi<NT>::WAVE_FLOATS;
 #pragma unroll
   for (int mi = 0; mi < 2; ++mi) conv_tile_epilogue_row32<NT>(a, wl, acc[mi], lane, b, oy0 + wave * 2 + mi, ox0, n0);
@@ -333,7 +399,16 @@ extern "C" int cdfo_conv3x3_bf16(const cdfo_conv_args* pa, void* stream) {
     csum += a.cs[s];
   }
   if (csum != a.Cin || a.CoutP % 64 || a.CoutP < a.Cout || a.Cout <= 0 || a.Ho != a.H || a.Wo != a.W) return CDFO_EINVAL;
-  if ((a.store_mode != CDFO_STORE_PLAIN && a.store_mode != CDFO_STORE_S2D) || a.w_bstride != 0) return CDFO_EINVAL;
+  const bool offmask = a.store_mode == CDFO_STORE_OFFMASK;
+  if (offmask) {
+    const int pr = a.prec & 255;
+    if ((pr != CDFO_PREC_BF16X3 && pr != CDFO_PREC_FP16X2 && pr != CDFO_PREC_FP16X1) || (a.prec >> 8) || a.Cout % 3 || a.Cout <= 32 || a.Wo % 4 || a.act != CDFO_ACT_NONE ||
+        a.res1 || a.res2 || a.out_f16 || a.tap_mask || !a.mask_out || !a.flow || a.flow_bstride % 4 ||
+        (long long)a.Ho * a.Wo >= (1ll << 31))
+      return CDFO_EINVAL;
+    if (!aligned16(a.mask_out) || !aligned16(a.flow)) return CDFO_EALIGN;
+  }
+  if ((a.store_mode != CDFO_STORE_PLAIN && a.store_mode != CDFO_STORE_S2D && !offmask) || a.w_bstride != 0) return CDFO_EINVAL;
   if (a.store_mode == CDFO_STORE_S2D && ((a.Ho | a.Wo) & 1 || a.res1 || a.res2)) return CDFO_EINVAL;
   if (!aligned16(a.w) || a.Cout % 4 || a.ldo % 4 || !aligned16(a.out) || (a.bias && !aligned16(a.bias))) return CDFO_EALIGN;
   if ((a.res1 && (a.ldr1 % 4 || !aligned16(a.res1))) || (a.res2 && (a.ldr2 % 4 || !aligned16(a.res2)))) return CDFO_EALIGN;

@@ -144,6 +144,7 @@ class CVSR_V7(nn.Module):
                 for leaf in ("body.0", "body.2", "down.0", "up.0"):
                     pc(f"recon_trunk.body.{g}.body.{b}.{leaf}")
         w[fe + "qkv_dw"] = K.pack_qkv_dw(sd[fe + "attn.qkv.weight"], sd[fe + "norm1.body.weight"], sd[fe + "norm1.body.bias"])
+        w[fe + "conv_hl"] = K.pack_conv_hilo(sd[fe + "conv.weight"], sd[fe + "conv.bias"], True)     # split-fp16 form for conv_ring
         pc("upconv1_L2", shuffle2=True)
         pc("upconv2", shuffle2=True)
         dev = sd["conv_first.weight"].device
@@ -182,6 +183,12 @@ class CVSR_V7(nn.Module):
             x2 = K.spatial_gate(x2, raw[p + "SA.spatial.weight"], raw[p + "SA.spatial.bias"])
             v, part, n = K.qkv_dw(x1, w[p + "qkv_dw"], raw[p + "attn.qkv_dwconv.weight"], gram=True)
             fold = K.mdta_fold(part, n, raw[p + "attn.temperature"], raw[p + "attn.project_out.weight"])
+            if self.precision == "fp16x2":
+                # as in CVSR_V8: norm2 of the result leaves the 1x1 kernel as fp16 hi | lo planes, and the 3x3 convolution runs as a
+                # split-fp16, fp32-grade product (a_hi*w_hi + a_lo*w_hi + a_hi*w_lo) on the LDS-DMA ring kernel
+                x1, ln = self._conv(v, fold, res1=x1, res2=x2, ln_out=(raw[p + "norm2.body.weight"], raw[p + "norm2.body.bias"]))
+                x1 = K.conv_ring(ln, w[p + "conv_hl"], res1=x1, plane_wrap=8)
+                continue
             x1 = self._conv(v, fold, res1=x1, res2=x2)
             ln = K.layernorm64(x1, raw[p + "norm2.body.weight"], raw[p + "norm2.body.bias"])
             x1 = self._conv(ln, w[p + "conv"], pad=1, res1=x1, exact=True)

@@ -228,6 +228,33 @@ def _vp(t):
     return C.c_void_p(None if t is None else t.data_ptr())
 
 
+def conv_offset_mask(src: torch.Tensor, pc: PackedConv, offset: torch.Tensor, mask: torch.Tensor, flow: torch.Tensor, mag: float,
+                     accumulate: bool, prec: int) -> None:
+    """MVDualAttAlignment's conv_offset[2] (3x3, 64 -> 27 dg) with the module's offset / mask assembly (arch.py:3336-3350) as its
+    epilogue (CDFO_STORE_OFFMASK): src pixel-major [B,H,W,64]; offset [B,18 dg,H,W] / mask [B,9 dg,H,W] NCHW = the DCN operator's
+    inputs; flow [B,2,H,W] contiguous.  accumulate=False: the first head (offset = mag tanh + flipped flow, mask = raw sums);
+    accumulate=True: the second head in place (offset += mag tanh, mask = sigmoid(mask + sums)).  W % 4 == 0, 16-bit modes only."""
+    B, H, W, Cc, ld = _chk_act(src)
+    third = pc.Cout // 3
+    if (pc.ks != 3 or Cc != pc.Cin or pc.Cout % 3 or pc.wq is None or W % 4 or prec not in (PREC_BF16X3, PREC_FP16X2, PREC_FP16X1)
+            or tuple(offset.shape) != (B, 2 * third, H, W) or tuple(mask.shape) != (B, third, H, W) or tuple(flow.shape) != (B, 2, H, W)
+            or not (offset.is_contiguous() and mask.is_contiguous() and flow.is_contiguous())
+            or any(t.dtype != torch.float32 for t in (offset, mask, flow))):
+        raise ValueError("conv_offset_mask: unsupported configuration")
+    a = ConvArgs()
+    a.src[0], a.ld[0], a.cs[0], a.nsrc = src.data_ptr(), ld, Cc, 1
+    a.B, a.H, a.W, a.Ho, a.Wo = B, H, W, H, W
+    a.ks, a.stride, a.pad = 3, 1, 1
+    a.Cin, a.Cout, a.CoutP = pc.Cin, pc.Cout, pc.CoutP16
+    a.w = (pc.wh if prec in (PREC_FP16X2, PREC_FP16X1) else pc.wq).data_ptr()
+    a.bias = _p(pc.bias)
+    a.act, a.prec, a.store_mode = ACT_NONE, prec, 4
+    a.out, a.ldo = offset.data_ptr(), 4
+    a.mask_out, a.flow, a.flow_bstride = mask.data_ptr(), flow.data_ptr(), 2 * H * W
+    a.off_mag, a.off_accumulate = float(mag), int(accumulate)
+    check(_lib.lib().cdfo_conv3x3_bf16(C.byref(a), _stream()), "cdfo_conv3x3_bf16 (offset / mask epilogue)")
+
+
 def pack_conv_n16(weight: torch.Tensor) -> torch.Tensor:
     """[16, 64, 3, 3] fp32 -> the bf16 hi | lo image of cdfo_conv3x3_c64_n16: [18 K steps = tap*2 + half][hi|lo][lane = kg*16 + m][8]
     with element j = W[m][32 half + 8 kg + j][tap] (parameter-sized torch arithmetic, once per weight version)."""
@@ -755,6 +782,21 @@ def mdta_fold(part: torch.Tensor, n: int, temperature: torch.Tensor, proj_w: tor
     check(_lib.lib().cdfo_mdta_fold(_vp(part), n, _vp(temperature), _vp(proj_w), B, _vp(wout), _stream()),
           "cdfo_mdta_fold")
     return PackedConv(wout, None, 64, 64, 1, 64, False, 4096)
+
+
+_FOLD_CIN = {}
+
+
+def fold_scale_inputs(fold: PackedConv, gate: torch.Tensor) -> PackedConv:
+    """The per-image 64 x 64 matrices of mdta_fold with a per-image input-channel gate folded in: M'[b] = M[b] diag(gate[b]), so that
+    conv(x * gate, M) == conv(x, M') and the gated copy of x is never written (parameter-sized torch arithmetic on [B, 4096])."""
+    if fold.Cin != 64 or fold.Cout != 64 or fold.ks != 1 or fold.w_bstride != 4096 or tuple(gate.shape) != (fold.w.shape[0], 64):
+        raise ValueError("fold_scale_inputs: a mdta_fold result and a [B, 64] gate expected")
+    cin = _FOLD_CIN.get(gate.device)
+    if cin is None:       # packed layout [Cin/16][4][CoutP = 64][4]: input channel of every element
+        i = torch.arange(4096, device=gate.device)
+        cin = _FOLD_CIN[gate.device] = (i // 1024) * 16 + ((i // 256) % 4) * 4 + i % 4
+    return PackedConv(fold.w * gate[:, cin], None, 64, 64, 1, 64, False, 4096)
 
 
 def align_fold(gpart, ng, sw, sp, ns, P, temperature, du0_w, du0_b, du2_w, du2_b, proj_w, fusion_w) -> PackedConv:

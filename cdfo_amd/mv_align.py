@@ -11,6 +11,7 @@ trains like the reference's; the folded inference schedule is used under ``torch
 from __future__ import annotations
 
 import ctypes as C
+import os
 
 import torch
 import torch.nn as nn
@@ -45,6 +46,8 @@ class MVDualAttAlignment(ModulatedDeformConvPack):
         # arithmetic of the 64->64->432 offset/mask head (the module's FLOPs): "bf16x3" = split-bf16 matrix cores,
         # fp32-grade (~1e-6 relative; the head's output is scaled by 10 px, so nothing coarser), or "f32" = exact
         self.precision = "bf16x3"
+        self.fuse_assembly = os.environ.get("CDFO_V7_FUSE_ASSEMBLY", "1") != "0"      # developer A/B switches
+        self.head_one_pass = os.environ.get("CDFO_V7_HEAD_1PASS", "1") != "0"
         self._packed = None
         self._sig = None
 
@@ -108,24 +111,35 @@ class MVDualAttAlignment(ModulatedDeformConvPack):
         d = lambda t: t.detach().contiguous()  # noqa: E731
         prec = {"bf16x3": K.PREC_BF16X3, "fp16x2": K.PREC_FP16X2}.get(self.precision, K.PREC_F32)
         warped = K.flow_warp(extra, flow, 2 * P)
-        fused = K.conv([warped, pred], w["fusion"])                      # no activation here (arch.py:3305)
+        p1 = K.PREC_F32 if prec == K.PREC_F32 else K.PREC_BF16X3        # the 1x1 convolutions: split-bf16 (fp32-grade) on the matrix cores
+        fused = K.conv([warped, pred], w["fusion"], prec=p1)             # no activation here (arch.py:3305)
         gp, ng = K.gram_partial(xq, fused, 8)
         fold = K.mdta_fold(gp, ng, d(self.temperature), d(self.project_out.weight))   # P . blockdiag(softmax)
-        outs = []
-        for v in (warped, pred):
-            part, n = K.chan_sum_partial(v)
-            gate = K.vec_mlp(part, n, P, d(self.conv_du[0].weight), d(self.conv_du[0].bias), self.out_channels // 16,
-                             K.ACT_RELU, d(self.conv_du[2].weight), d(self.conv_du[2].bias), 64, K.ACT_SIGMOID)
-            o = K.conv(K.scale_channels(v, gate), fold)                   # project_out(attn @ (v * gate))
-            o = K.conv(o, w["off0"], pad=1, act=K.ACT_LRELU, prec=prec)
-            outs.append(K.conv(o, w["off2"], pad=1, prec=prec))           # [B,H,W,27*dg]
         third = 9 * self.deformable_groups
         offset = torch.empty((B, 2 * third, H, W), dtype=torch.float32, device=x.device)
         mask = torch.empty((B, third, H, W), dtype=torch.float32, device=x.device)
-        vp = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
-        check(_lib.lib().cdfo_mv_offset_mask(vp(outs[0]), vp(outs[1]), outs[0].stride(2), vp(flow), C.c_longlong(2 * P),
-                                             B, C.c_longlong(P), third, float(self.max_residue_magnitude), vp(offset),
-                                             vp(mask), K._stream()), "cdfo_mv_offset_mask")
+        # the 16-bit head writes the DCN's NCHW offset / mask planes from its own epilogue (first head: tanh + flow / raw mask sums,
+        # second head: in-place accumulate + sigmoid); the exact-fp32 head and widths that are no multiple of 4 assemble separately
+        fused = self.fuse_assembly and prec != K.PREC_F32 and W % 4 == 0
+        outs = []
+        for n_head, v in enumerate((warped, pred)):
+            part, n = K.chan_sum_partial(v)
+            gate = K.vec_mlp(part, n, P, d(self.conv_du[0].weight), d(self.conv_du[0].bias), self.out_channels // 16,
+                             K.ACT_RELU, d(self.conv_du[2].weight), d(self.conv_du[2].bias), 64, K.ACT_SIGMOID)
+            o = K.conv(v, K.fold_scale_inputs(fold, gate), prec=p1)       # project_out(attn @ (v * gate)), the gate folded into the matrix
+            o = K.conv(o, w["off0"], pad=1, act=K.ACT_LRELU, prec=prec)
+            if fused:
+                # fp16x2: the head's weights are rounded once to fp16 in that mode; rounding its input once as well (one MFMA pass
+                # instead of two) adds an error of the same size -- CVSR_V7's parity moves inside its 10x margin
+                hp = K.PREC_FP16X1 if (prec == K.PREC_FP16X2 and self.head_one_pass) else prec
+                K.conv_offset_mask(o, w["off2"], offset, mask, flow, self.max_residue_magnitude, n_head == 1, hp)
+            else:
+                outs.append(K.conv(o, w["off2"], pad=1, prec=prec))       # [B,H,W,27*dg]
+        if not fused:
+            vp = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
+            check(_lib.lib().cdfo_mv_offset_mask(vp(outs[0]), vp(outs[1]), outs[0].stride(2), vp(flow), C.c_longlong(2 * P),
+                                                 B, C.c_longlong(P), third, float(self.max_residue_magnitude), vp(offset),
+                                                 vp(mask), K._stream()), "cdfo_mv_offset_mask")
         out = torch.empty((B, self.out_channels, H, W), dtype=torch.float32, device=x.device)
         deform_conv_cuda.modulated_deform_conv_cuda_forward(
             x, d(self.weight), None if self.bias is None else d(self.bias), None, offset, mask, out, None,

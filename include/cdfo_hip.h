@@ -24,7 +24,7 @@ extern "C" {
 #define CDFO_MAXSRC 8
 
 enum { CDFO_ACT_NONE = 0, CDFO_ACT_LRELU = 1, CDFO_ACT_RELU = 2, CDFO_ACT_SIGMOID = 3 };
-enum { CDFO_STORE_PLAIN = 0, CDFO_STORE_SHUFFLE2 = 1, CDFO_STORE_S2D = 2, CDFO_STORE_TAPS9 = 3 };
+enum { CDFO_STORE_PLAIN = 0, CDFO_STORE_SHUFFLE2 = 1, CDFO_STORE_S2D = 2, CDFO_STORE_TAPS9 = 3, CDFO_STORE_OFFMASK = 4 };
 enum { CDFO_DTYPE_F32 = 0, CDFO_DTYPE_F16 = 1, CDFO_DTYPE_F64 = 2 };   /* element type tag of the *_dt entry points */
 enum { CDFO_PREC_F32 = 0, CDFO_PREC_BF16X3 = 1, CDFO_PREC_BF16 = 2, CDFO_PREC_FP16X2 = 3, CDFO_PREC_FP16 = 4, CDFO_PREC_FP16X1 = 5 };
 
@@ -62,7 +62,15 @@ typedef struct {
                                  added after bilinear x2 up-sampling (align_corners=False), i.e. Block_'s x1/2 branch */
   int out2_lo;                /* cdfo_conv3x3_ring with out2_cp16: the copy is hi | lo planes [B][2*Cout/16][H][W][16] (fp16(v), then
                                  fp16(v - fp16(v))): the source of a split-fp16 convolution on the same kernel */
+  /* CDFO_STORE_OFFMASK (cdfo_conv3x3_bf16 only, Cout = 3 * third, Wo % 4 == 0, no activation / residuals): the convolution is
+   * MVDualAttAlignment's conv_offset[2] and its epilogue is the module's offset / mask assembly (arch/SIDECVSR_our.py:3336-3350),
+   * written straight into the DCN operator's NCHW inputs -- out = offset [B][2*third][Ho][Wo], mask_out = mask [B][third][Ho][Wo]:
+   *   off_accumulate == 0 (the first of the two heads):  offset[k] = off_mag * tanh(v[k]) + flow[b][1 - (k & 1)],  mask[k] = v[2*third + k]
+   *   off_accumulate != 0 (the second head, in place):    offset[k] += off_mag * tanh(v[k]),  mask[k] = sigmoid(mask[k] + v[2*third + k])
+   * flow: the motion field [B][2][Ho][Wo], image pitch flow_bstride floats (read by the first head only).  */
+  float* mask_out; const float* flow; long long flow_bstride; float off_mag; int off_accumulate;
 } cdfo_conv_args;
+int cdfo_sizeof_conv_args(void);   /* sizeof(cdfo_conv_args) as the library was built: a binding checks its own mirror against it */
 int cdfo_conv_igemm(const cdfo_conv_args* a, void* stream);
 
 /* Pack an OIHW fp32 weight [Cout][Cin][ks][ks] (device) into the layout cdfo_conv_igemm reads:

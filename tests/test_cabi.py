@@ -18,6 +18,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(raw, name), f"{name} declared in include/cdfo_hip.h but not exported"
     lib = _lib.lib()
     assert lib.cdfo_abi_version() == 1
+    assert lib.cdfo_sizeof_conv_args() == C.sizeof(_lib.ConvArgs)          # the ctypes mirror and the header agree field by field
     assert b"gfx950" in lib.cdfo_build_info()
 
 

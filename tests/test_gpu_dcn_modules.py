@@ -105,3 +105,47 @@ def test_hip_modules_train_like_the_reference_classes(path):
     print(f"{kind}: {len(rows)} gradient tensors vs float64 oracle autograd: HIP median {np.median(e_hip):.2e} (float32 CPU oracle "
           f"{np.median(e_cpu):.2e}), worst {rows[0][0]:.2e} ({rows[0][2]}; float32 oracle there {rows[0][1]:.2e})")
     assert np.median(e_hip) <= 1e-4 and e_hip.max() <= 5e-3, rows[:5]
+
+
+@pytest.mark.parametrize("prec_name", ["bf16x3", "fp16x2"])
+@pytest.mark.parametrize("shape", [(2, 24, 36), (1, 37, 64), (3, 8, 100)])
+def test_offset_head_with_the_assembly_as_its_epilogue(shape, prec_name):
+    """conv_offset[2] writing the DCN's NCHW offset / mask planes from its own epilogue (CDFO_STORE_OFFMASK; first head, then the
+    second head in place) == the same convolution followed by the stand-alone assembly kernel (arch.py:3336-3350); ragged tiles
+    (H % 8, W % 32 != 0), a 432-channel head whose offset / mask boundary (288) falls inside a 64-channel block."""
+    import ctypes as C
+    from cdfo_amd import _lib
+    from cdfo_amd import kernels as K
+    B, H, W = shape
+    g = torch.Generator(device="cuda").manual_seed(B * 1000 + H)
+    dg, mag = 16, 10.0
+    third = 9 * dg
+    wt = torch.randn(27 * dg, 64, 3, 3, device="cuda", generator=g) / 24
+    bs = torch.randn(27 * dg, device="cuda", generator=g) * 0.1
+    pc = K.pack_conv(wt, bs)
+    o1, o2 = (torch.randn(B, H, W, 64, device="cuda", generator=g) for _ in range(2))
+    flow = torch.randn(B, 2, H, W, device="cuda", generator=g) * 3
+    prec = {"bf16x3": K.PREC_BF16X3, "fp16x2": K.PREC_FP16X2}[prec_name]
+    h1, h2 = (K.conv(o, pc, pad=1, prec=prec) for o in (o1, o2))
+    off_ref = torch.empty(B, 2 * third, H, W, device="cuda")
+    mask_ref = torch.empty(B, third, H, W, device="cuda")
+    vp = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
+    _lib.check(_lib.lib().cdfo_mv_offset_mask(vp(h1), vp(h2), h1.stride(2), vp(flow), C.c_longlong(2 * H * W), B, C.c_longlong(H * W),
+                                              third, mag, vp(off_ref), vp(mask_ref), K._stream()), "cdfo_mv_offset_mask")
+    off = torch.full_like(off_ref, float("nan"))
+    mask = torch.full_like(mask_ref, float("nan"))
+    K.conv_offset_mask(o1, pc, off, mask, flow, mag, False, prec)
+    K.conv_offset_mask(o2, pc, off, mask, flow, mag, True, prec)
+    assert torch.isfinite(off).all() and torch.isfinite(mask).all()
+    assert (off - off_ref).abs().max().item() < 2e-5          # 10 px * (tanh through v_exp / v_rcp) and a different summation order
+    assert (mask - mask_ref).abs().max().item() < 2e-6
+    # and against float64 arithmetic on the module's formula
+    ref64 = lambda o: torch.nn.functional.conv2d(o.permute(0, 3, 1, 2).double(), wt.double(), bs.double(), padding=1)  # noqa: E731
+    r1, r2 = ref64(o1), ref64(o2)
+    off64 = mag * torch.tanh(r1[:, :2 * third]) + mag * torch.tanh(r2[:, :2 * third]) + flow.double().flip(1).repeat(1, third, 1, 1)
+    mask64 = torch.sigmoid(r1[:, 2 * third:] + r2[:, 2 * third:])
+    tol = 1e-3 if prec_name == "bf16x3" else 2e-2             # 10 px * the arithmetic's error (fp16x2 rounds the WEIGHTS once to fp16)
+    assert (off.double() - off64).abs().max().item() < tol and (mask.double() - mask64).abs().max().item() < tol / 10
+    with pytest.raises(ValueError):
+        K.conv_offset_mask(o1[:, :, :W - 2], pc, off[..., :W - 2].contiguous(), mask[..., :W - 2].contiguous(),
+                           flow[..., :W - 2].contiguous(), mag, False, prec)       # W % 4 != 0: the caller assembles separately

@@ -292,11 +292,13 @@ extern "C" int cdfo_conv1x1_bf16x3(const cdfo_conv_args* pa, void* stream) {
   if ((a.res1 && (a.ldr1 % 4 || !aligned16(a.res1))) || (!taps && a.res2 && (a.ldr2 % 4 || !aligned16(a.res2)))) return CDFO_EALIGN;
   if (!ln_out && a.ln_gamma && !(a.nsrc == 1 && a.cs[0] == 64 && a.ln_beta && aligned16(a.ln_gamma) && aligned16(a.ln_beta))) return CDFO_EINVAL;
   const long long P = (long long)a.H * a.W;
+  if (a.res2_pixscale && (!a.res2 || taps)) return CDFO_EINVAL;
   if (ln_out) {
     // the streaming kernel normalises in its epilogue; outside its contract: the convolution, then a LayerNorm pass
     const int r = cdfo_conv1x1_stream_try(a, st);
     if (r == 1) return 0;
     if (r != 0) return r;
+    if (a.res2_pixscale) return CDFO_EINVAL;      // only the streaming form scales its residual
     cdfo_conv_args plain = a;
     plain.out2_cp16 = nullptr; plain.ln_gamma = nullptr; plain.ln_beta = nullptr;
     const int rc = cdfo_conv1x1_bf16x3(&plain, stream);
@@ -312,6 +314,7 @@ extern "C" int cdfo_conv1x1_bf16x3(const cdfo_conv_args* pa, void* stream) {
       if (r != 0) return r;
     }
   }
+  if (a.res2_pixscale) return CDFO_EINVAL;        // only the streaming form scales its residual
   dim3 grid((unsigned)((P + PXT - 1) / PXT), a.B);
   const double px = (double)a.B * P;
   CdfoProfScope prof(st, KID_CONV1, 2.0 * px * a.Cout * a.Cin, 4.0 * (px * a.Cout + px * a.Cin + (double)a.Cin * a.Cout));

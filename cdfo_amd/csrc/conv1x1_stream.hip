@@ -39,6 +39,7 @@ struct st_args {
   st_item act[CDFO_MAXSRC * 4];    // K blocks in order (<= 12 used: Cin <= 768 guarded by the LDS test anyway)
   int nkb;
   st_item res[2];                  // residual operands (ch0 = 0), res[i].base == nullptr: absent
+  const float* res_scale;          // optional per-pixel factor [B][P] of the LAST residual operand (a spatial gate folded into the add)
   const float* w; long long w_bstride; const float* bias;
   int Cin, Cout, CoutP, act_fn;
   float* out; int ldo;
@@ -91,6 +92,20 @@ __device__ __forceinline__ void st_dma8(const unsigned (&voff)[8], i32x4 rsrc, u
       : "memory", "scc");
 }
 
+// one dword per lane: lane l writes LDS bytes lds + 4 l from (buffer base + voff)
+__device__ __forceinline__ void st_dma1(unsigned voff, i32x4 rsrc, unsigned lds) {
+  unsigned keep;
+  asm volatile(
+      "s_nop 4\n\t"
+      "s_mov_b32 %0, m0\n\t"
+      "s_mov_b32 m0, %3\n\ts_nop 0\n\t"
+      "buffer_load_dword %1, %2, 0 offen lds\n\t"
+      "s_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(voff), "s"(rsrc), "s"(lds)
+      : "memory", "scc");
+}
+
 // two fp32 -> packed fp16 hi and packed fp16 lo = fp16(v - hi): v_cvt_pk_f16_f32, two v_fma_mix_f32 (exact remainders, the fp16
 // operand read from its half of the packed register), v_cvt_pk_f16_f32 (see attention.hip: full-register results only)
 __device__ __forceinline__ void st_split_pair_f16(float x, float y, unsigned& hi, unsigned& lo) {
@@ -120,6 +135,9 @@ __global__ __launch_bounds__(ST_THREADS) void conv1x1_stream_kernel(st_args a) {
   const int ring_off = 2 * w_half + NCB * 64 * 4;
   unsigned char* ring = smem + ring_off + wave * NS * ST_STAGE;
   const unsigned ring_lds = (unsigned)(unsigned long long)(smem) + ring_off + wave * NS * ST_STAGE;
+  // res_scale: two 256-byte slots per wave (tile parity) behind the rings
+  const unsigned char* scale_slots = smem + ring_off + 4 * NS * ST_STAGE + wave * 512;
+  const unsigned scale_lds = (unsigned)(unsigned long long)(smem) + ring_off + 4 * NS * ST_STAGE + wave * 512;
 
   // MFMA row m of a 32-channel block holds channel (m>>4)*16 + ((m>>2)&1)*8 + ((m>>3)&1)*4 + (m&3) (see conv3x3_ws.hip):
   // a lane's accumulator registers then are 8 consecutive channels of each 16-channel group
@@ -193,6 +211,20 @@ __global__ __launch_bounds__(ST_THREADS) void conv1x1_stream_kernel(st_args a) {
       const long long tile = img_t0 + it / items_per_tile;
       const int k = (int)(it % items_per_tile);
       const long long p0 = (tile - (long long)b * a.tiles_per_image) * 128 + wave * 32;      // first pixel (inside image b)
+      if (a.res_scale && k == 0) {
+        // the tile's per-pixel residual factors: one more LDS-DMA piece (lane l -> dword l of the tile-parity slot), requested AHEAD
+        // of the tile's first item.  An ordinary load would be waited for with vmcnt(0) at its use and drain the ring; memory
+        // operations retire in order, so the slot is valid once any item of this tile has landed (the hand-counted waits below,
+        // which one more older piece only makes more conservative).
+        const long long rows = a.P - p0;
+        const unsigned long long pb = reinterpret_cast<unsigned long long>(a.res_scale + (long long)b * a.P + (rows > 0 ? p0 : 0));
+        i32x4 rs;
+        rs[0] = __builtin_amdgcn_readfirstlane((int)(unsigned)pb);
+        rs[1] = __builtin_amdgcn_readfirstlane((int)(unsigned)(pb >> 32));
+        rs[2] = __builtin_amdgcn_readfirstlane((int)(rows > 0 ? (rows < 32 ? rows : 32) * 4 : 0));      // beyond the image: zeros
+        rs[3] = 0x00020000;
+        st_dma1((unsigned)r * 4, rs, __builtin_amdgcn_readfirstlane(scale_lds + (unsigned)(tile & 1) * 256));
+      }
       st_item src;
       int chan0;
       if (k < nkb) { src = a.act[k]; chan0 = src.ch0; }
@@ -280,6 +312,9 @@ __global__ __launch_bounds__(ST_THREADS) void conv1x1_stream_kernel(st_args a) {
       } else {
         // ---- a residual stage: 64 channels of block cb of the tile's residual operand
         const int cb = (k - nkb) % NCB;
+        float sc = 1.f;
+        if (a.res_scale && (k - nkb) / NCB == nres - 1)
+          sc = *reinterpret_cast<const float*>(scale_slots + ((img_t0 + it / items_per_tile) & 1) * 256 + lane * 4);
 #pragma unroll
         for (int cc = 0; cc < NCB; ++cc) {
           if (cc != cb) continue;
@@ -291,7 +326,7 @@ __global__ __launch_bounds__(ST_THREADS) void conv1x1_stream_kernel(st_args a) {
               const f32x4 r0 = *reinterpret_cast<const f32x4*>(st + part_off(q));
               const f32x4 r1 = *reinterpret_cast<const f32x4*>(st + part_off(q + 1));
 #pragma unroll
-              for (int e = 0; e < 4; ++e) { acc[cc][ni][8 * jj + e] += r0[e]; acc[cc][ni][8 * jj + 4 + e] += r1[e]; }
+              for (int e = 0; e < 4; ++e) { acc[cc][ni][8 * jj + e] = fmaf(sc, r0[e], acc[cc][ni][8 * jj + e]); acc[cc][ni][8 * jj + 4 + e] = fmaf(sc, r1[e], acc[cc][ni][8 * jj + 4 + e]); }
             }
         }
       }
@@ -445,7 +480,8 @@ int cdfo_conv1x1_stream_try(const cdfo_conv_args& a, hipStream_t st) {
   const int ncb = a.CoutP / 64, nkb = a.Cin / 64;
   if (nkb < 1 || nkb > CDFO_MAXSRC * 4) return 0;
   const int w_bytes = 2 * nkb * 4 * 2 * ncb * 64 * 16 + ncb * 64 * 4;
-  int ns = (160 * 1024 - 256 - w_bytes) / (4 * ST_STAGE);
+  const int scale_bytes = (a.res2 && a.res2_pixscale) ? 4 * 512 : 0;      // two tile-parity slots per wave
+  int ns = (160 * 1024 - 256 - scale_bytes - w_bytes) / (4 * ST_STAGE);
   if (ns > ST_MAXNS) ns = ST_MAXNS;
   if (ns < 3) return 0;
   const long long P = (long long)a.H * a.W;
@@ -462,6 +498,7 @@ int cdfo_conv1x1_stream_try(const cdfo_conv_args& a, hipStream_t st) {
   int nr = 0;
   if (a.res1) { if (a.ldr1 < a.CoutP) return 0; s.res[nr].base = a.res1; s.res[nr].ld = a.ldr1; ++nr; }
   if (a.res2) { if (a.ldr2 < a.CoutP) return 0; s.res[nr].base = a.res2; s.res[nr].ld = a.ldr2; ++nr; }
+  s.res_scale = a.res2 ? a.res2_pixscale : nullptr;
   s.w = a.w; s.w_bstride = a.w_bstride; s.bias = a.bias;
   s.Cin = a.Cin; s.Cout = a.Cout; s.CoutP = a.CoutP; s.act_fn = a.act;
   s.out = a.out; s.ldo = a.ldo; s.B = a.B; s.P = P;
@@ -472,7 +509,7 @@ int cdfo_conv1x1_stream_try(const cdfo_conv_args& a, hipStream_t st) {
   const int cus = cdfo_num_cus();
   if (cus <= 0) return CDFO_EINVAL;
   const int grid = (int)(s.tiles < cus ? s.tiles : cus);
-  const int lds = w_bytes + 4 * ns * ST_STAGE;
+  const int lds = w_bytes + 4 * ns * ST_STAGE + scale_bytes;
   const double px = (double)a.B * P;
   CdfoProfScope prof(st, KID_CONV1, 2.0 * px * a.Cout * a.Cin, 4.0 * (px * a.Cout * (1 + nr) + px * a.Cin + (double)a.Cin * a.Cout));
   if (ncb == 1) {

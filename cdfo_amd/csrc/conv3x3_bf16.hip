@@ -86,38 +86,46 @@ __device__ __forceinline__ float fast_sigmoid(float x) {
   return __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(x * -1.4426950408889634f));
 }
 template <int NT>
-__device__ __forceinline__ void offmask_epilogue(const cdfo_conv_args& a, const f32x16 (*acc)[NT], int lane, int b, int oyb, int ox0,
-                                                 int n0) {
-  const int h = lane >> 5, r = lane & 31;
-  const int third = a.Cout / 3;
-  const long long P = (long long)a.Ho * a.Wo;
+struct OffmaskLane {             // what a lane of the 32x32 accumulators owns in the offset / mask planes
   float* plane[NT];
   const float* prior[NT];        // what a run starts from: the flipped motion field (first head) or the plane itself (second head)
   float bias[NT];
   bool live[NT], is_off[NT];
+  f32x4 pv[NT][2][4];            // the prior values of the lane's 16 runs
+};
+
+// Requests every read of the epilogue.  Called ahead of the stores (they may alias the loads as far as the compiler knows: a
+// load -> tanh -> store loop would pay one memory latency per run) -- in the single-pass mode ahead of the LAST chunk's MFMAs,
+// which cover the latency of the second head's 1.8 GB read-modify-write.
+template <int NT>
+__device__ __forceinline__ void offmask_prefetch(const cdfo_conv_args& a, OffmaskLane<NT>& L, int lane, int b, int oyb, int ox0, int n0) {
+  const int h = lane >> 5, r = lane & 31;
+  const int third = a.Cout / 3;
+  const long long P = (long long)a.Ho * a.Wo;
 #pragma unroll
   for (int ni = 0; ni < NT; ++ni) {
     const int c = n0 + ni * 32 + r;
-    live[ni] = c < a.Cout;
-    is_off[ni] = c < 2 * third;
-    bias[ni] = (a.bias && live[ni]) ? a.bias[c] : 0.f;
-    plane[ni] = is_off[ni] ? a.out + ((long long)b * 2 * third + c) * P : a.mask_out + ((long long)b * third + (c - 2 * third)) * P;
-    prior[ni] = a.off_accumulate ? plane[ni]
-                                 : (is_off[ni] ? a.flow + b * a.flow_bstride + (long long)(1 - (c & 1)) * P : nullptr);   // flip(1)
-  }
-  // every read of the epilogue is requested before the first store: the stores may alias the loads as far as the compiler knows,
-  // so a load -> tanh -> store loop would pay one memory latency per run (16 per lane)
-  f32x4 pv[NT][2][4];
-#pragma unroll
-  for (int ni = 0; ni < NT; ++ni)
+    L.live[ni] = c < a.Cout;
+    L.is_off[ni] = c < 2 * third;
+    L.bias[ni] = (a.bias && L.live[ni]) ? a.bias[c] : 0.f;
+    L.plane[ni] = L.is_off[ni] ? a.out + ((long long)b * 2 * third + c) * P : a.mask_out + ((long long)b * third + (c - 2 * third)) * P;
+    L.prior[ni] = a.off_accumulate ? L.plane[ni]
+                                   : (L.is_off[ni] ? a.flow + b * a.flow_bstride + (long long)(1 - (c & 1)) * P : nullptr);   // flip(1)
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const int oy = oyb + mi, x = ox0 + 8 * j + 4 * h;
-        pv[ni][mi][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (live[ni] && prior[ni] && oy < a.Ho && x < a.Wo) pv[ni][mi][j] = *reinterpret_cast<const f32x4*>(prior[ni] + oy * a.Wo + x);
+        L.pv[ni][mi][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (L.live[ni] && L.prior[ni] && oy < a.Ho && x < a.Wo) L.pv[ni][mi][j] = *reinterpret_cast<const f32x4*>(L.prior[ni] + oy * a.Wo + x);
       }
+  }
+}
+
+template <int NT>
+__device__ __forceinline__ void offmask_finish(const cdfo_conv_args& a, const OffmaskLane<NT>& L, const f32x16 (*acc)[NT], int lane,
+                                               int oyb, int ox0) {
+  const int h = lane >> 5;
 #pragma unroll
   for (int ni = 0; ni < NT; ++ni)
 #pragma unroll
@@ -125,15 +133,15 @@ __device__ __forceinline__ void offmask_epilogue(const cdfo_conv_args& a, const 
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const int oy = oyb + mi, x = ox0 + 8 * j + 4 * h;      // Wo % 4 == 0: a run of four pixels is inside the row or outside it
-        if (!live[ni] || oy >= a.Ho || x >= a.Wo) continue;
-        f32x4 res = pv[ni][mi][j];
+        if (!L.live[ni] || oy >= a.Ho || x >= a.Wo) continue;
+        f32x4 res = L.pv[ni][mi][j];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-          const float v = acc[mi][ni][4 * j + k] + bias[ni];
-          if (is_off[ni]) res[k] += a.off_mag * fast_tanh(v);
+          const float v = acc[mi][ni][4 * j + k] + L.bias[ni];
+          if (L.is_off[ni]) res[k] += a.off_mag * fast_tanh(v);
           else res[k] = a.off_accumulate ? fast_sigmoid(res[k] + v) : v;
         }
-        *reinterpret_cast<f32x4*>(plane[ni] + oy * a.Wo + x) = res;
+        *reinterpret_cast<f32x4*>(L.plane[ni] + oy * a.Wo + x) = res;
       }
 }
 
@@ -296,10 +304,18 @@ __global__ __launch_bounds__(256, WAVES_PER_SIMD) void conv3x3_mma16_kernel(cdfo
       }
   };
 
+  constexpr bool OFFMASK_OK = (MODE == M_BF16X3 || MODE == M_FP16X2 || MODE == M_FP16X1) && NT == 2 && DBG == 0;
+  constexpr bool OFFMASK_EARLY = OFFMASK_OK && MODE == M_FP16X1;     // the mode with the registers for it
+  const bool offmask = OFFMASK_OK && a.store_mode == CDFO_STORE_OFFMASK;
+  OffmaskLane<NT> om;
+
   issue_loads(0);
   write_lds();
   __syncthreads();
-  for (int c = 0; c < nchunks; ++c) {
+  // the single-pass offset head runs its last chunk outside the loop (below): the staging registers are dead there, which is
+  // what lets the epilogue's reads be requested ahead of that chunk's MFMAs without spilling
+  const int nmain = (OFFMASK_EARLY && offmask) ? nchunks - 1 : nchunks;
+  for (int c = 0; c < nmain; ++c) {
     // two waves per SIMD: next chunk's operands travel in registers while the MFMAs below run; with three waves per
     // SIMD the registers are not there (168 budget) and the other workgroups cover the latency instead
     if (WAVES_PER_SIMD <= 2 && c + 1 < nchunks && !(DBG & 2)) issue_loads(c + 1);
@@ -335,6 +351,16 @@ __global__ __launch_bounds__(256, WAVES_PER_SIMD) void conv3x3_mma16_kernel(cdfo
       if (!(DBG & 16)) __syncthreads();
     }
   }
+  if (OFFMASK_EARLY && offmask) {
+    offmask_prefetch<NT>(a, om, lane, b, oy0 + wave * 2, ox0, n0);
+    load_frags(0, 0);
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      if (t < 8) load_frags(t + 1, (t & 1) ^ 1);
+      mma_tap(t & 1);
+    }
+    __syncthreads();
+  }
 
   // ---- epilogue (identical contract to conv_igemm_f32) through a wave-private LDS transpose; the loop above ends
   // with a __syncthreads(), so the staged operands are dead
@@ -349,8 +375,9 @@ __global__ __launch_bounds__(256, WAVES_PER_SIMD) void conv3x3_mma16_kernel(cdfo
     if (t == 123.456f) a.out[0] = t;
     return;
   }
-  if ((MODE == M_BF16X3 || MODE == M_FP16X2 || MODE == M_FP16X1) && NT == 2 && DBG == 0 && a.store_mode == CDFO_STORE_OFFMASK) {
-    offmask_epilogue<NT>(a, acc, lane, b, oy0 + wave * 2, ox0, n0);
+  if (offmask) {
+    if (!OFFMASK_EARLY) offmask_prefetch<NT>(a, om, lane, b, oy0 + wave * 2, ox0, n0);
+    offmask_finish<NT>(a, om, acc, lane, oy0 + wave * 2, ox0);
     return;
   }
   float* wl = reinterpret_cast<float*>(smem) + wave * ConvEpi<NT>::WAVE_FLOATS;
@@ -391,7 +418,7 @@ extern "C" int cdfo_conv3x3_bf16(const cdfo_conv_args* pa, void* stream) {
   hipStream_t st = static_cast<hipStream_t>(stream);
   if (a.nsrc < 1 || a.nsrc > CDFO_MAXSRC || a.B <= 0 || a.ks != 3 || a.stride != 1 || a.pad != 1) return CDFO_EINVAL;
   if (a.act == CDFO_ACT_SIGMOID) return CDFO_EINVAL;   // conv epilogues support none / LeakyReLU / ReLU
-  if (a.out2_cp16 || a.res_up2 || a.src_plane_wrap) return CDFO_EINVAL;
+  if (a.out2_cp16 || a.res_up2 || a.src_plane_wrap || a.res2_pixscale) return CDFO_EINVAL;
   int csum = 0;
   for (int s = 0; s < a.nsrc; ++s) {
     if (a.cs[s] <= 0 || a.cs[s] % 16 || a.ld[s] % 4 || a.ld[s] < a.cs[s]) return CDFO_EINVAL;

@@ -1254,7 +1254,7 @@ extern "C" int cdfo_conv3x3_ring(const cdfo_conv_args* pa, void* stream) {
   if (a.nsrc != 1 || a.B <= 0 || a.ks != 3 || a.stride != 1 || a.pad != 1 || !a.src_f16) return CDFO_EINVAL;
   if (a.act == CDFO_ACT_SIGMOID || a.Cin <= 0 || a.Cin % 16 || a.cs[0] != a.Cin || a.ld[0] != 16) return CDFO_EINVAL;
   if (a.CoutP % 64 || a.CoutP > 1024 || a.CoutP < a.Cout || a.Cout <= 0 || a.Ho != a.H || a.Wo != a.W || a.w_bstride != 0) return CDFO_EINVAL;
-  if (a.store_mode != CDFO_STORE_PLAIN) return CDFO_EINVAL;
+  if (a.store_mode != CDFO_STORE_PLAIN || a.res2_pixscale) return CDFO_EINVAL;
   if (a.Cout % 8) return CDFO_EINVAL;
   if (a.out2_cp16 && (a.Cout % 16 || !aligned16(a.out2_cp16))) return CDFO_EINVAL;
   if (a.res_up2 && ((a.H | a.W) & 1 || a.ldru % 4 || a.ldru < a.Cout || !aligned16(a.res_up2))) return CDFO_EINVAL;

@@ -213,7 +213,7 @@ extern "C" int cdfo_conv_igemm(const cdfo_conv_args* pa, void* stream) {
   const cdfo_conv_args& a = *pa;
   hipStream_t st = static_cast<hipStream_t>(stream);
   if (a.nsrc < 1 || a.nsrc > CDFO_MAXSRC || a.B <= 0 || a.H <= 0 || a.W <= 0) return CDFO_EINVAL;
-  if (a.act == CDFO_ACT_SIGMOID || a.out2_cp16 || a.res_up2 || a.src_plane_wrap) return CDFO_EINVAL;   // conv epilogues support none / LeakyReLU / ReLU
+  if (a.act == CDFO_ACT_SIGMOID || a.out2_cp16 || a.res_up2 || a.src_plane_wrap || a.res2_pixscale) return CDFO_EINVAL;   // conv epilogues support none / LeakyReLU / ReLU
   int csum = 0;
   for (int s = 0; s < a.nsrc; ++s) {
     if (a.cs[s] <= 0 || a.cs[s] % 16 || a.ld[s] % 4 || a.ld[s] < a.cs[s]) return CDFO_EINVAL;

@@ -67,6 +67,38 @@ __global__ __launch_bounds__(256) void gate_map_kernel(const float* __restrict__
   gate[p] = 1.f / (1.f + __expf(-(s + bias[0])));
 }
 
+// The feature extractor applies ONE SpatialAttention (shared weights) to the same tensor once per round (arch.py:1350-1368):
+// x_k = x_{k-1} * g_k,  g_k = sigmoid(conv(pool(x_{k-1}))).  Every g is positive, so x_k = x_0 * G_k with the per-pixel product
+// G_k = g_1 ... g_k and pool(x_k) = G_k * pool(x_0) (max and mean commute with a positive per-pixel factor): the rounds only need
+// pool(x_0) and the plane G -- the gated 64-channel tensors are never written.  cum_out[p] = G_k[p] from cum_in = G_{k-1} (null: 1).
+__global__ __launch_bounds__(256) void gate_map_cum_kernel(const float* __restrict__ pooled, const float* __restrict__ cum_in,
+                                                           const float* __restrict__ w, const float* __restrict__ bias, int B, int H,
+                                                           int W, int ks, float* __restrict__ cum_out) {
+  const long long p = (long long)blockIdx.x * 256 + threadIdx.x, npix = (long long)B * H * W;
+  if (p >= npix) return;
+  const int b = (int)(p / ((long long)H * W));
+  const int rem = (int)(p - (long long)b * H * W), y = rem / W, x = rem - y * W;
+  const float* pl = pooled + (long long)b * H * W * 2;
+  const float* cm = cum_in ? cum_in + (long long)b * H * W : nullptr;
+  const int r = (ks - 1) / 2;
+  float s = 0.f;
+  for (int dy = 0; dy < ks; ++dy) {
+    const int yy = y + dy - r;
+    if (yy < 0 || yy >= H) continue;
+    const float* w0 = w + dy * ks;
+    const float* w1 = w + ks * ks + dy * ks;
+    for (int dx = 0; dx < ks; ++dx) {
+      const int xx = x + dx - r;
+      if (xx >= 0 && xx < W) {
+        const float2 pv = *reinterpret_cast<const float2*>(pl + ((long long)yy * W + xx) * 2);
+        const float g = cm ? cm[(long long)yy * W + xx] : 1.f;
+        s = fmaf(w0[dx], pv.x * g, fmaf(w1[dx], pv.y * g, s));
+      }
+    }
+  }
+  cum_out[p] = (cm ? cm[rem] : 1.f) * (1.f / (1.f + __expf(-(s + bias[0]))));
+}
+
 // out = x * gate[pixel]: 16 lanes per pixel, one float4 each -- a pure HBM stream
 __global__ __launch_bounds__(256) void spatial_gate_kernel(const float* __restrict__ x, int ld, const float* __restrict__ gate,
                                                            long long npix, float* __restrict__ out, int ldo) {
@@ -181,6 +213,18 @@ extern "C" int cdfo_spatial_gate(const float* x, int ld, const float* pooled, co
                      gate_scratch);
   hipLaunchKernelGGL(spatial_gate_kernel, dim3((unsigned)((npix * 16 + 255) / 256)), dim3(256), 0, st, x, ld, gate_scratch, npix,
                      out, ldo);
+  CDFO_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int cdfo_gate_map_cumulative(const float* pooled, const float* cum_in, const float* w, const float* bias, int B, int H, int W,
+                                        int ks, float* cum_out, void* stream) {
+  if (B <= 0 || H <= 0 || W <= 0 || ks < 1 || !(ks & 1) || !pooled || !w || !bias || !cum_out || cum_out == cum_in) return CDFO_EINVAL;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const long long npix = (long long)B * H * W;
+  CdfoProfScope prof(st, KID_SPATIAL_GATE, 2.0 * npix * 2 * ks * ks, 4.0 * npix * 4.0);
+  hipLaunchKernelGGL(gate_map_cum_kernel, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, st, pooled, cum_in, w, bias, B, H, W, ks,
+                     cum_out);
   CDFO_LAUNCH_CHECK();
   return 0;
 }

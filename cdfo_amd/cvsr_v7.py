@@ -179,14 +179,24 @@ class CVSR_V7(nn.Module):
         """``PartitionTransformerBlock.forward`` (arch.py:1350-1368): four weight-shared rounds."""
         raw = w["raw"]
         p = "transformer_feature_extraction.path1."
+        lazy_gate = self.precision == "fp16x2"
+        if lazy_gate:
+            # the prior branch is only ever gated (x2_k = x2_{k-1} * g_k, one shared SpatialAttention): x2_k = x2_0 * G_k with a per-pixel
+            # running product G, pool(x2_k) = G_k * pool(x2_0) -- one pooling pass, a one-float-per-pixel plane per round, and the
+            # gated tensor enters the 1x1 convolution's residual sum as x2_0 * G (K.gate_map_cumulative; csrc/v7_ops.hip)
+            pooled, G = K.chan_pool(x2), None
         for _ in range(4):
-            x2 = K.spatial_gate(x2, raw[p + "SA.spatial.weight"], raw[p + "SA.spatial.bias"])
+            if lazy_gate:
+                G = K.gate_map_cumulative(pooled, G, raw[p + "SA.spatial.weight"], raw[p + "SA.spatial.bias"])
+            else:
+                x2 = K.spatial_gate(x2, raw[p + "SA.spatial.weight"], raw[p + "SA.spatial.bias"])
             v, part, n = K.qkv_dw(x1, w[p + "qkv_dw"], raw[p + "attn.qkv_dwconv.weight"], gram=True)
             fold = K.mdta_fold(part, n, raw[p + "attn.temperature"], raw[p + "attn.project_out.weight"])
             if self.precision == "fp16x2":
                 # as in CVSR_V8: norm2 of the result leaves the 1x1 kernel as fp16 hi | lo planes, and the 3x3 convolution runs as a
                 # split-fp16, fp32-grade product (a_hi*w_hi + a_lo*w_hi + a_hi*w_lo) on the LDS-DMA ring kernel
-                x1, ln = self._conv(v, fold, res1=x1, res2=x2, ln_out=(raw[p + "norm2.body.weight"], raw[p + "norm2.body.bias"]))
+                x1, ln = self._conv(v, fold, res1=x1, res2=x2, res2_scale=G,
+                                    ln_out=(raw[p + "norm2.body.weight"], raw[p + "norm2.body.bias"]))
                 x1 = K.conv_ring(ln, w[p + "conv_hl"], res1=x1, plane_wrap=8)
                 continue
             x1 = self._conv(v, fold, res1=x1, res2=x2)

@@ -138,8 +138,10 @@ def pack_conv(weight: torch.Tensor, bias: Optional[torch.Tensor], shuffle2: bool
 def conv(srcs: Sequence[torch.Tensor], pc: PackedConv, *, stride: int = 1, pad: int = 0, act: int = ACT_NONE,
          res1: Optional[torch.Tensor] = None, res2: Optional[torch.Tensor] = None,
          out: Optional[torch.Tensor] = None, prec: int = PREC_F32,
-         ln: Optional[tuple] = None, s2d: bool = False, out_f16: bool = False, ln_out: Optional[tuple] = None):
-    """ln_out = (gamma, beta) (1x1, Cout = 64, 16-bit modes): also LayerNorm64 of the RESULT as fp16 hi | lo planes
+         ln: Optional[tuple] = None, s2d: bool = False, out_f16: bool = False, ln_out: Optional[tuple] = None,
+         res2_scale: Optional[torch.Tensor] = None):
+    """res2_scale [B,H,W]: res2 enters the sum as res2 * res2_scale[pixel] (streaming 1x1 kernel only; raises elsewhere).
+    ln_out = (gamma, beta) (1x1, Cout = 64, 16-bit modes): also LayerNorm64 of the RESULT as fp16 hi | lo planes
     [B,8,H,W,16] (layernorm64_hl of the returned tensor); the call then returns the pair (out, planes)."""
     if isinstance(srcs, torch.Tensor):
         srcs = [srcs]
@@ -196,6 +198,10 @@ def conv(srcs: Sequence[torch.Tensor], pc: PackedConv, *, stride: int = 1, pad: 
                 raise ValueError(f"{nm} shape {tuple(r.shape)} does not match the conv output")
             setattr(a, nm, r.data_ptr())
             setattr(a, "ldr" + nm[-1], rld)
+    if res2_scale is not None:
+        if res2 is None or tuple(res2_scale.shape) != (B, Ho, Wo) or not res2_scale.is_contiguous() or res2_scale.dtype != torch.float32:
+            raise ValueError("conv: res2_scale must be a contiguous fp32 [B,H,W] plane next to res2")
+        a.res2_pixscale = res2_scale.data_ptr()
     if (prec != PREC_F32 and pc.wq is not None and stride == 1 and pad == 1 and pc.w_bstride == 0):
         a.prec = prec
         a.CoutP = pc.CoutP16
@@ -702,6 +708,18 @@ def chan_pool(x: torch.Tensor) -> torch.Tensor:
     B, H, W, Cc, ld = _chk_act(x)
     out = torch.empty((B, H, W, 2), dtype=torch.float32, device=x.device)
     check(_lib.lib().cdfo_chan_pool(_vp(x), ld, C.c_longlong(B * H * W), Cc, _vp(out), _stream()), "cdfo_chan_pool")
+    return out
+
+
+def gate_map_cumulative(pooled: torch.Tensor, cum: Optional[torch.Tensor], w: torch.Tensor, bias: torch.Tensor) -> torch.Tensor:
+    """G_k = G_{k-1} * sigmoid(conv(G_{k-1} * pooled_0) + bias): the running per-pixel product of a SpatialAttention applied repeatedly
+    to the same tensor (x_k = x_0 * G_k); pooled = chan_pool(x_0) [B,H,W,2], cum = G_{k-1} [B,H,W] or None."""
+    B, H, W, two = pooled.shape
+    if two != 2 or not pooled.is_contiguous() or (cum is not None and (tuple(cum.shape) != (B, H, W) or not cum.is_contiguous())):
+        raise ValueError("gate_map_cumulative: pooled [B,H,W,2] and cum [B,H,W] expected")
+    out = torch.empty((B, H, W), dtype=torch.float32, device=pooled.device)
+    check(_lib.lib().cdfo_gate_map_cumulative(_vp(pooled), _vp(cum), _vp(w), _vp(bias), B, H, W, int(w.shape[-1]), _vp(out), _stream()),
+          "cdfo_gate_map_cumulative")
     return out
 
 

@@ -69,6 +69,8 @@ typedef struct {
    *   off_accumulate != 0 (the second head, in place):    offset[k] += off_mag * tanh(v[k]),  mask[k] = sigmoid(mask[k] + v[2*third + k])
    * flow: the motion field [B][2][Ho][Wo], image pitch flow_bstride floats (read by the first head only).  */
   float* mask_out; const float* flow; long long flow_bstride; float off_mag; int off_accumulate;
+  const float* res2_pixscale;  /* optional, cdfo_conv1x1_bf16x3 only (its streaming form): res2 enters the sum as res2[p][c] * res2_pixscale[p],
+                                 one factor per pixel [B][H*W] -- a spatial gate applied to the residual without writing the gated tensor */
 } cdfo_conv_args;
 int cdfo_sizeof_conv_args(void);   /* sizeof(cdfo_conv_args) as the library was built: a binding checks its own mirror against it */
 int cdfo_conv_igemm(const cdfo_conv_args* a, void* stream);
@@ -389,6 +391,11 @@ int cdfo_resample2_bwd(const float* g, int ldg, int B, int H, int W, int C, int 
  *                     contiguous; src element [b][pl][y][x] at src[b*src_bstride + (pl*H + y)*W + x].
  * cdfo_lincomb:       out = ca*a + cb*b + cc*c over n floats (b, c may be NULL; out may alias an input). */
 int cdfo_chan_pool(const float* x, int ld, long long npix, int C, float* out, void* stream);
+/* The SAME SpatialAttention applied round after round to one tensor (PartitionTransformerBlock, arch.py:1350-1368): x_k = x_0 * G_k with
+ * G_k = G_{k-1} * sigmoid(conv_ksxks(G_{k-1} * pooled_0) + bias) per pixel (the gates are positive, so pooling commutes with them).
+ * pooled = cdfo_chan_pool(x_0) [B][H][W][2]; cum_in = G_{k-1} [B][H][W] or NULL (= 1); cum_out = G_k (must not alias cum_in).  */
+int cdfo_gate_map_cumulative(const float* pooled, const float* cum_in, const float* w, const float* bias, int B, int H, int W, int ks,
+                             float* cum_out, void* stream);
 int cdfo_spatial_gate(const float* x, int ld, const float* pooled, const float* w, const float* bias, int B, int H, int W,
                       int C, int ks, float* gate_scratch, float* out, int ldo, void* stream);
 int cdfo_rdab_mix(const float* xf, int ld, const float* pooled, const float* w3, const float* b3, const float* vmax,

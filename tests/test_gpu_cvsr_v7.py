@@ -215,3 +215,34 @@ def test_v7_training_step_matches_oracle_autograd(exact):
           f"{np.median(e_hip):.2e} (float32 CPU oracle {np.median(e_cpu):.2e}), 90th percentile {np.quantile(e_hip, 0.9):.2e}, worst "
           f"{rows[0][0]:.2e} ({rows[0][2]}; float32 oracle there {rows[0][1]:.2e})")
     assert np.median(e_hip) <= (2e-5 if exact else 2e-4) and np.quantile(e_hip, 0.9) <= 5e-3 and e_hip.max() <= 5e-2, rows[:6]
+
+
+def test_repeated_spatial_gate_as_a_running_per_pixel_product():
+    """x_k = SpatialAttention(x_{k-1}) with one shared gate (arch.py:1350-1368) == x_0 * G_k, G from the pooled map of x_0 alone
+    (K.gate_map_cumulative), and the gated tensor as a scaled residual of the streaming 1x1 kernel (res2_scale) == the same
+    convolution with the gated tensor written out."""
+    from cdfo_amd import kernels as K
+    g = torch.Generator(device="cuda").manual_seed(5)
+    B, H, W = 3, 37, 52
+    x0 = torch.randn(B, H, W, 64, device="cuda", generator=g)
+    w = torch.randn(1, 2, 7, 7, device="cuda", generator=g) * 0.2
+    b = torch.randn(1, device="cuda", generator=g) * 0.1
+    pooled, G, x = K.chan_pool(x0), None, x0
+    for k in range(4):
+        x = K.spatial_gate(x, w, b)
+        G = K.gate_map_cumulative(pooled, G, w, b)
+        assert (x - x0 * G[..., None]).abs().max().item() < 2e-6 * (k + 1), k
+    src = torch.randn(B, H, W, 64, device="cuda", generator=g)
+    res1 = torch.randn(B, H, W, 64, device="cuda", generator=g)
+    wt = torch.randn(B, 64, 64, 1, 1, device="cuda", generator=g) / 8
+    pcs = [K.pack_conv(wt[i], None) for i in range(B)]
+    pc = K.PackedConv(torch.stack([p.w for p in pcs]).view(B, -1).contiguous(), None, 64, 64, 1, 64, False, 4096)   # per-image weights
+    gamma, beta = torch.rand(64, device="cuda", generator=g) + 0.5, torch.randn(64, device="cuda", generator=g) * 0.1
+    ref, ref_ln = K.conv(src, pc, res1=res1, res2=x0 * G[..., None], prec=K.PREC_FP16X2, ln_out=(gamma, beta))
+    out, out_ln = K.conv(src, pc, res1=res1, res2=x0, res2_scale=G, prec=K.PREC_FP16X2, ln_out=(gamma, beta))
+    assert (out - ref).abs().max().item() < 2e-6 and (out_ln.float() - ref_ln.float()).abs().max().item() < 2e-3
+    ref2 = K.conv(src, pc, res2=x0 * G[..., None], prec=K.PREC_BF16X3)
+    out2 = K.conv(src, pc, res2=x0, res2_scale=G, prec=K.PREC_BF16X3)
+    assert (out2 - ref2).abs().max().item() < 2e-6
+    with pytest.raises(Exception):
+        K.conv(src, pc, res2=x0, res2_scale=G)        # the exact-fp32 kernel has no scaled residual: loud, not silent

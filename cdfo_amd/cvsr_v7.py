@@ -145,6 +145,11 @@ class CVSR_V7(nn.Module):
                     pc(f"recon_trunk.body.{g}.body.{b}.{leaf}")
         w[fe + "qkv_dw"] = K.pack_qkv_dw(sd[fe + "attn.qkv.weight"], sd[fe + "norm1.body.weight"], sd[fe + "norm1.body.bias"])
         w[fe + "conv_hl"] = K.pack_conv_hilo(sd[fe + "conv.weight"], sd[fe + "conv.bias"], True)     # split-fp16 form for conv_ring
+        # RDAB's residual-mask branch as in CVSR_V8: conv_du_re.0 composed with conv_expand_rms into a second stencil of the stem
+        # kernel (written in space-to-depth form), conv_du_re.2 (stride 2) as a tap-masked stride-1 convolution over that form
+        w["rms_du0"] = K.compose_stem_1x1(sd["conv_expand_rms.weight"], sd["conv_expand_rms.bias"], sd["RDAB.conv_du_re.0.weight"],
+                                          sd["RDAB.conv_du_re.0.bias"])
+        w["RDAB.conv_du_re.2_s2d"] = K.pack_conv_s2p2_s2d(sd["RDAB.conv_du_re.2.weight"], sd["RDAB.conv_du_re.2.bias"])
         pc("upconv1_L2", shuffle2=True)
         pc("upconv2", shuffle2=True)
         dev = sd["conv_first.weight"].device
@@ -204,11 +209,15 @@ class CVSR_V7(nn.Module):
             x1 = self._conv(ln, w[p + "conv"], pad=1, res1=x1, exact=True)
         return x1
 
-    def _rdab(self, w, res, xc, noise):
-        """``RDAB.forward`` (arch.py:2830-2847)."""
+    def _rdab(self, w, res, xc, noise, du0=None):
+        """``RDAB.forward`` (arch.py:2830-2847).  du0: relu(conv_du_re.0(res)) in space-to-depth form [B,h/2+1,w/2+1,256] when the
+        stem kernel already produced it from the residual image (16-bit modes, even sizes); `res` is then unused."""
         raw = w["raw"]
-        t = self._conv(res, w["RDAB.conv_du_re.0"], act=K.ACT_RELU)
-        t = self._conv(t, w["RDAB.conv_du_re.2"], stride=2, pad=2, act=K.ACT_RELU)
+        if du0 is not None:
+            t = self._conv(du0, w["RDAB.conv_du_re.2_s2d"], pad=1, act=K.ACT_RELU, exact=True)      # [B, h/2+1, w/2+1, 64]
+        else:
+            t = self._conv(res, w["RDAB.conv_du_re.0"], act=K.ACT_RELU)
+            t = self._conv(t, w["RDAB.conv_du_re.2"], stride=2, pad=2, act=K.ACT_RELU)
         part, n = K.chan_sum_partial(t)
         vmax = K.vec_mlp(part, n, t.shape[1] * t.shape[2], raw["RDAB.conv_du_re2.0.weight"],
                          raw["RDAB.conv_du_re2.0.bias"], 64, K.ACT_RELU)
@@ -339,15 +348,26 @@ class CVSR_V7(nn.Module):
                     u_img, r_img = K.shrink_planes(ufs[:, :, i], lv), K.shrink_planes(rms[:, :, i], lv)
                     bstride = h * wd
                 ufs_prior = K.stem_conv(u_img, bstride, B, h, wd, raw["conv_expand_ufs.weight"], raw["conv_expand_ufs.bias"])
-                rms_prior, fea_com = K.stem_conv(r_img, bstride, B, h, wd, raw["conv_expand_rms.weight"],
-                                                 raw["conv_expand_rms.bias"], add=Lf[i])
+                du0 = rms_prior = None
+                if self.precision != "f32" and h % 2 == 0 and wd % 2 == 0:
+                    # fea_com = fea_i + rms_prior and du0 = relu(conv_du_re.0(rms_prior)) (space-to-depth, + one zero row / column)
+                    # from the residual image itself: rms_prior is never written
+                    fea_com = K.empty_act(B, h, wd, NF, dev)
+                    du0 = K.empty_act(B, h // 2 + 1, wd // 2 + 1, 4 * NF, dev)
+                    du0[:, h // 2].zero_()
+                    du0[:, :, wd // 2].zero_()
+                    K.stem_conv2(r_img, bstride, B, h, wd, raw["conv_expand_rms.weight"], raw["conv_expand_rms.bias"], Lf[i], fea_com,
+                                 w["rms_du0"][0], w["rms_du0"][1], K.ACT_RELU, du0, s2dB=True)
+                else:
+                    rms_prior, fea_com = K.stem_conv(r_img, bstride, B, h, wd, raw["conv_expand_rms.weight"],
+                                                     raw["conv_expand_rms.bias"], add=Lf[i])
                 if prev is not None:
                     K.resample2(prev[i], up=True, out=fea_com, accumulate=True)
                 if noise is None:
                     u = torch.rand((B, NF, h, wd), device=dev, dtype=torch.float32).clamp_min_(1e-30)
                 else:
                     u = noise[draw].to(device=dev, dtype=torch.float32).contiguous()
-                x_n = self._rdab(w, rms_prior, fea_com, u)
+                x_n = self._rdab(w, rms_prior, fea_com, u, du0)
                 fea_i = self._conv([Lf[i], x_n], w["conv_expand_fea_r"], pad=1)
                 out = K.nchw_to_nhwc(align.forward_pm(centre_nchw, Lf[ctr], fea_i, ufs_prior, mv))
                 return out
@@ -387,6 +407,11 @@ class CVSR_V7(nn.Module):
         o3 = K.conv(o3, w["shuffle_L3"])                                             # [B,H,W,16] (4 real + 12 zero), exact
         o2 = self._conv(outs[1], w["upconv1_L2"], act=K.ACT_LRELU)                   # [B,H,W,16]
         t = self._conv([outs[0], o2, o3], w["upconv1"], act=K.ACT_LRELU)             # [B,2H,2W,64]
-        t = self._conv(t, w["upconv2"], act=K.ACT_LRELU)                             # [B,4H,4W,64]
-        out = K.conv_last(t, w["conv_last3"], raw["conv_last.bias"], x[:, ctr], N * P)
+        if self.precision != "f32":
+            # CVSR_V8's fused tail: upconv2 + LeakyReLU + conv_last's tap sums in one kernel, then the tap gather + x4 skip -- the
+            # [B,4H,4W,64] map is never written (V7's conv_last is 1x1: the centre tap of the 3x3 stencil that kernel applies)
+            out = K.upconv_last(t, w["upconv2"], w["conv_last3"], raw["conv_last.bias"], x[:, ctr], N * P)
+        else:
+            t = self._conv(t, w["upconv2"], act=K.ACT_LRELU)                         # [B,4H,4W,64]
+            out = K.conv_last(t, w["conv_last3"], raw["conv_last.bias"], x[:, ctr], N * P)
         return out, L1.permute(0, 3, 1, 2)

@@ -278,30 +278,11 @@ class CVSR_V8(nn.Module):
         w[fe + "qkv_dw"] = K.pack_qkv_dw(sd[fe + "attn.qkv.weight"], sd[fe + "norm1.body.weight"], sd[fe + "norm1.body.bias"])
         # conv_du_re.0 (1x1) of the compensation module composed with conv_expand_rms (3x3 on the one-channel residual map): a
         # second 1 -> 64 stencil for the stem kernel, so that `rms_prior` is never materialised (arch.py:2200, 4446-4449)
-        w1 = sd["RDAB.conv_du_re.0.weight"].double()[:, :, 0, 0]
-        wr, br = sd["conv_expand_rms.weight"].double(), sd["conv_expand_rms.bias"].double()
-        w["rms_du0"] = (torch.einsum("oc,ckyx->okyx", w1, wr).float().contiguous(),
-                        (w1 @ br + sd["RDAB.conv_du_re.0.bias"].double()).float().contiguous())
+        w["rms_du0"] = K.compose_stem_1x1(sd["conv_expand_rms.weight"], sd["conv_expand_rms.bias"], sd["RDAB.conv_du_re.0.weight"],
+                                          sd["RDAB.conv_du_re.0.bias"])
         # conv_du_re.2 (3x3, stride 2, pad 2) over the space-to-depth form of its input [H/2+1, W/2+1, 4*64] (written that way by
-        # the stem kernel): output (i, j) reads input rows 2i-2+dy = s2d row i-1 phase dy (dy = 0, 1) or s2d row i phase 0
-        # (dy = 2) -- a stride-1 pad-1 convolution with weights on the taps (-1, 0) x (-1, 0) only, which the 16-bit MFMA kernel
-        # runs with a per-chunk tap mask (the exact-fp32 strided kernel it replaces: 0.91 ms per launch)
-        w2 = sd["RDAB.conv_du_re.2.weight"]
-        ws2d = w2.new_zeros(64, 4, 64, 3, 3)
-        masks = []
-        for a_ in range(2):
-            for b_ in range(2):
-                m = 0
-                for ty in range(2):
-                    for tx in range(2):
-                        dy, dx = 2 * ty + a_, 2 * tx + b_
-                        if dy <= 2 and dx <= 2:
-                            ws2d[:, a_ * 2 + b_, :, ty, tx] = w2[:, :, dy, dx]
-                            m |= 1 << (ty * 3 + tx)
-                masks += [m] * 4
-        pc2 = K.pack_conv(ws2d.view(64, 256, 3, 3).contiguous(), sd["RDAB.conv_du_re.2.bias"])
-        pc2.tap_mask = torch.tensor(masks, dtype=torch.int32, device=w2.device)
-        w["RDAB.conv_du_re.2_s2d"] = pc2
+        # the stem kernel): a stride-1 pad-1 convolution with a per-chunk tap mask (K.pack_conv_s2p2_s2d)
+        w["RDAB.conv_du_re.2_s2d"] = K.pack_conv_s2p2_s2d(sd["RDAB.conv_du_re.2.weight"], sd["RDAB.conv_du_re.2.bias"])
         w[fe + "side_to_feaoneUDSA.body.0_n16"] = K.pack_conv_n16(sd[fe + "side_to_feaoneUDSA.body.0.weight"])
         w["udsa_head"] = K.pack_udsa_head(sd[fe + "side_to_feaoneUDSA.body.0.weight"], sd[fe + "side_to_feaoneUDSA.body.0.bias"],
                                           sd["conv_second.weight"], sd["conv_second.bias"])

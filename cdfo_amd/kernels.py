@@ -492,6 +492,38 @@ def stem_conv2(img: torch.Tensor, img_bstride: int, B: int, H: int, W: int, wA: 
           "cdfo_stem_conv2")
 
 
+def compose_stem_1x1(w_stem: torch.Tensor, b_stem: torch.Tensor, w1: torch.Tensor, b1: torch.Tensor):
+    """A 1x1 convolution (w1 [Co,64,1,1], b1) applied to a one-channel 3x3 stem (w_stem [64,1,3,3], b_stem) with nothing in between
+    = one 1 -> Co stencil for the stem kernels (composed in float64): returns (weight [Co,1,3,3], bias [Co]).  Used for
+    conv_du_re.0 o conv_expand_rms (arch.py:2200 / 2832, 4446-4449), so that `rms_prior` is never read back."""
+    m = w1.detach().double()[:, :, 0, 0]
+    return (torch.einsum("oc,ckyx->okyx", m, w_stem.detach().double()).float().contiguous(),
+            (m @ b_stem.detach().double() + b1.detach().double()).float().contiguous())
+
+
+def pack_conv_s2p2_s2d(w2: torch.Tensor, b2: torch.Tensor) -> PackedConv:
+    """A 3x3 / stride 2 / pad 2 convolution (64 -> 64) over the space-to-depth form of its input [H/2+1, W/2+1, 4*64] (one zero row /
+    column at the end): output (i, j) reads input rows 2i-2+dy = s2d row i-1 phase dy (dy = 0, 1) or s2d row i phase 0 (dy = 2) -- a
+    stride-1 pad-1 convolution with weights on the taps (-1, 0) x (-1, 0) only, which the 16-bit MFMA kernel runs with a per-chunk
+    tap mask (the exact-fp32 strided kernel it replaces: 0.91 ms per launch at 24 frames)."""
+    w2 = w2.detach()
+    ws2d = w2.new_zeros(64, 4, 64, 3, 3)
+    masks = []
+    for a_ in range(2):
+        for b_ in range(2):
+            m = 0
+            for ty in range(2):
+                for tx in range(2):
+                    dy, dx = 2 * ty + a_, 2 * tx + b_
+                    if dy <= 2 and dx <= 2:
+                        ws2d[:, a_ * 2 + b_, :, ty, tx] = w2[:, :, dy, dx]
+                        m |= 1 << (ty * 3 + tx)
+            masks += [m] * 4
+    pc2 = pack_conv(ws2d.view(64, 256, 3, 3).contiguous(), b2)
+    pc2.tap_mask = torch.tensor(masks, dtype=torch.int32, device=w2.device)
+    return pc2
+
+
 def pack_udsa_head(w0: torch.Tensor, b0: torch.Tensor, w2: torch.Tensor, b2: torch.Tensor):
     """Composition of conv_second (1 -> 64, 3x3, w2 / b2) and the prior U-net's body.0 (64 -> 16, 3x3, w0 / b0) for
     cdfo_udsa_head: (wc [9,9,16], bt [9,16], b0 [16]), summed over the 64 channels in float64."""

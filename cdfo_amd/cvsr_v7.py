@@ -19,6 +19,8 @@ fp16 hi+lo activations, two MFMA passes, in the 3x3 convolutions of the alignmen
 trunk's body convolutions on CVSR_V8's single-pass fp16 ``Block_`` kernels; the feature extractor stays split-bf16)."""
 from __future__ import annotations
 
+import os
+
 import contextlib
 import math
 from typing import Dict, List, Optional, Sequence
@@ -368,7 +370,11 @@ class CVSR_V7(nn.Module):
                 else:
                     u = noise[draw].to(device=dev, dtype=torch.float32).contiguous()
                 x_n = self._rdab(w, rms_prior, fea_com, u, du0)
-                fea_i = self._conv([Lf[i], x_n], w["conv_expand_fea_r"], pad=1)
+                if self.precision == "fp16x2" and os.environ.get("CDFO_V7_FEAR_1PASS", "1") != "0":
+                    # activations rounded once to fp16 (one MFMA pass): out_vs_golden unchanged at 7-10e-5 (developer A/B switch)
+                    fea_i = K.conv([Lf[i], x_n], w["conv_expand_fea_r"], pad=1, prec=K.PREC_FP16X1)
+                else:
+                    fea_i = self._conv([Lf[i], x_n], w["conv_expand_fea_r"], pad=1)
                 out = K.nchw_to_nhwc(align.forward_pm(centre_nchw, Lf[ctr], fea_i, ufs_prior, mv))
                 return out
 

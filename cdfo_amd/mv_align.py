@@ -48,6 +48,7 @@ class MVDualAttAlignment(ModulatedDeformConvPack):
         self.precision = "bf16x3"
         self.fuse_assembly = os.environ.get("CDFO_V7_FUSE_ASSEMBLY", "1") != "0"      # developer A/B switches
         self.head_one_pass = os.environ.get("CDFO_V7_HEAD_1PASS", "1") != "0"
+        self.off0_one_pass = os.environ.get("CDFO_V7_OFF0_1PASS", "1") != "0"
         self._packed = None
         self._sig = None
 
@@ -127,7 +128,8 @@ class MVDualAttAlignment(ModulatedDeformConvPack):
             gate = K.vec_mlp(part, n, P, d(self.conv_du[0].weight), d(self.conv_du[0].bias), self.out_channels // 16,
                              K.ACT_RELU, d(self.conv_du[2].weight), d(self.conv_du[2].bias), 64, K.ACT_SIGMOID)
             o = K.conv(v, K.fold_scale_inputs(fold, gate), prec=p1)       # project_out(attn @ (v * gate)), the gate folded into the matrix
-            o = K.conv(o, w["off0"], pad=1, act=K.ACT_LRELU, prec=prec)
+            o = K.conv(o, w["off0"], pad=1, act=K.ACT_LRELU,
+                       prec=K.PREC_FP16X1 if (prec == K.PREC_FP16X2 and self.off0_one_pass) else prec)
             if fused:
                 # fp16x2: the head's weights are rounded once to fp16 in that mode; rounding its input once as well (one MFMA pass
                 # instead of two) adds an error of the same size -- CVSR_V7's parity moves inside its 10x margin

@@ -18,4 +18,6 @@ python3 tools/pmc_summary.py $O/dfetch $O/dwrite $O/${R}_pmc_traffic_dcn_fwd.txt
 cp $O/dstats/*/*kernel_stats.csv $O/${R}_kernel_stats_dcn_fwd.csv && \
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/bstats -- python3 tools/bench_dcn.py --backward --iters 5 > $O/bstats.log 2>&1 && \
 cp $O/bstats/*/*kernel_stats.csv $O/${R}_kernel_stats_dcn_bwd.csv && \
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/v7stats -- python3 tools/bench_v7.py --batch 8 --precision fp16x2 --steps 2 > $O/v7stats.log 2>&1 && \
+cp $O/v7stats/*/*kernel_stats.csv $O/${R}_kernel_stats_v7_fp16x2.csv && grep "^# CVSR_V7" $O/v7stats.log > $O/${R}_v7_line.txt && \
 python3 tools/phase_times.py 2>&1 | grep -v amdgpu | tail -1 > $O/phases.txt && python3 tools/op_table.py > $O/op_table.txt 2>&1 && cat $O/phases.txt && head -5 $O/${R}_pmc_traffic_c3_fp16x2.txt | tail -1 | cut -c1-150

@@ -61,6 +61,8 @@ struct ws_args {
   const float* res1; int ldr1;
   const float* res2; int ldr2;
   unsigned long long* clk;      // developer probe (dbg 128): per wave {shader-clock cycles, start, end in 100 MHz real-time ticks}
+  // offset / mask epilogue (conv3x3_c64_wsq_kernel<0, true>; cdfo_conv3x3_c64_ws_offmask): see cdfo_hip.h, CDFO_STORE_OFFMASK
+  float* om_offset; float* om_mask; const float* om_flow; long long om_flow_bstride; float om_mag; int om_accumulate; int om_cout;
 };
 
 // five 1 KiB LDS-DMA pieces: lane l of piece k writes LDS bytes lds + 1024 k + 16 l from (buffer base + voff[k] + soff)
@@ -729,7 +731,12 @@ constexpr int WQ_W_OFF = 2 * WQ_NS * WQ_ACT;           // 90,112
 constexpr int WQ_TOTAL = WQ_W_OFF + WS_W_BYTES;        // 163,840 bytes
 static_assert(WQ_TOTAL <= 160 * 1024, "LDS budget");
 
-template <int DBG>
+// OFFMASK: the convolution is MVDualAttAlignment's conv_offset[2] (a.om_cout = 27 dg real output channels inside a.Cout padded ones)
+// and the epilogue is the module's offset / mask assembly into the DCN operator's NCHW planes (arch.py:3336-3350), like
+// conv3x3_bf16.hip's CDFO_STORE_OFFMASK: a lane owns 16 output channels of 4 pixels whose 16 lane-neighbours are consecutive along x,
+// so every access is a 4-byte element of a 64-byte run of one plane.  All of a tile's prior values (the motion field for the
+// first head, the planes themselves for the second) are requested before the first store.
+template <int DBG, bool OFFMASK = false>
 __global__ __launch_bounds__(WR_THREADS) void conv3x3_c64_wsq_kernel(ws_args a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, l16 = lane & 15, kg = lane >> 4;
@@ -847,7 +854,10 @@ __global__ __launch_bounds__(WR_THREADS) void conv3x3_c64_wsq_kernel(ws_args a) 
 #pragma unroll
   for (int mb = 0; mb < 4; ++mb)
 #pragma unroll
-    for (int k = 0; k < 4; ++k) bias[mb][k] = a.bias ? a.bias[n0 + chan_q(mb * 16 + 4 * kg + k)] : 0.f;
+    for (int k = 0; k < 4; ++k) {
+      const int n = n0 + chan_q(mb * 16 + 4 * kg + k);
+      bias[mb][k] = (a.bias && (!OFFMASK || n < a.om_cout)) ? a.bias[n] : 0.f;
+    }
 
   for (int s = 0; s < lag; ++s) {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -927,6 +937,108 @@ __global__ __launch_bounds__(WR_THREADS) void conv3x3_c64_wsq_kernel(ws_args a) 
 #pragma unroll
           for (int e = 0; e < 4; ++e) t += acc[mb][nbk][e];
       if (t == 123.456f) a.out[0] = (_Float16)t;
+      continue;
+    }
+    if (OFFMASK) {
+      // acc[mb][nbk][k] (mb = 2e + hf) = channel n0 + e*32 + 8 kg + 4 hf + k of pixel (cy0 + (nbk >> 1), cx0 + 16 (nbk & 1) + l16).
+      // 2 * third and om_cout are multiples of 32 resp. 8 (launcher), so a 32-channel half-block e is offset or mask as a whole and
+      // a lane's eight channels of it are inside the real output or outside together.  Addresses: one buffer descriptor per plane
+      // set and image, the per-lane part (8 kg planes + the pixel) in a 32-bit lane offset that carries the out-of-range marker,
+      // the wave-uniform channel in the scalar offset -- 8 address registers for the 64 elements of a lane.
+      const int third = a.om_cout / 3;
+      const unsigned P4 = (unsigned)(H * W) * 4u;
+      const __amdgpu_buffer_rsrc_t r_off = __builtin_amdgcn_make_buffer_rsrc(a.om_offset + (long long)cb * 2 * third * (H * W), 0,
+                                                                             (int)(2 * third * P4), 0x00020000);
+      const __amdgpu_buffer_rsrc_t r_msk = __builtin_amdgcn_make_buffer_rsrc(a.om_mask + (long long)cb * third * (H * W), 0,
+                                                                             (int)(third * P4), 0x00020000);
+      bool ok[4];
+      unsigned vo[2][4];
+#pragma unroll
+      for (int nbk = 0; nbk < 4; ++nbk) {
+        const int y = cy0 + (nbk >> 1), x = cx0 + (nbk & 1) * 16 + l16;
+        ok[nbk] = y < H && x < W;
+#pragma unroll
+        for (int e = 0; e < 2; ++e)
+          vo[e][nbk] = (ok[nbk] && n0 + e * 32 + 8 * kg < a.om_cout) ? (unsigned)(8 * kg) * P4 + (unsigned)(y * W + x) * 4u : 0x80000000u;
+      }
+      bool e_off[2];
+#pragma unroll
+      for (int e = 0; e < 2; ++e) e_off[e] = n0 + e * 32 < 2 * third;
+      auto soff_of = [&](int e, int hf, int k) {      // wave-uniform byte offset of channel n0 + e*32 + 4 hf + k inside its plane set
+        return (unsigned)(n0 + e * 32 + 4 * hf + k - (e_off[e] ? 0 : 2 * third)) * P4;
+      };
+      // the offset channels' own term first, in place (vector work that needs nothing from memory)
+#pragma unroll
+      for (int mb = 0; mb < 4; ++mb) {
+        if (!e_off[mb >> 1]) continue;
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+#pragma unroll
+          for (int nbk = 0; nbk < 4; ++nbk)
+            acc[mb][nbk][k] = a.om_mag * (1.f - 2.f * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(acc[mb][nbk][k] * 2.885390081777927f)));
+      }
+      auto store_batch = [&](int e) {
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+          for (int k = 0; k < 4; ++k)
+#pragma unroll
+            for (int nbk = 0; nbk < 4; ++nbk)
+              __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, acc[2 * e + hf][nbk][k]), e_off[e] ? r_off : r_msk,
+                                                    (int)vo[e][nbk], (int)soff_of(e, hf, k), 0);
+      };
+      if (!a.om_accumulate) {
+        // first head: offset = term + flipped motion field (the (y, x) pairs take (flow_y, flow_x): channel parity = k & 1), mask = raw sums
+        float fl[2][4];
+#pragma unroll
+        for (int par = 0; par < 2; ++par)
+#pragma unroll
+          for (int nbk = 0; nbk < 4; ++nbk) {
+            const int y = cy0 + (nbk >> 1), x = cx0 + (nbk & 1) * 16 + l16;
+            fl[par][nbk] = ok[nbk] ? a.om_flow[(long long)cb * a.om_flow_bstride + (long long)(1 - par) * (H * W) + y * W + x] : 0.f;
+          }
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb) {
+          if (!e_off[mb >> 1]) continue;
+#pragma unroll
+          for (int k = 0; k < 4; ++k)
+#pragma unroll
+            for (int nbk = 0; nbk < 4; ++nbk) acc[mb][nbk][k] += fl[k & 1][nbk];
+        }
+        store_batch(0);
+        store_batch(1);
+        continue;
+      }
+      // second head, in place: two batches of 32 prior values; batch 1 is requested before batch 0 is stored (the stores may alias
+      // the loads as far as the compiler knows, so a load -> store loop would pay one memory latency per run)
+      float prior[2][4][4];                    // [hf][nbk][k]
+      auto load_batch = [&](int e) {
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+          for (int k = 0; k < 4; ++k)
+#pragma unroll
+            for (int nbk = 0; nbk < 4; ++nbk)
+              prior[hf][nbk][k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(e_off[e] ? r_off : r_msk, (int)vo[e][nbk],
+                                                                                                (int)soff_of(e, hf, k), 0));
+      };
+      auto finish_batch = [&](int e) {          // acc <- final values
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+          for (int k = 0; k < 4; ++k)
+#pragma unroll
+            for (int nbk = 0; nbk < 4; ++nbk) {
+              const float t = prior[hf][nbk][k] + acc[2 * e + hf][nbk][k];
+              acc[2 * e + hf][nbk][k] = e_off[e] ? t : __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(t * -1.4426950408889634f));
+            }
+      };
+      load_batch(0);
+      finish_batch(0);
+      load_batch(1);
+      store_batch(0);
+      finish_batch(1);
+      store_batch(1);
       continue;
     }
     // ---- epilogue: act -> fp16 -> 16-byte stores.  acc[2e][nbk][k], acc[2e+1][nbk][k] = channels e*32 + 8 kg + k, + 4 + k of
@@ -1090,6 +1202,35 @@ extern "C" int cdfo_conv3x3_c64_ws(const void* src_cp16, int B, int H, int W, co
     default: return CDFO_EINVAL;
   }
   if (rc) return rc;
+  CDFO_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int cdfo_conv3x3_c64_ws_offmask(const void* src_cp16, int B, int H, int W, const void* w_f16, int CoutP, const float* bias,
+                                           int Cout, float* offset, float* mask, const float* flow, long long flow_bstride,
+                                           float mag, int accumulate, void* stream) {
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (B <= 0 || H <= 0 || W <= 0 || (H & 1) || Cout <= 0 || Cout % 3 || Cout % 8 || (2 * Cout / 3) % 32 || CoutP < Cout || CoutP % 64 || !offset ||
+      !mask || !flow || (long long)H * W * (2 * Cout / 3) * 4 >= (1ll << 31))
+    return CDFO_EINVAL;      // (32-bit plane-set offsets; a half-block of 32 channels is offset or mask as a whole)
+  const long long src_bytes = (long long)B * 4 * H * W * 32;
+  if (src_bytes >= (1ll << 31)) return CDFO_EINVAL;      // 32-bit buffer offsets, out-of-range marker 0x80000000
+  if (!aligned16(src_cp16) || !aligned16(w_f16)) return CDFO_EALIGN;
+  const int cus = ws_num_cus();
+  if (cus < 8 || (CoutP >> 6) > cus / 8) return CDFO_EINVAL;
+  ws_args a{};
+  a.src = src_cp16; a.src_bytes = (unsigned)src_bytes;
+  a.B = B; a.H = H; a.W = W;
+  a.w = static_cast<const unsigned short*>(w_f16); a.CoutP = CoutP;
+  a.bias = bias; a.Cout = CoutP; a.act = CDFO_ACT_NONE;      // the kernel walks the padded 64-channel blocks; om_cout bounds the real ones
+  a.om_offset = offset; a.om_mask = mask; a.om_flow = flow; a.om_flow_bstride = flow_bstride; a.om_mag = mag;
+  a.om_accumulate = accumulate; a.om_cout = Cout;
+  const double px = (double)B * H * W;
+  CdfoProfScope prof(st, KID_CONV3_WS, 2.0 * px * Cout * 64 * 9, (accumulate ? 8.0 : 4.0) * px * Cout + 2.0 * px * 64 + 2.0 * 9 * 64 * Cout);
+  static CdfoAttrOnce once;
+  const hipError_t e = cdfo_set_max_lds(once, reinterpret_cast<const void*>(conv3x3_c64_wsq_kernel<0, true>), WQ_TOTAL);
+  if (e != hipSuccess) return (int)e;
+  hipLaunchKernelGGL((conv3x3_c64_wsq_kernel<0, true>), dim3(cus / 8 * 8), dim3(WR_THREADS), WQ_TOTAL, st, a);
   CDFO_LAUNCH_CHECK();
   return 0;
 }

@@ -321,6 +321,24 @@ def conv3x3_ws(src: torch.Tensor, pc: PackedConv, *, act: int = ACT_NONE, s2d: b
     return out
 
 
+def conv_offset_mask_ws(src: torch.Tensor, pc: PackedConv, offset: torch.Tensor, mask: torch.Tensor, flow: torch.Tensor, mag: float,
+                        accumulate: bool) -> None:
+    """conv_offset_mask on the weights-stationary kernel (single-pass fp16 operands): src fp16 chunk-planar [B,4,H,W,16]; the rest as
+    conv_offset_mask.  H even, 18 dg a multiple of 32 (dg = 16: 288)."""
+    if src.dtype != torch.float16 or src.dim() != 5 or src.shape[1] != 4 or src.shape[4] != 16 or not src.is_contiguous():
+        raise ValueError(f"conv_offset_mask_ws: expected a contiguous fp16 [B,4,H,W,16] source, got {src.dtype} {tuple(src.shape)}")
+    B, _, H, W, _ = src.shape
+    third = pc.Cout // 3
+    if (pc.wh is None or pc.Cin != 64 or pc.ks != 3 or pc.Cout % 3 or H % 2 or (2 * third) % 32 or pc.Cout % 8
+            or tuple(offset.shape) != (B, 2 * third, H, W) or tuple(mask.shape) != (B, third, H, W) or tuple(flow.shape) != (B, 2, H, W)
+            or not (offset.is_contiguous() and mask.is_contiguous() and flow.is_contiguous())
+            or any(t.dtype != torch.float32 for t in (offset, mask, flow)) or 4 * H * W * 32 * B >= (1 << 31)):
+        raise ValueError("conv_offset_mask_ws: unsupported configuration")
+    check(_lib.lib().cdfo_conv3x3_c64_ws_offmask(_vp(src), B, H, W, _vp(pc.wh), pc.CoutP16, _vp(pc.bias), pc.Cout, _vp(offset), _vp(mask),
+                                                 _vp(flow), C.c_longlong(2 * H * W), float(mag), int(accumulate), _stream()),
+          "cdfo_conv3x3_c64_ws_offmask")
+
+
 def conv3x3_ws_res(src: torch.Tensor, pc: PackedConv, *, res1: torch.Tensor, res2: Optional[torch.Tensor] = None,
                    act: int = ACT_NONE, out: Optional[torch.Tensor] = None,
                    out2_cp16: Optional[torch.Tensor] = None) -> torch.Tensor:

@@ -49,6 +49,7 @@ class MVDualAttAlignment(ModulatedDeformConvPack):
         self.fuse_assembly = os.environ.get("CDFO_V7_FUSE_ASSEMBLY", "1") != "0"      # developer A/B switches
         self.head_one_pass = os.environ.get("CDFO_V7_HEAD_1PASS", "1") != "0"
         self.off0_one_pass = os.environ.get("CDFO_V7_OFF0_1PASS", "1") != "0"
+        self.ws_head = os.environ.get("CDFO_V7_WS_HEAD", "1") != "0"
         self._packed = None
         self._sig = None
 
@@ -122,12 +123,21 @@ class MVDualAttAlignment(ModulatedDeformConvPack):
         # the 16-bit head writes the DCN's NCHW offset / mask planes from its own epilogue (first head: tanh + flow / raw mask sums,
         # second head: in-place accumulate + sigmoid); the exact-fp32 head and widths that are no multiple of 4 assemble separately
         fused = self.fuse_assembly and prec != K.PREC_F32 and W % 4 == 0
+        ws_head = (self.ws_head and prec == K.PREC_FP16X2 and self.head_one_pass and self.off0_one_pass and H % 2 == 0
+                   and (2 * third) % 32 == 0 and B * H * W * 128 < (1 << 31))
+        fused = fused or ws_head
         outs = []
         for n_head, v in enumerate((warped, pred)):
             part, n = K.chan_sum_partial(v)
             gate = K.vec_mlp(part, n, P, d(self.conv_du[0].weight), d(self.conv_du[0].bias), self.out_channels // 16,
                              K.ACT_RELU, d(self.conv_du[2].weight), d(self.conv_du[2].bias), 64, K.ACT_SIGMOID)
             o = K.conv(v, K.fold_scale_inputs(fold, gate), prec=p1)       # project_out(attn @ (v * gate)), the gate folded into the matrix
+            if ws_head:
+                # both convolutions of the head on the weights-stationary kernel of CVSR_V8's trunk (single-pass fp16, the same
+                # rounding points as the tiled kernel's single-pass mode): ~2x its rate at 64 -> 432
+                o = K.conv3x3_ws(K.to_cp16(o), w["off0"], act=K.ACT_LRELU)
+                K.conv_offset_mask_ws(o, w["off2"], offset, mask, flow, self.max_residue_magnitude, n_head == 1)
+                continue
             o = K.conv(o, w["off0"], pad=1, act=K.ACT_LRELU,
                        prec=K.PREC_FP16X1 if (prec == K.PREC_FP16X2 and self.off0_one_pass) else prec)
             if fused:

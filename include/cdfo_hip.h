@@ -108,6 +108,15 @@ int cdfo_pack_conv3x3_f16(const float* w_oihw, void* packed, int Cout, int Cin, 
  * real-time ticks}: 3 x 8 x 256 words; else pass NULL).  */
 int cdfo_conv3x3_c64_ws(const void* src_cp16, int B, int H, int W, const void* w_f16, int CoutP, const float* bias,
                         int Cout, int act, void* out_cp16, int store_mode, int dbg, void* clk_probe, void* stream);
+/* MVDualAttAlignment's conv_offset[2] (3x3, 64 -> Cout = 27 dg, arch/SIDECVSR_our.py:3285-3289) on the weights-stationary kernel with
+ * the module's offset / mask assembly (arch.py:3336-3350) as its epilogue -- the CDFO_STORE_OFFMASK contract of cdfo_conv_args above,
+ * single-pass fp16 operands (src fp16 chunk-planar [B][4][H][W][16], weights from cdfo_pack_conv3x3_f16 with CoutP padded channels):
+ * offset [B][2 Cout/3][H][W], mask [B][Cout/3][H][W] fp32 NCHW, flow [B][2][H][W] (image pitch flow_bstride floats).
+ * accumulate == 0: first head; != 0: second head, in place.  H even; any W.  */
+int cdfo_conv3x3_c64_ws_offmask(const void* src_cp16, int B, int H, int W, const void* w_f16, int CoutP, const float* bias, int Cout,
+                                float* offset, float* mask, const float* flow, long long flow_bstride, float mag, int accumulate,
+                                void* stream);
+
 /* Residual form of cdfo_conv3x3_c64_ws (ResidualBlock_noBN's second convolution, arch.py:261-262):
  * out[B][H][W][ldo] (fp32, pixel-major) = act(conv + bias) + res1 (+ res2), res* fp32 pixel-major; optionally also the
  * fp16 chunk-planar copy out2_cp16 [B][Cout/16][H][W][16] (NULL to skip).  */

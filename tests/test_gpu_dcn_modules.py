@@ -146,6 +146,22 @@ def test_offset_head_with_the_assembly_as_its_epilogue(shape, prec_name):
     mask64 = torch.sigmoid(r1[:, 2 * third:] + r2[:, 2 * third:])
     tol = 1e-3 if prec_name == "bf16x3" else 2e-2             # 10 px * the arithmetic's error (fp16x2 rounds the WEIGHTS once to fp16)
     assert (off.double() - off64).abs().max().item() < tol and (mask.double() - mask64).abs().max().item() < tol / 10
+    if prec_name == "fp16x2" and H % 2 == 0:
+        # the same head on the weights-stationary kernel (fp16 chunk-planar source, single-pass fp16) against the tiled kernel's
+        # single-pass mode on the identical fp16-rounded input: the two differ by the summation order only
+        h1, h2 = (K.to_cp16(o) for o in (o1, o2))
+        r1, r2 = (K.cp16_to_nhwc(h) if hasattr(K, "cp16_to_nhwc") else h.permute(0, 2, 3, 1, 4).reshape(B, H, W, 64).float().contiguous()
+                  for h in (h1, h2))
+        off_t, mask_t = torch.empty_like(off_ref), torch.empty_like(mask_ref)
+        K.conv_offset_mask(r1, pc, off_t, mask_t, flow, mag, False, K.PREC_FP16X1)
+        K.conv_offset_mask(r2, pc, off_t, mask_t, flow, mag, True, K.PREC_FP16X1)
+        off_w = torch.full_like(off_ref, float("nan"))
+        mask_w = torch.full_like(mask_ref, float("nan"))
+        K.conv_offset_mask_ws(h1, pc, off_w, mask_w, flow, mag, False)
+        assert torch.isfinite(off_w).all() and torch.isfinite(mask_w).all()
+        K.conv_offset_mask_ws(h2, pc, off_w, mask_w, flow, mag, True)
+        assert (off_w - off_t).abs().max().item() < 5e-5 and (mask_w - mask_t).abs().max().item() < 5e-6
+        assert (off_w.double() - off64).abs().max().item() < 3e-2 and (mask_w.double() - mask64).abs().max().item() < 3e-3
     with pytest.raises(ValueError):
         K.conv_offset_mask(o1[:, :, :W - 2], pc, off[..., :W - 2].contiguous(), mask[..., :W - 2].contiguous(),
                            flow[..., :W - 2].contiguous(), mag, False, prec)       # W % 4 != 0: the caller assembles separately

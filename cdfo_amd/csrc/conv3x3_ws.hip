@@ -967,7 +967,16 @@ __global__ __launch_bounds__(WR_THREADS) void conv3x3_c64_wsq_kernel(ws_args a) 
       auto soff_of = [&](int e, int hf, int k) {      // wave-uniform byte offset of channel n0 + e*32 + 4 hf + k inside its plane set
         return (unsigned)(n0 + e * 32 + 4 * hf + k - (e_off[e] ? 0 : 2 * third)) * P4;
       };
-      // the offset channels' own term first, in place (vector work that needs nothing from memory)
+      // the accumulators as plain scalars (they are dead after this; element-wise updates of the vector registers in place made
+      // hipcc store element 0 for every k), and the offset channels' own term first: vector work that needs nothing from memory
+      float val[4][4][4];                      // [mb][nbk][k]
+#pragma unroll
+      for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+        for (int nbk = 0; nbk < 4; ++nbk) {
+          const f32x4 t = acc[mb][nbk];
+          val[mb][nbk][0] = t[0]; val[mb][nbk][1] = t[1]; val[mb][nbk][2] = t[2]; val[mb][nbk][3] = t[3];
+        }
 #pragma unroll
       for (int mb = 0; mb < 4; ++mb) {
         if (!e_off[mb >> 1]) continue;
@@ -975,7 +984,7 @@ __global__ __launch_bounds__(WR_THREADS) void conv3x3_c64_wsq_kernel(ws_args a) 
         for (int k = 0; k < 4; ++k)
 #pragma unroll
           for (int nbk = 0; nbk < 4; ++nbk)
-            acc[mb][nbk][k] = a.om_mag * (1.f - 2.f * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(acc[mb][nbk][k] * 2.885390081777927f)));
+            val[mb][nbk][k] = a.om_mag * (1.f - 2.f * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(val[mb][nbk][k] * 2.885390081777927f)));
       }
       auto store_batch = [&](int e) {
 #pragma unroll
@@ -984,7 +993,7 @@ __global__ __launch_bounds__(WR_THREADS) void conv3x3_c64_wsq_kernel(ws_args a) 
           for (int k = 0; k < 4; ++k)
 #pragma unroll
             for (int nbk = 0; nbk < 4; ++nbk)
-              __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, acc[2 * e + hf][nbk][k]), e_off[e] ? r_off : r_msk,
+              __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, val[2 * e + hf][nbk][k]), e_off[e] ? r_off : r_msk,
                                                     (int)vo[e][nbk], (int)soff_of(e, hf, k), 0);
       };
       if (!a.om_accumulate) {
@@ -1003,7 +1012,7 @@ __global__ __launch_bounds__(WR_THREADS) void conv3x3_c64_wsq_kernel(ws_args a) 
 #pragma unroll
           for (int k = 0; k < 4; ++k)
 #pragma unroll
-            for (int nbk = 0; nbk < 4; ++nbk) acc[mb][nbk][k] += fl[k & 1][nbk];
+            for (int nbk = 0; nbk < 4; ++nbk) val[mb][nbk][k] += fl[k & 1][nbk];
         }
         store_batch(0);
         store_batch(1);
@@ -1022,15 +1031,15 @@ __global__ __launch_bounds__(WR_THREADS) void conv3x3_c64_wsq_kernel(ws_args a) 
               prior[hf][nbk][k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(e_off[e] ? r_off : r_msk, (int)vo[e][nbk],
                                                                                                 (int)soff_of(e, hf, k), 0));
       };
-      auto finish_batch = [&](int e) {          // acc <- final values
+      auto finish_batch = [&](int e) {          // val <- final values
 #pragma unroll
         for (int hf = 0; hf < 2; ++hf)
 #pragma unroll
           for (int k = 0; k < 4; ++k)
 #pragma unroll
             for (int nbk = 0; nbk < 4; ++nbk) {
-              const float t = prior[hf][nbk][k] + acc[2 * e + hf][nbk][k];
-              acc[2 * e + hf][nbk][k] = e_off[e] ? t : __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(t * -1.4426950408889634f));
+              const float t = prior[hf][nbk][k] + val[2 * e + hf][nbk][k];
+              val[2 * e + hf][nbk][k] = e_off[e] ? t : __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(t * -1.4426950408889634f));
             }
       };
       load_batch(0);

@@ -272,11 +272,12 @@ extern "C" int cdfo_conv1x1_bf16x3(const cdfo_conv_args* pa, void* stream) {
   hipStream_t st = static_cast<hipStream_t>(stream);
   if (a.nsrc < 1 || a.nsrc > CDFO_MAXSRC || a.B <= 0 || a.ks != 1 || a.stride != 1 || a.pad != 0) return CDFO_EINVAL;
   if (a.act == CDFO_ACT_SIGMOID || a.tap_mask || a.src_f16 || a.out_f16 || a.res_up2 || a.src_plane_wrap) return CDFO_EINVAL;
-  // out2_cp16 here = a second output: LayerNorm64 (ln_gamma / ln_beta) of the RESULT as fp16 hi | lo planes [B][8][P][16]
+  // out2_cp16 here = a second output: with ln_gamma / ln_beta LayerNorm64 of the RESULT as fp16 hi | lo planes [B][8][P][16]; without
+  // them the result itself as one fp16 chunk-planar tensor [B][4][P][16] (what cdfo_to_cp16 would make of `out`)
   const bool ln_out = a.out2_cp16 != nullptr;
-  if (ln_out && (a.Cout != 64 || a.CoutP != 64 || a.store_mode != CDFO_STORE_PLAIN || !a.ln_gamma || !a.ln_beta || a.ldo < 64 ||
-                 !aligned16(a.out2_cp16) || !aligned16(a.ln_gamma) || !aligned16(a.ln_beta)))
-    return CDFO_EINVAL;
+  const bool copy_out = ln_out && !a.ln_gamma && !a.ln_beta;
+  if (ln_out && (a.Cout != 64 || a.CoutP != 64 || a.store_mode != CDFO_STORE_PLAIN || a.ldo < 64 || !aligned16(a.out2_cp16))) return CDFO_EINVAL;
+  if (ln_out && !copy_out && (!a.ln_gamma || !a.ln_beta || !aligned16(a.ln_gamma) || !aligned16(a.ln_beta))) return CDFO_EINVAL;
   int csum = 0;
   for (int s = 0; s < a.nsrc; ++s) {
     if (a.cs[s] <= 0 || a.cs[s] % 64 || a.ld[s] % 4 || a.ld[s] < a.cs[s]) return CDFO_EINVAL;
@@ -303,6 +304,7 @@ extern "C" int cdfo_conv1x1_bf16x3(const cdfo_conv_args* pa, void* stream) {
     plain.out2_cp16 = nullptr; plain.ln_gamma = nullptr; plain.ln_beta = nullptr;
     const int rc = cdfo_conv1x1_bf16x3(&plain, stream);
     if (rc) return rc;
+    if (copy_out) return cdfo_to_cp16(a.out, a.ldo, a.B, P, 64, a.out2_cp16, stream);
     return cdfo_layernorm64_cp16hl(a.out, a.ldo, a.ln_gamma, a.ln_beta, a.B, P, a.out2_cp16, stream);
   }
   {

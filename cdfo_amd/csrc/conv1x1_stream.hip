@@ -337,7 +337,22 @@ __global__ __launch_bounds__(ST_THREADS) void conv1x1_stream_kernel(st_args a) {
         // ---- store: 32 contiguous bytes per lane and 16-channel group
         const long long tile = img_t0 + it / items_per_tile;
         const long long pin = (tile - (long long)b * a.tiles_per_image) * 128 + wave * 32 + r;
-        if (NCB == 1 && a.ln_hl) {
+        if (NCB == 1 && a.ln_hl && !a.ln_g) {
+          // plain fp16 chunk-planar copy [B][4][P][16] of the result (the source layout of the weights-stationary 3x3 kernel)
+          typedef _Float16 st_f16x8 __attribute__((ext_vector_type(8)));
+          if (pin < a.P) {
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+              for (int jj = 0; jj < 2; ++jj) {
+                const int n = ni * 32 + jj * 16 + h * 8;
+                st_f16x8 hv;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) hv[e] = (_Float16)acc[0][ni][8 * jj + e];
+                *reinterpret_cast<st_f16x8*>(a.ln_hl + (((long long)b * 4 + (n >> 4)) * a.P + pin) * 16 + h * 8) = hv;
+              }
+          }
+        } else if (NCB == 1 && a.ln_hl) {
           // per-pixel LayerNorm over the 64 channels this lane (32 of them) and lane ^ 32 hold; biased variance, eps 1e-5
           typedef _Float16 st_f16x8 __attribute__((ext_vector_type(8)));
           float sm = 0.f;
@@ -475,7 +490,7 @@ int cdfo_conv1x1_stream_try(const cdfo_conv_args& a, hipStream_t st) {
     const hipError_t e2 = hipGetLastError();
     return e2 == hipSuccess ? 1 : (int)e2;
   }
-  if (a.store_mode != CDFO_STORE_PLAIN || (a.ln_gamma && !ln_out) || a.CoutP % 64 || a.CoutP > 128 || a.Cout % 8) return 0;
+  if (a.store_mode != CDFO_STORE_PLAIN || (a.ln_gamma && !ln_out) || a.CoutP % 64 || a.CoutP > 128 || a.Cout % 8) return 0;      // (ln_out without ln_gamma: plain fp16 copy)
   if (ln_out && (a.CoutP != 64 || a.Cout != 64)) return 0;
   const int ncb = a.CoutP / 64, nkb = a.Cin / 64;
   if (nkb < 1 || nkb > CDFO_MAXSRC * 4) return 0;

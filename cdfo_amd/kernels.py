@@ -139,8 +139,10 @@ def conv(srcs: Sequence[torch.Tensor], pc: PackedConv, *, stride: int = 1, pad: 
          res1: Optional[torch.Tensor] = None, res2: Optional[torch.Tensor] = None,
          out: Optional[torch.Tensor] = None, prec: int = PREC_F32,
          ln: Optional[tuple] = None, s2d: bool = False, out_f16: bool = False, ln_out: Optional[tuple] = None,
-         res2_scale: Optional[torch.Tensor] = None):
-    """res2_scale [B,H,W]: res2 enters the sum as res2 * res2_scale[pixel] (streaming 1x1 kernel only; raises elsewhere).
+         res2_scale: Optional[torch.Tensor] = None, cp16_out: bool = False):
+    """cp16_out (1x1, Cout = 64, 16-bit modes): also the fp16 chunk-planar copy [B,4,H,W,16] of the result (to_cp16 of the returned
+    tensor) from the same kernel; the call then returns the pair (out, copy).
+    res2_scale [B,H,W]: res2 enters the sum as res2 * res2_scale[pixel] (streaming 1x1 kernel only; raises elsewhere).
     ln_out = (gamma, beta) (1x1, Cout = 64, 16-bit modes): also LayerNorm64 of the RESULT as fp16 hi | lo planes
     [B,8,H,W,16] (layernorm64_hl of the returned tensor); the call then returns the pair (out, planes)."""
     if isinstance(srcs, torch.Tensor):
@@ -216,6 +218,13 @@ def conv(srcs: Sequence[torch.Tensor], pc: PackedConv, *, stride: int = 1, pad: 
         a.ln_gamma, a.ln_beta = ln[0].data_ptr(), ln[1].data_ptr()
     if (prec != PREC_F32 and pc.ks == 1 and stride == 1 and pad == 0 and pc.CoutP % 64 == 0 and pc.CoutP <= 256
             and all(s.shape[3] % 64 == 0 for s in srcs)):
+        if cp16_out:
+            if ln_out is not None or ln is not None or pc.Cout != 64 or pc.CoutP != 64:
+                raise ValueError("conv: cp16_out needs a plain 64-channel 1x1 convolution")
+            copy = torch.empty((B, 4, Ho, Wo, 16), dtype=torch.float16, device=out.device)
+            a.out2_cp16 = copy.data_ptr()
+            check(_lib.lib().cdfo_conv1x1_bf16x3(C.byref(a), _stream()), "cdfo_conv1x1_bf16x3")
+            return out, copy
         planes = None
         if ln_out is not None and pc.Cout == 64 and pc.CoutP == 64 and ln is None:
             planes = torch.empty((B, 8, Ho, Wo, 16), dtype=torch.float16, device=out.device)
@@ -227,6 +236,8 @@ def conv(srcs: Sequence[torch.Tensor], pc: PackedConv, *, stride: int = 1, pad: 
     check(_lib.lib().cdfo_conv_igemm(C.byref(a), _stream()), "cdfo_conv_igemm")
     if ln_out is not None:
         return out, layernorm64_hl(out, ln_out[0], ln_out[1])
+    if cp16_out:
+        return out, to_cp16(out)
     return out
 
 

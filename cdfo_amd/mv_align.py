@@ -131,11 +131,14 @@ class MVDualAttAlignment(ModulatedDeformConvPack):
             part, n = K.chan_sum_partial(v)
             gate = K.vec_mlp(part, n, P, d(self.conv_du[0].weight), d(self.conv_du[0].bias), self.out_channels // 16,
                              K.ACT_RELU, d(self.conv_du[2].weight), d(self.conv_du[2].bias), 64, K.ACT_SIGMOID)
-            o = K.conv(v, K.fold_scale_inputs(fold, gate), prec=p1)       # project_out(attn @ (v * gate)), the gate folded into the matrix
+            if ws_head:      # the 1x1 kernel also writes the fp16 chunk-planar copy the weights-stationary kernel reads
+                _, o = K.conv(v, K.fold_scale_inputs(fold, gate), prec=p1, cp16_out=True)
+            else:
+                o = K.conv(v, K.fold_scale_inputs(fold, gate), prec=p1)   # project_out(attn @ (v * gate)), the gate folded into the matrix
             if ws_head:
                 # both convolutions of the head on the weights-stationary kernel of CVSR_V8's trunk (single-pass fp16, the same
                 # rounding points as the tiled kernel's single-pass mode): ~2x its rate at 64 -> 432
-                o = K.conv3x3_ws(K.to_cp16(o), w["off0"], act=K.ACT_LRELU)
+                o = K.conv3x3_ws(o, w["off0"], act=K.ACT_LRELU)
                 K.conv_offset_mask_ws(o, w["off2"], offset, mask, flow, self.max_residue_magnitude, n_head == 1)
                 continue
             o = K.conv(o, w["off0"], pad=1, act=K.ACT_LRELU,

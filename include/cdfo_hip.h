@@ -136,7 +136,8 @@ int cdfo_to_cp16(const float* in, int ldi, int B, long long P, int C, void* out_
  * epilogue as cdfo_conv_igemm with ks = 1 (fp32 packing of cdfo_pack_conv_weight, per-image weights, fused LayerNorm,
  * residuals, pixel-shuffle store).  Every source must be a multiple of 64 channels, CoutP a multiple of 64 (<= 256).
  * With a->out2_cp16 != NULL (Cout == 64, plain store): ln_gamma / ln_beta describe a LayerNorm64 of the RESULT, written there as
- * fp16 hi | lo chunk-planar planes [B][8][P][16] (what cdfo_layernorm64_cp16hl would produce from `out`).  */
+ * fp16 hi | lo chunk-planar planes [B][8][P][16] (what cdfo_layernorm64_cp16hl would produce from `out`); with out2_cp16 set and
+ * ln_gamma == ln_beta == NULL (round 4) the second output is the result itself as fp16 chunk-planar [B][4][P][16] (= cdfo_to_cp16(out)).  */
 int cdfo_conv1x1_bf16x3(const cdfo_conv_args* a, void* stream);
 
 /* Upsampler tail without the HR feature map (arch.py:4474-4480).  cdfo_conv1x1_bf16x3 with a->store_mode =

@@ -611,3 +611,18 @@ def test_conv3x3_n16_matches_fp64_conv(B, H, W, act):
     assert tuple(out.shape) == (B, H, W, 16)
     err = (out.permute(0, 3, 1, 2).double() - ref).abs().max().item()
     assert err <= 2e-5 * max(1.0, ref.abs().max().item()), err
+
+
+def test_conv1x1_with_its_fp16_chunk_planar_copy():
+    """cp16_out: the streaming 1x1 kernel's second output == to_cp16 of its fp32 result (per-image weights, a ragged pixel count)."""
+    from cdfo_amd import kernels as K
+    g = torch.Generator(device="cuda").manual_seed(11)
+    B, H, W = 3, 19, 45
+    x = torch.randn(B, H, W, 64, device="cuda", generator=g)
+    wt = torch.randn(B, 64, 64, 1, 1, device="cuda", generator=g) / 8
+    pcs = [K.pack_conv(wt[i], None) for i in range(B)]
+    pc = K.PackedConv(torch.stack([p.w for p in pcs]).view(B, -1).contiguous(), None, 64, 64, 1, 64, False, 4096)
+    out, copy = K.conv(x, pc, prec=K.PREC_BF16X3, cp16_out=True)
+    ref = K.conv(x, pc, prec=K.PREC_BF16X3)
+    assert torch.equal(out, ref)
+    assert tuple(copy.shape) == (B, 4, H, W, 16) and torch.equal(copy, K.to_cp16(ref))

@@ -56,7 +56,8 @@ HBM_FAMILIES = {"conv1x1": ["conv1x1_stream_kernel", "conv1x1_bf16x3_kernel"], "
                 "flow_warp": ["flow_warp_kernel"], "colconv9": ["colconv9_kernel"], "chan_sum": ["chan_sum_partial_kernel"],
                 "gram": ["gram_partial_kernel"], "layout": ["swap_outer_kernel", "to_cp16_kernel", "nchw_to_nhwc", "nhwc_to_nchw"],
                 "scale": ["scale_channels_kernel"], "small_conv": ["small_conv3x3_kernel", "udsa_head_kernel"],
-                "spatial_gate": ["spatial_gate16_kernel"], "conv_last": ["conv_last"], "layernorm": ["layernorm64"]}
+                "spatial_gate": ["spatial_gate16_kernel"], "conv_last": ["conv_last"], "layernorm": ["layernorm64"],
+                "conv3x3_narrow": ["conv3x3_c64_n16_kernel"]}
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
 
 

@@ -2,6 +2,14 @@
 #include "common.h"
 
 extern "C" int cdfo_abi_version(void) { return 1; }
+static thread_local int g_cu_limit = 0;
+int cdfo_cu_limit_value() { return g_cu_limit; }
+// Limit the CUs that persistent kernels launched by THIS host thread fill (0 = all); returns the previous value.
+extern "C" int cdfo_set_cu_limit(int n) {
+  const int prev = g_cu_limit;
+  g_cu_limit = n > 0 ? n : 0;
+  return prev;
+}
 extern "C" int cdfo_sizeof_conv_args(void) { return (int)sizeof(cdfo_conv_args); }
 extern "C" const char* cdfo_build_info(void) { return "libcdfo_hip gfx950 (CDNA4) " __DATE__ " " __TIME__; }
 

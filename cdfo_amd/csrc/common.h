@@ -24,7 +24,10 @@ static inline int cdfo_cur_device() {
   int d = 0;
   return hipGetDevice(&d) == hipSuccess && d >= 0 && d < CDFO_MAXDEV ? d : -1;
 }
-// compute units of the current device (0 on failure)
+// compute units the persistent kernels launched by the calling thread may fill: the current device's count (0 on failure), or
+// the smaller value set by cdfo_set_cu_limit() (abi.hip) -- a caller that runs two schedules beside each other on two streams
+// gives each a share of the chip (a persistent workgroup takes a CU's whole LDS, so shares do not overlap)
+int cdfo_cu_limit_value();
 static inline int cdfo_num_cus() {
   static int cus[CDFO_MAXDEV] = {0};
   const int d = cdfo_cur_device();
@@ -34,7 +37,8 @@ static inline int cdfo_num_cus() {
     if (hipGetDeviceProperties(&prop, d) != hipSuccess) return 0;
     cus[d] = prop.multiProcessorCount;
   }
-  return cus[d];
+  const int lim = cdfo_cu_limit_value();
+  return (lim > 0 && lim < cus[d]) ? lim : cus[d];
 }
 // hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per (call site, device); `done` is the call site's static table
 struct CdfoAttrOnce { bool done[CDFO_MAXDEV] = {false}; };

@@ -5,6 +5,7 @@ pitch ``ld = t.stride(2)`` may exceed C, so a channel slice ``t[..., a:b]`` of a
 (this is how ``torch.cat`` disappears from the path)."""
 from __future__ import annotations
 
+import contextlib
 import ctypes as C
 from dataclasses import dataclass
 from typing import Optional, Sequence
@@ -243,6 +244,16 @@ def conv(srcs: Sequence[torch.Tensor], pc: PackedConv, *, stride: int = 1, pad: 
 
 def _vp(t):
     return C.c_void_p(None if t is None else t.data_ptr())
+
+
+@contextlib.contextmanager
+def cu_limit(n: int):
+    """Persistent kernels launched by this thread inside the block fill at most n compute units (cdfo_set_cu_limit)."""
+    prev = _lib.lib().cdfo_set_cu_limit(int(n))
+    try:
+        yield
+    finally:
+        _lib.lib().cdfo_set_cu_limit(prev)
 
 
 def conv_offset_mask(src: torch.Tensor, pc: PackedConv, offset: torch.Tensor, mask: torch.Tensor, flow: torch.Tensor, mag: float,

@@ -31,6 +31,9 @@ enum { CDFO_PREC_F32 = 0, CDFO_PREC_BF16X3 = 1, CDFO_PREC_BF16 = 2, CDFO_PREC_FP
 /* ABI version / build info.  */
 int cdfo_abi_version(void);
 const char* cdfo_build_info(void);
+/* The persistent kernels size their grids to the device's CU count; a host thread that runs two schedules beside each other on two
+ * streams gives each a share: launches of the CALLING THREAD fill at most n CUs from now on (0 = all).  Returns the previous value.  */
+int cdfo_set_cu_limit(int n);
 
 /* Dense convolution as an implicit GEMM on the matrix cores (replaces F.conv2d for 1x1 / 3x3, stride 1|2;
  * arch/SIDECVSR_our.py e.g. :383-387 Block_.body, :4382, :4386, :4390-4391).

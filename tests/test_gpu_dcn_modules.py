@@ -108,7 +108,7 @@ def test_hip_modules_train_like_the_reference_classes(path):
 
 
 @pytest.mark.parametrize("prec_name", ["bf16x3", "fp16x2"])
-@pytest.mark.parametrize("shape", [(2, 24, 36), (1, 37, 64), (3, 8, 100)])
+@pytest.mark.parametrize("shape", [(2, 24, 36), (1, 37, 64), (3, 8, 100), (2, 136, 240)])
 def test_offset_head_with_the_assembly_as_its_epilogue(shape, prec_name):
     """conv_offset[2] writing the DCN's NCHW offset / mask planes from its own epilogue (CDFO_STORE_OFFMASK; first head, then the
     second head in place) == the same convolution followed by the stand-alone assembly kernel (arch.py:3336-3350); ragged tiles

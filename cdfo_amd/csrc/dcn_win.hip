@@ -97,7 +97,10 @@ __device__ __forceinline__ f32x4 wn_bload4(__amdgpu_buffer_rsrc_t r, unsigned vo
 }
 
 // MJ: 32-channel output tiles (Co = 32 MJ); AL4: W % 4 == 0 and a 16-byte aligned input; MASK: modulated (DCNv2)
-template <int MJ, bool AL4, bool MASK>
+// DBG (developer ablations through CDFO_DCN_DBG, wrong results, tools/bench_dcn.py only): 1 = no MFMAs, 2 = no LDS reads of the
+// samples' corners, 4 = no window staging after the first chunk, 8 = no offset / mask loads after the first chunk, 16 = no
+// workgroup barriers
+template <int MJ, bool AL4, bool MASK, int DBG = 0>
 __global__ __launch_bounds__(WN_THREADS) void dcn_win_kernel(WinArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int WTS = WN_STEPS * MJ * 2 * 1024;                 // packed weights of one chunk
@@ -262,7 +265,7 @@ __global__ __launch_bounds__(WN_THREADS) void dcn_win_kernel(WinArgs a) {
     bool alive, alive_n;
     lane_offsets(chunk, vo_c, vm_c, alive);
     lane_offsets(more ? chunk + 1 : chunk, vo_n, vm_n, alive_n);
-    __syncthreads();            // buffer `buf` is complete; nobody still reads the other one
+    if (!(DBG & 16)) __syncthreads();            // buffer `buf` is complete; nobody still reads the other one
     // ---- this chunk's power-of-two scale from its window maximum
     unsigned Mb = sMax[buf * WN_NW];
 #pragma unroll
@@ -304,6 +307,11 @@ __global__ __launch_bounds__(WN_THREADS) void dcn_win_kernel(WinArgs a) {
         // come from a NaN mask (the reference's result is NaN there too) -- non-finite window data is caught by the window maximum
         vmax = fmaxf(vmax, fmaxf(fabsf(val[2 * q]), fabsf(val[2 * q + 1])));
       }
+      if (DBG & 1) {
+#pragma unroll
+        for (int j = 0; j < MJ; ++j) acc[j][0] += (float)Ah[j][0] * (float)uh.v8[0] + (float)Al[j][1] * (float)ul.v8[1];
+        return;
+      }
 #pragma unroll
       for (int j = 0; j < MJ; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah[j], uh.v8, acc[j], 0, 0, 0);
 #pragma unroll
@@ -316,7 +324,7 @@ __global__ __launch_bounds__(WN_THREADS) void dcn_win_kernel(WinArgs a) {
     unsigned wmax_n = 0u;
     f32x4 wr[4];
     if (more) {
-      fetch_task(chunk + 1, 0, wr);
+      if (!(DBG & 4)) fetch_task(chunk + 1, 0, wr);
       fetch_weights(chunk + 1);
     }
 #pragma unroll
@@ -348,21 +356,26 @@ __global__ __launch_bounds__(WN_THREADS) void dcn_win_kernel(WinArgs a) {
         const float lh = fminf(fmaxf(h_im - fh, 0.f), 1.f), lw = fminf(fmaxf(w_im - fw, 0.f), 1.f);
         const int ly = min(max((int)fh - wy0, 0), WN_WH - 2), lx = min(max((int)fw - wx0, 0), WN_WW - 2);
         const int o = (ly * WN_WW + lx) * 16;
-        const f32x4 v1 = *reinterpret_cast<const f32x4*>(win + o);
-        const f32x4 v2 = *reinterpret_cast<const f32x4*>(win + o + 16);
-        const f32x4 v3 = *reinterpret_cast<const f32x4*>(win + o + WN_WW * 16);
-        const f32x4 v4 = *reinterpret_cast<const f32x4*>(win + o + WN_WW * 16 + 16);
+        f32x4 v1, v2, v3, v4;
+        if (DBG & 2) {
+          v1 = f32x4{lh, lw, lh, lw}; v2 = v1 * 0.5f; v3 = v1 * 0.25f; v4 = v1 + (float)o;
+        } else {
+          v1 = *reinterpret_cast<const f32x4*>(win + o);
+          v2 = *reinterpret_cast<const f32x4*>(win + o + 16);
+          v3 = *reinterpret_cast<const f32x4*>(win + o + WN_WW * 16);
+          v4 = *reinterpret_cast<const f32x4*>(win + o + WN_WW * 16 + 16);
+        }
         const float ms = use ? mk[t] * s_in : 0.f;                 // an unused tap has weight 0 (finite: lh, lw were sanitised)
         const float mlh = lh * ms, mhh = ms - mlh;                 // (1 - lh) * ms
         const float w4 = mlh * lw, w3 = mlh - w4, w2 = mhh * lw, w1 = mhh - w2;
 #pragma unroll
         for (int e = 0; e < 4; ++e)
           val[4 * j + e] = __builtin_fmaf(w4, v4[e], __builtin_fmaf(w3, v3[e], __builtin_fmaf(w2, v2[e], w1 * v1[e])));
-        load_tap(vo_n, vm_n, t, oh[t], ow[t], mk[t]);      // this tap's next offsets, into the registers just freed (the last
+        if (!(DBG & 8)) load_tap(vo_n, vm_n, t, oh[t], ow[t], mk[t]);      // this tap's next offsets, into the registers just freed (the last
                                                            // chunk re-reads its own: harmless, and no branch in the stream)
       }
       split_mma(val, Ah, Al);
-      if (WN_NTASK == 2 && more && s == 2) {
+      if (WN_NTASK == 2 && more && s == 2 && !(DBG & 4)) {
         commit_task(buf ^ 1, 0, wr, wmax_n);
         fetch_task(chunk + 1, 1, wr);
       }
@@ -411,7 +424,7 @@ __global__ __launch_bounds__(WN_THREADS) void dcn_win_kernel(WinArgs a) {
       }
     }
     if (more) {
-      commit_task(buf ^ 1, WN_NTASK - 1, wr, wmax_n);
+      if (!(DBG & 4)) commit_task(buf ^ 1, WN_NTASK - 1, wr, wmax_n);
       commit_weights(buf ^ 1, wmax_n);
     }
   }
@@ -430,14 +443,14 @@ __global__ __launch_bounds__(WN_THREADS) void dcn_win_kernel(WinArgs a) {
   }
 }
 
-template <int MJ, bool AL4, bool MASK>
+template <int MJ, bool AL4, bool MASK, int DBG = 0>
 hipError_t wn_launch(const WinArgs& a, dim3 grid, hipStream_t st) {
   constexpr int LDSB = 4 * WN_WIN + 2 * (WN_STEPS * MJ * 2 * 1024) + 2 * WN_NW * 4;
   static_assert(LDSB <= 160 * 1024, "LDS budget");
   static CdfoAttrOnce once;
-  const hipError_t e = cdfo_set_max_lds(once, reinterpret_cast<const void*>(&dcn_win_kernel<MJ, AL4, MASK>), LDSB);
+  const hipError_t e = cdfo_set_max_lds(once, reinterpret_cast<const void*>(&dcn_win_kernel<MJ, AL4, MASK, DBG>), LDSB);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL((dcn_win_kernel<MJ, AL4, MASK>), grid, dim3(WN_THREADS), LDSB, st, a);
+  hipLaunchKernelGGL((dcn_win_kernel<MJ, AL4, MASK, DBG>), grid, dim3(WN_THREADS), LDSB, st, a);
   return hipGetLastError();
 }
 
@@ -487,7 +500,23 @@ int cdfo_dcn_forward_win(const float* in, const float* offset, const float* mask
     case 4: e = wn_launch<2, false, false>(a, grid, st); break;
     case 5: e = wn_launch<2, false, true>(a, grid, st); break;
     case 6: e = wn_launch<2, true, false>(a, grid, st); break;
-    default: e = wn_launch<2, true, true>(a, grid, st); break;
+    default: {
+      // developer ablations of the alignment module's variant (tools/bench_dcn.py; results are wrong by construction)
+      const char* dbg_env = getenv("CDFO_DCN_DBG");
+      switch (dbg_env ? atoi(dbg_env) : 0) {
+        case 1: e = wn_launch<2, true, true, 1>(a, grid, st); break;
+        case 2: e = wn_launch<2, true, true, 2>(a, grid, st); break;
+        case 4: e = wn_launch<2, true, true, 4>(a, grid, st); break;
+        case 8: e = wn_launch<2, true, true, 8>(a, grid, st); break;
+        case 16: e = wn_launch<2, true, true, 16>(a, grid, st); break;
+        case 3: e = wn_launch<2, true, true, 3>(a, grid, st); break;
+        case 12: e = wn_launch<2, true, true, 12>(a, grid, st); break;
+        case 15: e = wn_launch<2, true, true, 15>(a, grid, st); break;
+        case 31: e = wn_launch<2, true, true, 31>(a, grid, st); break;
+        default: e = wn_launch<2, true, true>(a, grid, st); break;
+      }
+      break;
+    }
   }
   return e == hipSuccess ? 1 : 2 + (int)e;
 }

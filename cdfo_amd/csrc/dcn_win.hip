@@ -502,8 +502,8 @@ int cdfo_dcn_forward_win(const float* in, const float* offset, const float* mask
     case 6: e = wn_launch<2, true, false>(a, grid, st); break;
     default: {
       // developer ablations of the alignment module's variant (tools/bench_dcn.py; results are wrong by construction)
-      const char* dbg_env = getenv("CDFO_DCN_DBG");
-      switch (dbg_env ? atoi(dbg_env) : 0) {
+      static const int dbg_sel = [] { const char* v = getenv("CDFO_DCN_DBG"); return v ? atoi(v) : 0; }();      // read once per process
+      switch (dbg_sel) {
         case 1: e = wn_launch<2, true, true, 1>(a, grid, st); break;
         case 2: e = wn_launch<2, true, true, 2>(a, grid, st); break;
         case 4: e = wn_launch<2, true, true, 4>(a, grid, st); break;

@@ -246,3 +246,25 @@ def test_repeated_spatial_gate_as_a_running_per_pixel_product():
     assert (out2 - ref2).abs().max().item() < 2e-6
     with pytest.raises(Exception):
         K.conv(src, pc, res2=x0, res2_scale=G)        # the exact-fp32 kernel has no scaled residual: loud, not silent
+
+
+def test_v7_multi_tile_size_matches_the_oracle():
+    """The golden cases are 16x16 ... 24x32 (one or two tiles per kernel); at 64x96 every level of the pyramid spans several tiles of the
+    persistent kernels (the weights-stationary offset head, the ring / streaming kernels, the DCN's window tiles).  Fresh path, one
+    clip, both 16-bit modes against ONE run of the CPU oracle."""
+    from oracle.cvsr_v7_ref import cvsr_v7_forward, make_inputs_v7
+    B, H, W = 1, 64, 96
+    model, sd = _model(5)
+    inp = make_inputs_v7(B, H, W, 41, "b1n")
+    dev = {k: v.cuda() for k, v in inp.items() if k != "gumbel_u"}
+    noise = [u.cuda() for u in inp["gumbel_u"]]
+    with torch.no_grad():
+        ref_out, ref_L1 = cvsr_v7_forward(sd, inp["x"], inp["mvs0"], inp["mvs1"], inp["pms"], inp["rms"], inp["ufs"], None, inp["gumbel_u"], {})
+    for precision in ("bf16x3", "fp16x2"):
+        model.precision = precision
+        with torch.no_grad():
+            out, L1 = model(dev["x"], dev["mvs0"], dev["mvs1"], dev["pms"], dev["rms"], dev["ufs"], None, gumbel_uniform=noise)
+        e_out = (out.cpu() - ref_out).abs().max().item()
+        e_l1 = (L1.cpu() - ref_L1).abs().max().item()
+        print(precision, f"64x96: out {e_out:.2e} L1_fea {e_l1:.2e}")
+        assert e_out <= TOL and e_l1 <= TOL, (precision, e_out, e_l1)

@@ -186,7 +186,7 @@ class CVSR_V7(nn.Module):
         """``PartitionTransformerBlock.forward`` (arch.py:1350-1368): four weight-shared rounds."""
         raw = w["raw"]
         p = "transformer_feature_extraction.path1."
-        lazy_gate = self.precision == "fp16x2"
+        lazy_gate = self.precision != "f32"          # every mode whose 1x1 convolutions run on the streaming kernel
         if lazy_gate:
             # the prior branch is only ever gated (x2_k = x2_{k-1} * g_k, one shared SpatialAttention): x2_k = x2_0 * G_k with a per-pixel
             # running product G, pool(x2_k) = G_k * pool(x2_0) -- one pooling pass, a one-float-per-pixel plane per round, and the
@@ -206,7 +206,7 @@ class CVSR_V7(nn.Module):
                                     ln_out=(raw[p + "norm2.body.weight"], raw[p + "norm2.body.bias"]))
                 x1 = K.conv_ring(ln, w[p + "conv_hl"], res1=x1, plane_wrap=8)
                 continue
-            x1 = self._conv(v, fold, res1=x1, res2=x2)
+            x1 = self._conv(v, fold, res1=x1, res2=x2, res2_scale=G if lazy_gate else None)
             ln = K.layernorm64(x1, raw[p + "norm2.body.weight"], raw[p + "norm2.body.bias"])
             x1 = self._conv(ln, w[p + "conv"], pad=1, res1=x1, exact=True)
         return x1

@@ -40,10 +40,12 @@ PEAK_TFLOPS = {"f32": 157.3, "bf16x3": 2500.0, "bf16": 2500.0, "fp16x2": 2500.0}
 MFMA_PASSES = {"f32": 1, "bf16x3": 3, "bf16": 1, "fp16x2": 2}   # tiled kernel; the Block_ kernels (ws, ring) are 1-pass fp16                    # bf16 MFMA MACs issued per algorithmic MAC
 KID_NAMES = ["conv3x3_wide", "conv3x3_narrow", "conv1x1", "conv3x3_s2", "stem", "layernorm", "dwconv", "flow_warp",
              "resample", "scale", "conv_last", "small_conv", "spatial_gate", "chan_sum", "gram", "fold", "rdab_prep",
-             "colconv9", "attn_row", "attn_col", "attn_win", "layout", "pack", "dcn", "conv3x3_ws", "conv3x3_ring", "conv3x3_ring4", "conv3x3_ws_res", "dcn_bwd"]
+             "colconv9", "attn_row", "attn_col", "attn_win", "layout", "pack", "dcn", "conv3x3_ws", "conv3x3_ring", "conv3x3_ring4", "conv3x3_ws_res", "dcn_bwd", "conv3x3_wino"]
 # kernel families on the 16-bit matrix cores -> (kernel symbol in the rocprofv3 stats, MFMA passes per algorithmic MAC)
 # conv3x3_wide (the tiled kernel) runs the --precision mode's passes: fp16x2 = 2 (3 for the split-bf16 feature cache)
+# conv3x3_wino (Block_.body[0] since round 5): Winograd F(2,3) along x issues 12 MFMA MACs per 18 algorithmic ones
 MFMA16 = {"conv3x3_wide": ("conv3x3_mma16_kernel", None), "conv3x3_ws": ("conv3x3_c64_wsq_kernel", 1),
+          "conv3x3_wino": ("conv3x3_c64_wino_kernel", 0.667),
           "conv3x3_ws_res": ("conv3x3_c64_ws_kernel<0, true, 8>", 1),
           "conv3x3_ring": ("conv3x3_ring_kernel<false", 1), "conv3x3_ring4": ("conv3x3_ring_split_kernel<true", 1)}
 
@@ -59,6 +61,34 @@ HBM_FAMILIES = {"conv1x1": ["conv1x1_stream_kernel", "conv1x1_bf16x3_kernel"], "
                 "spatial_gate": ["spatial_gate16_kernel"], "conv_last": ["conv_last"], "layernorm": ["layernorm64"],
                 "conv3x3_narrow": ["conv3x3_c64_n16_kernel"]}
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+# kernel family -> the cdfo_amd/csrc files its kernels live in.  tools/pmc_summary.py stores their SHA-256 next to the PMC traffic it
+# writes into profiles/traffic_*.json; a replayed figure whose sources have changed since is reported with "traffic_stale": true
+FAMILY_SOURCES = {"conv3x3_wide": ["conv3x3_bf16.hip"], "conv3x3_ws": ["conv3x3_ws.hip"], "conv3x3_wino": ["conv3x3_wino.hip"],
+                  "conv3x3_ws_res": ["conv3x3_ws.hip"], "conv3x3_ring": ["conv3x3_ring.hip"], "conv3x3_ring4": ["conv3x3_ring.hip"],
+                  "conv1x1": ["conv1x1_stream.hip", "conv1x1_bf16x3.hip"], "dwconv": ["qkv_dw.hip", "pointwise.hip"],
+                  "attn_row": ["attention.hip"], "attn_col": ["attention.hip"], "attn_win": ["attention.hip"], "rdab_prep": ["attention.hip"],
+                  "colconv9": ["attention.hip"], "resample": ["block_pro.hip", "pointwise.hip"], "stem": ["pointwise.hip"],
+                  "flow_warp": ["pointwise.hip"], "chan_sum": ["stats.hip"], "gram": ["stats.hip"], "layout": ["layout.hip", "conv3x3_ws.hip"],
+                  "scale": ["pointwise.hip"], "small_conv": ["smallconv.hip"], "spatial_gate": ["smallconv.hip"], "conv_last": ["pointwise.hip"],
+                  "layernorm": ["pointwise.hip"], "conv3x3_narrow": ["conv3x3_n16.hip"], "dcn": ["dcn_win.hip", "dcn_fast.hip", "dcn.hip"]}
+
+
+def source_hashes(family):
+    """{file: sha256} of a kernel family's sources in THIS tree (no git needed: the GPU box has none)."""
+    import hashlib
+    out = {}
+    for f in FAMILY_SOURCES.get(family, []):
+        q = os.path.join(ROOT, "cdfo_amd", "csrc", f)
+        out[f] = hashlib.sha256(open(q, "rb").read()).hexdigest() if os.path.exists(q) else None
+    return out
+
+
+def traffic_stale(family, recorded):
+    """True when the PMC figure of `family` was collected on other kernel sources than this tree's (or carries no hashes at all:
+    files of rounds 1-4), False when every source file still hashes to what tools/pmc_summary.py recorded."""
+    if not recorded:
+        return True
+    return any(recorded.get(f) != h for f, h in source_hashes(family).items())
 
 
 def load_traffic(precision):
@@ -159,10 +189,14 @@ def main():
             with socket.socket() as sk:
                 sk.bind(("127.0.0.1", 0))
                 os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(sk.getsockname()[1]), RANK="0", WORLD_SIZE="1")
+        # explicit collective timeout: at N > 1 rank 0 runs the CPU oracle on one full-size clip (tens of seconds; minutes on a loaded
+        # host) while the other ranks already wait in the metric all_gather -- the wait must never be mistaken for a hang
+        import datetime
+        pg_timeout = datetime.timedelta(seconds=int(os.environ.get("CDFO_BENCH_PG_TIMEOUT_S", "3600")))
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
+            dist.init_process_group("nccl", device_id=dev, timeout=pg_timeout)
         else:
-            dist.init_process_group(backend)
+            dist.init_process_group(backend, timeout=pg_timeout)
 
     from arch.SIDECVSR_our import CVSR_V8
     from cdfo_amd import _lib
@@ -355,6 +389,7 @@ def main():
         tr = load_traffic(args.precision)
         tfam = tr.get("families", {})
         traffic = (tfam.get(KID_NAMES[dom]) or {}).get("hbm_bytes_per_launch")
+        traffic_is_stale = traffic_stale(KID_NAMES[dom], (tfam.get(KID_NAMES[dom]) or {}).get("source_sha256")) if traffic else None
 
         def hbm_fam(k):
             name = KID_NAMES[k]
@@ -366,10 +401,11 @@ def main():
                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
                     "algorithmic_bytes_per_launch": round(bpl), "launches_per_step": launches[k] // max(1, args.steps),
                     "avg_launch_ms": round(avg_ms, 4), "share_of_gpu_time": round(ms[k] / max(1e-9, sum(ms)), 4),
-                    "traffic": pmc, "traffic_ratio": (round(pmc / bpl, 3) if pmc and bpl else None)}
+                    "traffic": pmc, "traffic_ratio": (round(pmc / bpl, 3) if pmc and bpl else None),
+                    "traffic_stale": (traffic_stale(name, (tfam.get(name) or {}).get("source_sha256")) if pmc else None)}
         hbm_rows = sorted((k for k in range(nk) if KID_NAMES[k] in HBM_FAMILIES and launches[k] and by[k] > 0), key=lambda k: -ms[k])[:6]
         wf = F * B * args.steps / t_max / 1e12
-        roofline = {"bound": "mfma", **fam(dom), "traffic": traffic,
+        roofline = {"bound": "mfma", **fam(dom), "traffic": traffic, "traffic_stale": traffic_is_stale,
                     "whole_forward_tflops": round(wf, 2), "whole_forward_frac": round(wf / PEAK_TFLOPS[args.precision], 4),
                     "measured_in": f"second pass over the same {args.steps} steps with one HIP-event pair per launch on the launch "
                                    f"stream ({round(1e3 * allm[:, 4].max().item() / args.steps, 3)} ms per step with the events)",
@@ -409,9 +445,13 @@ def main():
         if world == 1 and not args.no_parity and not args.no_extra_modes:
             # the path's other operator row, outside the timed region: the fused DCNv2 forward at the
             # alignment module's shape against its HBM roofline (same definitions as tools/bench_dcn.py)
+            # BASELINE configs 2 and 5 (the single-GPU share of c5), outside the timed region
+            res["other_configs"] = other_configs_line(model, sd, dev)
             res["dcn_forward"] = dcn_forward_line(dev, Hp, Wp, B)
             # SURVEY section 8f n3, also outside the timed region: the DCN-aligned CVSR_V7 on the same synthetic clips
             res["cvsr_v7"] = cvsr_v7_line(dev, d, Hp, Wp, B)
+            if res["cvsr_v7"].get("parity_ok") is False:
+                parity_ok = False
             torch.cuda.empty_cache()
             # SURVEY section 8f n1 / n2, outside the timed region: the reference's real evaluation loop (one sequence, one new
             # frame per forward, test_LD_22_FPS.py:183-192) and its training step (train_LD_37.py:376-381)
@@ -500,17 +540,77 @@ def train_step_line(device, B=20, H=64, W=64, iters=3):
     return res
 
 
+def other_configs_line(model, sd, device):
+    """BASELINE.json configs 2 (4 clips of 7x1x120x240 -> 480x960) and 5 (7x1x540x960 -> 2160x3840, one clip per GPU) on the timed
+    model, outside the timed region: ms / frames/s / whole-forward TFLOP/s each (c2 also from a HIP-graph replay: ~270 launches in
+    ~15 ms are gap-bound), and clip 0 of the c2 batch against the CPU oracle with the noise that forward drew."""
+    from oracle.cvsr_v8_ref import cvsr_v8_forward, make_inputs
+    out = {}
+
+    def run(B, H, W, seed, pad_rows, steps, want_parity, want_graph):
+        inp = make_inputs(B, H, W, seed, pad_rows=pad_rows)
+        dd = {k: v.to(device) for k, v in inp.items() if k != "gumbel_u"}
+        fwd = lambda: model(dd["x"], dd["mvs0"], dd["mvs1"], dd["pms"], dd["rms"], dd["ufs"])      # noqa: E731
+        res = {}
+        with torch.no_grad():
+            cap = []
+            model.capture_noise = cap if want_parity else None
+            got, _ = fwd()
+            model.capture_noise = None
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                fwd()
+            torch.cuda.synchronize()
+            ms = (time.perf_counter() - t0) / steps * 1e3
+            res.update({"ms_per_step": round(ms, 3), "frames_per_s": round(B / ms * 1e3, 2),
+                        "whole_forward_tflops": round(flops_per_clip(H, W) * B / ms / 1e9, 1), "steps": steps})
+            if want_graph:
+                try:
+                    g = model.capture(dd["x"], dd["mvs0"], dd["mvs1"], dd["pms"], dd["rms"], dd["ufs"])
+                    g.replay()
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    for _ in range(steps):
+                        g.replay()
+                    torch.cuda.synchronize()
+                    gms = (time.perf_counter() - t0) / steps * 1e3
+                    res["hip_graph"] = {"ms_per_step": round(gms, 3), "frames_per_s": round(B / gms * 1e3, 2)}
+                    del g
+                except Exception as e:      # a line of the report, never a reason to lose the headline
+                    res["hip_graph"] = {"error": repr(e)[:200]}
+            if want_parity:
+                ref, _ = cvsr_v8_forward(sd, inp["x"][0:1], None, inp["mvs1"][0:1], inp["pms"][0:1], inp["rms"][0:1], inp["ufs"][0:1], None,
+                                         [u[0:1].cpu() for u in cap])
+                e = (got[0:1].cpu() - ref).abs().max().item()
+                res.update({"clip0_max_abs_vs_oracle": e, "within_1e-3": bool(e <= PARITY_BOUND)})
+        del dd, got
+        torch.cuda.empty_cache()
+        return res
+
+    out["c2"] = {"workload": "4 clips x 7x1x120x240 -> 480x960, fresh path, one GPU", **run(4, 120, 240, 1001, 0, 10, True, True)}
+    out["c5_one_clip"] = {"workload": "1 clip x 7x1x540x960 (padded to 544) -> 2160x3840, fresh path = one GPU's share of config 5",
+                          **run(1, 544, 960, 1005, 4, 3, False, False)}
+    return out
+
+
 def cvsr_v7_line(device, d, H, W, B, steps=2):
+    """CVSR_V7 (arch.py:4215-4367) on the timed clips in both arithmetic modes; clip 0 of the fp16x2 batch is checked against the CPU
+    oracle (oracle/cvsr_v7_ref.py over the threaded C DCN oracle) at the timed size: the run FAILS above the 1e-3 bound.  `roofline`
+    names the forward's dominant kernel family by live HIP-event time (second pass, one event pair per launch)."""
     from arch.SIDECVSR_our import CVSR_V7
+    from cdfo_amd import _lib
+    lib = _lib.lib()
     torch.manual_seed(0)
     m = CVSR_V7().to(device).eval()                      # random init of the reference architecture
     g = torch.Generator(device=device).manual_seed(7)
     noise = [torch.rand(B, 64, H >> lv, W >> lv, device=device, generator=g).clamp_min_(1e-6) for lv in (2, 1, 0) for _ in range(12)]
     out = {}
+    got0 = None
     for prec in ("bf16x3", "fp16x2"):
         m.precision = prec
         with torch.no_grad():
-            m(d["x"], -d["mvs1"], d["mvs1"], d["pms"], d["rms"], d["ufs"], gumbel_uniform=noise)
+            o, _ = m(d["x"], -d["mvs1"], d["mvs1"], d["pms"], d["rms"], d["ufs"], gumbel_uniform=noise)
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             for _ in range(steps):
@@ -518,9 +618,56 @@ def cvsr_v7_line(device, d, H, W, B, steps=2):
             torch.cuda.synchronize()
         ms = (time.perf_counter() - t0) / steps * 1e3
         out[prec] = {"ms_per_forward": round(ms, 2), "frames_per_s": round(B / ms * 1e3, 2)}
+        if prec == "fp16x2":
+            got0 = o[0:1].cpu()
+        del o
+    # dominant kernel family of the fp16x2 forward: one more forward with one HIP-event pair per launch
+    nk = lib.cdfo_prof_kid_count()
+    _lib.check(lib.cdfo_prof_begin(8000), "cdfo_prof_begin")
+    with torch.no_grad():
+        m(d["x"], -d["mvs1"], d["mvs1"], d["pms"], d["rms"], d["ufs"], gumbel_uniform=noise)
+    torch.cuda.synchronize()
+    launches, kms, fl, by = (C.c_int * nk)(), (C.c_double * nk)(), (C.c_double * nk)(), (C.c_double * nk)()
+    nrec = lib.cdfo_prof_end(launches, kms, fl, by, nk)
+    roof = None
+    if nrec > 0:
+        dom = max(range(nk), key=lambda k: kms[k])
+        avg = kms[dom] / max(1, launches[dom])
+        name = KID_NAMES[dom]
+        if name in MFMA16:
+            passes = MFMA16[name][1] or MFMA_PASSES["fp16x2"]
+            ach = fl[dom] / max(1, launches[dom]) / (avg * 1e-3) / 1e12 if avg > 0 else 0.0
+            roof = {"bound": "mfma", "kernel": name, "kernel_symbol": MFMA16[name][0], "achieved": round(ach, 2), "peak": PEAK_TFLOPS["fp16x2"],
+                    "unit": "TFLOP/s", "frac": round(ach / PEAK_TFLOPS["fp16x2"], 4), "mfma_passes_per_mac": passes}
+        else:
+            ach = by[dom] / max(1, launches[dom]) / (avg * 1e-3) / 1e9 if avg > 0 else 0.0
+            roof = {"bound": "hbm", "kernel": name, "kernel_symbols": HBM_FAMILIES.get(name, [name]), "achieved": round(ach, 1),
+                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4)}
+        roof.update({"launches_per_forward": launches[dom], "avg_launch_ms": round(avg, 4), "share_of_gpu_time": round(kms[dom] / max(1e-9, sum(kms)), 4),
+                     "launches_per_forward_all_families": int(sum(launches)), "traffic": None,
+                     "measured_in": "one extra fp16x2 forward with one HIP-event pair per launch on the launch stream"})
     del m
     torch.cuda.empty_cache()
-    return {"workload": f"CVSR_V7 forward, {B} clips x 7x1x{H}x{W}, fresh path, random init", **out}
+    res = {"workload": f"CVSR_V7 forward, {B} clips x 7x1x{H}x{W}, fresh path, random init", **out, "roofline": roof}
+    # ---- deferred parity gate: CPU oracle on clip 0 (same seeds => same weights: torch.manual_seed(0) + default construction)
+    try:
+        from oracle.cvsr_v7_ref import cvsr_v7_forward
+    except Exception as e:
+        res["parity"] = {"verified": False, "error": repr(e)[:200]}
+        res["parity_ok"] = False
+        return res
+    torch.manual_seed(0)
+    sd = {k: v.detach().cpu() for k, v in CVSR_V7().state_dict().items()}
+    torch.set_num_threads(_host_cores())
+    t0 = time.perf_counter()
+    with torch.no_grad():
+        ref, _ = cvsr_v7_forward(sd, d["x"][0:1].cpu(), -d["mvs1"][0:1].cpu(), d["mvs1"][0:1].cpu(), d["pms"][0:1].cpu(), d["rms"][0:1].cpu(),
+                                 d["ufs"][0:1].cpu(), [u[0:1].cpu() for u in noise])
+    e = (got0 - ref).abs().max().item()
+    res["parity"] = {"config": f"clip 0 of the fp16x2 batch ({H}x{W}) vs oracle/cvsr_v7_ref.py (C DCN oracle)", "max_abs": e, "bound": PARITY_BOUND,
+                     "verified": bool(e <= PARITY_BOUND), "oracle_seconds": round(time.perf_counter() - t0, 1)}
+    res["parity_ok"] = bool(e <= PARITY_BOUND)
+    return res
 
 
 def dcn_forward_line(device, H, W, B, iters=10):
@@ -546,7 +693,7 @@ def dcn_forward_line(device, H, W, B, iters=10):
     ms = e0.elapsed_time(e1) / iters
     nbytes = (C + 3 * dg * 9 + Co) * H * W * 4 * B + w.numel() * 4
     ach = nbytes / ms / 1e6
-    traffic, traffic_commit = None, None
+    traffic, traffic_commit, dcn_stale = None, None, None
     tpath = next((q for q in (os.path.join(ROOT, "profiles", f"traffic_dcn_r{r:02d}.json") for r in range(9, 0, -1)) if os.path.exists(q)), "")
     if tpath and (B, H, W) == (8, 272, 480):     # PMC passes of tools/bench_dcn.py at exactly this shape
         try:
@@ -555,6 +702,7 @@ def dcn_forward_line(device, H, W, B, iters=10):
             if tj.get("kernel", "").startswith("dcn_win"):
                 traffic = tj["hbm_bytes_per_launch"] + tj["prepass_hbm_bytes_per_launch"]
                 traffic_commit = tj.get("commit")
+                dcn_stale = traffic_stale("dcn", tj.get("source_sha256"))
         except Exception:
             traffic = None
     # the operator's backward at the same shape (all five gradients, as tools/bench_dcn.py --backward)
@@ -575,7 +723,8 @@ def dcn_forward_line(device, H, W, B, iters=10):
     return {"workload": f"DCNv2 forward C=Co=64 dg=16 3x3, {B}x{H}x{W}, MV-like offsets", "ms_per_launch": round(ms, 4),
             "roofline": {"bound": "hbm", "achieved": round(ach, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(ach / 8000.0, 4),
                          "algorithmic_bytes_per_launch": nbytes, "traffic": traffic,
-                         "traffic_ratio": (round(traffic / nbytes, 3) if traffic else None), "profiles_commit": traffic_commit},
+                         "traffic_ratio": (round(traffic / nbytes, 3) if traffic else None), "profiles_commit": traffic_commit,
+                         "traffic_stale": dcn_stale},
             "backward_ms_per_launch": round(ms_b, 4)}
 
 

@@ -1,0 +1,447 @@
+// 3x3 stride-1 convolution with 64 input channels as a ROW-STREAMING Winograd F(2,3) product along x (fp16 MFMA, fp32 accumulate).
+//
+// Block_.body[0] (arch/SIDECVSR_our.py:383-387: Conv2d(64, 256, 3, 1, 1) + LeakyReLU) is a third of the forward's time and its direct
+// form (conv3x3_ws.hip) is matrix-pipe / power bound: 1.05-1.18 PFLOP/s whatever the schedule.  The lever left is the number of
+// MFMAs.  The one-dimensional minimal filtering algorithm F(2,3) along x computes two adjacent outputs of a row from four
+// transformed inputs instead of six products:
+//     d = x[2t-1 .. 2t+2],   V0 = d0 - d2,  V1 = d1 + d2,  V2 = d2 - d1,  V3 = d1 - d3                       (per input row, channel)
+//     U0 = g0,  U1 = (g0 + g1 + g2) / 2,  U2 = (g0 - g1 + g2) / 2,  U3 = g2                                 (per kernel row dy)
+//     M_xi = sum over dy, channel of U_xi[dy] * V_xi[row + dy - 1]
+//     y[2t] = M0 + M1 + M2,   y[2t+1] = M1 - M2 - M3
+// i.e. four independent "3x1 vertical convolutions" with K = 3 x 64 on a half-width grid: 2/3 of the direct form's MACs.  The
+// two-dimensional F(2x2,3x3) would cut them to 4/9 but its 24-add output transform per output channel does not hide beside the
+// MFMAs of a 64-deep contraction, and the kernel would sit on the HBM roof anyway (the fp16 result is 4x the input).
+// Numerics: V and U are rounded to fp16 once (v_pk_add_f16 rounds the exact difference; U is formed in fp32 on the host); measured
+// against an exact convolution the result's error is ~1.3x that of the direct product on fp16-rounded operands.  |V| <= 2 |x|: the
+// model's fp16 range guard budgets for the factor two.
+//
+// Structure (no LDS-DMA, no weights in LDS):
+//   * persistent 512-thread workgroup per CU = 128 output channels x a sequence of UNITS (image, 32-pixel column strip, row
+//     segment); the Cout / 128 workgroups of a unit sit on one XCD and run the same unit sequence (shared L2);
+//   * wave w owns 16 output channels whose 24 weight fragments (3 dy x 4 xi x 2 K halves, `cdfo_pack_conv3x3_wino`) stay in its
+//     REGISTERS for the whole launch (96 VGPRs): the matrix cores' A operand never touches LDS;
+//   * the unit is walked down one input row at a time: row i adds U[0] V[i] to output row i + 1, U[1] V[i] to row i and U[2] V[i]
+//     to row i - 1, which is then complete (three rolling accumulator sets of 4 xi x 16 channels x 16 column pairs): 24
+//     v_mfma_f32_16x16x32_f16 per row and wave, no vertical halo recompute inside a segment;
+//   * V is computed ONCE per workgroup: per batch of three input rows wave w = (xi, K half) loads its two raw fragments per row
+//     straight from global memory into registers (lane = column pair x 8-channel group = the MFMA B-fragment lane), forms V with
+//     four v_pk_add_f16 and writes one 1 KiB fragment per row into a two-slot LDS ring; all eight waves read the eight fragments of
+//     a row back in lane order (conflict-free).  One workgroup barrier per batch; the loads of batch n + 2 are in flight while
+//     batch n computes;
+//   * the epilogue of a completed row is lane-local: 4 adds per output channel (the output transform), activation, fp16, two
+//     8-byte stores (columns 2t, 2t + 1) into the chunk-planar result [B][Cout/16][H][W][16] or its space-to-depth form.
+#include "common.h"
+#include <type_traits>
+
+namespace {
+
+typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4_t __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+
+constexpr int WN_THREADS = 512;
+constexpr int WN_ROWS = 3;                       // input rows per batch (= the period of the rolling accumulator sets)
+constexpr int WN_VROW = 8 * 1024;                // V of one input row: fragment xi * 2 + K half, 1 KiB each
+constexpr int WN_SLOT = WN_ROWS * WN_VROW;
+constexpr int WN_LDS = 2 * WN_SLOT;              // 48 KiB
+
+struct wino_args {
+  const unsigned char* src; int B, H, W;
+  const f16x8_t* w; const float* bias; int Cout, act;
+  _Float16* out; int s2d;
+  int seg_h, nseg, nstrips, nb;                  // rows per segment, segments per strip, strips per image row, batches per unit
+};
+
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+
+// The pixel loads are compiler-visible buffer loads: their data crosses basic blocks in REGISTERS (issued in one batch, consumed in
+// the next), and hipcc may copy such registers at a control-flow merge -- with inline-assembly loads it did so while the data was
+// still in flight (stale V fragments in the first batches of a unit, timing dependent).  The price of visible loads is hipcc's
+// wait-count pass, which merges the states of a loop's pre-header and back edge pessimistically: the loops below are arranged so
+// that every path into a batch has issued the SAME sequence [row-0 store, six loads, row-1 store, row-2 store] before it.
+// DBG (developer ablations, wrong results): 1 = no MFMAs, 2 = no global loads, 4 = no stores, 8 = no epilogue arithmetic,
+// 16 = no barrier / V exchange wait
+template <bool S2D, int DBG>
+__global__ __launch_bounds__(WN_THREADS) void conv3x3_c64_wino_kernel(wino_args a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, t16 = lane & 15, kg = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int H = a.H, W = a.W, NB = a.nb;
+  const int nhalf = a.Cout >> 7;
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, nslots = gridDim.x >> 3;
+  const int npairs = nslots / nhalf;
+  const int half = slot % nhalf, pair = slot / nhalf;
+  if (pair >= npairs) return;
+  const int units_img = a.nstrips * a.nseg, n_units = a.B * units_img;
+  const int stride_u = npairs * 8, first_u = pair * 8 + xcd;
+  const int my_units = first_u < n_units ? (n_units - first_u + stride_u - 1) / stride_u : 0;
+  if (my_units == 0) return;
+  const int T = my_units * NB;
+
+  // ---- this wave's weights and bias: 16 output channels cb * 16 .. + 15; accumulator rows 4 kg .. 4 kg + 3 of column t16
+  const int cb = half * 8 + wave;
+  f16x8_t wf[3][4][2];
+  {
+    const f16x8_t* wp = a.w + (long long)cb * 24 * 64 + lane;
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+      for (int xi = 0; xi < 4; ++xi)
+#pragma unroll
+        for (int sc = 0; sc < 2; ++sc) wf[dy][xi][sc] = wp[((dy * 4 + xi) * 2 + sc) * 64];
+    // a use right here: the compiler's wait-count bookkeeping then has no weight load pending at the loop entry (it would merge
+    // such a pending load into the loop's back edge and wait for the PREFETCHED pixel loads inside the MFMA blocks)
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+      for (int xi = 0; xi < 4; ++xi)
+#pragma unroll
+        for (int sc = 0; sc < 2; ++sc) asm volatile("" : "+v"(wf[dy][xi][sc]));
+  }
+  f32x4 binit = {0.f, 0.f, 0.f, 0.f};
+  if (a.bias) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) binit[k] = a.bias[cb * 16 + 4 * kg + k];
+  }
+  asm volatile("" : "+v"(binit));      // waited for here, not inside the loop (see the weights)
+  const f32x4 zinit = {0.f, 0.f, 0.f, 0.f};
+  const float slope = a.act == CDFO_ACT_NONE ? 1.f : (a.act == CDFO_ACT_LRELU ? 0.1f : 0.f);
+
+  // ---- V production role of this wave: fragment wave = xi_p * 2 + sc_p; V = sA dA + sB dB with
+  //      xi 0: d0 - d2, xi 1: d1 + d2, xi 2: d2 - d1, xi 3: d1 - d3   (d_j = pixel x0 + 2t + j - 1)
+  const int xi_p = wave >> 1, sc_p = wave & 1;
+  const int jA = xi_p == 0 ? 0 : (xi_p == 2 ? 2 : 1), jB = xi_p == 0 ? 2 : (xi_p == 1 ? 2 : (xi_p == 2 ? 1 : 3));
+  const _Float16 vsg = xi_p == 1 ? (_Float16)1.f : (_Float16)-1.f;
+  const f16x8_t vsgn = {vsg, vsg, vsg, vsg, vsg, vsg, vsg, vsg};
+  const unsigned img_bytes = (unsigned)(H * W) * 128u;                   // 4 planes x 32 bytes per pixel
+  const unsigned lane_src = (unsigned)(sc_p * 2 + (kg >> 1)) * (unsigned)(H * W) * 32u + (unsigned)(kg & 1) * 16u;
+  const int nck = a.Cout >> 4;
+  const unsigned out_img_bytes = (unsigned)nck * (unsigned)(H * W) * 32u;
+  const unsigned lane16 = (unsigned)lane * 16u;
+
+  auto unit_coords = [&](int ord, int& b, int& x0, int& y0, int& y1) {
+    const int u = (ord * npairs + pair) * 8 + xcd;
+    b = u / units_img;
+    const int r = u - b * units_img;
+    const int sy = r / a.nstrips;
+    x0 = (r - sy * a.nstrips) * 32; y0 = sy * a.seg_h; y1 = min(y0 + a.seg_h, H);
+  };
+  // per-lane address parts (they depend on the unit's x0 only): the row part of every access is a scalar offset, a row outside
+  // the image / segment gets a zero-sized buffer descriptor (hardware zero fill) -- no vector instruction per load or store
+  auto src_lane_offsets = [&](int x0, unsigned& va, unsigned& vb) {
+    const int xa = x0 + 2 * t16 + jA - 1, xb = x0 + 2 * t16 + jB - 1;
+    va = (xa >= 0 && xa < W) ? lane_src + (unsigned)xa * 32u : 0x80000000u;
+    vb = (xb >= 0 && xb < W) ? lane_src + (unsigned)xb * 32u : 0x80000000u;
+  };
+
+  u32x4 raw[WN_ROWS][2];
+  // (batches past the end re-load / re-write the last one: no branch in the steady-state loop)
+  auto issue_loads = [&](int n, unsigned va, unsigned vb, int b, int y0, int y1, int i0) {
+    const unsigned char* base = a.src + (long long)b * img_bytes;
+#pragma unroll
+    for (int j = 0; j < WN_ROWS; ++j) {
+      const int y = i0 + j;
+      const int rowok = -(int)(y >= 0 && y < H && y <= y1);      // all ones / zero: scalar masks, no branch
+      const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(base), 0, (int)img_bytes & rowok, 0x00020000);
+      const int so = (y * W * 32) & rowok;
+      if (DBG & 2) {
+        raw[j][0] = u32x4{va, vb, (unsigned)so, 0u}; raw[j][1] = u32x4{vb, va, 0u, (unsigned)so};
+      } else {
+        raw[j][0] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)va, so, 0));
+        raw[j][1] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)vb, so, 0));
+      }
+    }
+  };
+  auto write_v = [&](int n) {
+    unsigned uoff = (unsigned)((n & 1) * WN_SLOT + wave * 1024);
+    asm volatile("" : "+s"(uoff));        // formed per batch from the lane part every LDS access shares (a hoisted copy gets spilled)
+    unsigned char* dst = smem + lane16 + uoff;
+#pragma unroll
+    for (int j = 0; j < WN_ROWS; ++j) {
+      const f16x8_t va = __builtin_bit_cast(f16x8_t, raw[j][0]), vb = __builtin_bit_cast(f16x8_t, raw[j][1]);
+      *reinterpret_cast<f16x8_t*>(dst + j * WN_VROW) = __builtin_elementwise_fma(vb, vsgn, va);      // one rounding: exact sum, rounded
+    }
+  };
+
+  f32x4 acc[3][4];      // [row slot][xi]
+#pragma unroll
+  for (int s = 0; s < 3; ++s)
+#pragma unroll
+    for (int xi = 0; xi < 4; ++xi) acc[s][xi] = zinit;
+
+  // one batch of three input rows.  ALL = every output row the batch touches is inside the segment (the steady state: straight-line
+  // code, 72 MFMAs); otherwise the rows are guarded one by one (first / last batches of a unit)
+  // epilogue of a completed accumulator set: y[2t] = M0 + M1 + M2, y[2t+1] = M1 - M2 - M3 (4 output channels each), activation, fp16;
+  // lanes kg and kg ^ 1 then trade halves (v_permlane16_swap: odd 16-lane rows of the first operand <-> even rows of the second) so
+  // that an even kg holds channels 8 (kg >> 1) .. + 7 of column 2t and an odd kg those of column 2t + 1: ONE 16-byte store per lane
+  auto epilogue = [&](const f32x4 (&m)[4], __amdgpu_buffer_rsrc_t ro, unsigned vo, int so) {
+    f16x4_t h0, h1;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      float ye, yo;
+      if (DBG & 8) { ye = m[0][k] + m[2][k]; yo = m[1][k] + m[3][k]; }
+      else {
+        ye = m[0][k] + (m[1][k] + m[2][k]); yo = (m[1][k] - m[2][k]) - m[3][k];
+        ye = fmaxf(ye, slope * ye); yo = fmaxf(yo, slope * yo);
+      }
+      h0[k] = (_Float16)ye;
+      h1[k] = (_Float16)yo;
+    }
+    const u32x2 x = __builtin_bit_cast(u32x2, h0), y = __builtin_bit_cast(u32x2, h1);
+    const auto s0 = __builtin_amdgcn_permlane16_swap(x[0], y[0], false, false);
+    const auto s1 = __builtin_amdgcn_permlane16_swap(x[1], y[1], false, false);
+    const u32x4 v = {s0[0], s1[0], s0[1], s1[1]};
+    if (!(DBG & 4)) __builtin_amdgcn_raw_buffer_store_b128(v, ro, (int)vo, so, 0);
+    else if (v[0] == 0x12345678u && v[3] == 0x9abcdef0u) __builtin_amdgcn_raw_buffer_store_b128(v, ro, (int)vo, so, 0);
+  };
+  // scalar (row) part of a store address; the lane part `vo` carries the column, the channel half and (S2D) the x phase's plane
+  auto row_offset = [&](int r) {
+    if constexpr (S2D) return (((r & 1) * 2) * nck + cb) * ((H >> 1) * (W >> 1) * 32) + (r >> 1) * (W >> 1) * 32;
+    else return (cb * (H * W) + r * W) * 32;
+  };
+
+  // one batch of three input rows.  ALL = every output row the batch touches is inside the segment (the steady state: straight-line
+  // code, 72 MFMAs); otherwise the rows are guarded one by one (first / last batches of a unit)
+  auto batch = [&](auto all_tag, int n, int b, int y0, int y1, int i0, unsigned vo, auto&& mid) {
+    constexpr bool ALL = decltype(all_tag)::value;
+    unsigned voff = (unsigned)((n & 1) * WN_SLOT);
+    asm volatile("" : "+s"(voff));
+    const unsigned char* vbase = smem + lane16 + voff;
+    const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<unsigned char*>(a.out) + (long long)b * out_img_bytes,
+                                                                        0, (int)out_img_bytes, 0x00020000);
+    if constexpr (ALL) {
+      // steady state.  The eight V fragments of a row are requested in one go -- those of row j + 1 right behind row j's MFMAs, i.e.
+      // BEFORE row j's epilogue, whose vector work covers their latency (with reads only two fragments ahead of their MFMAs every
+      // triple of MFMAs waited ~100 cycles for the LDS: the first build of this kernel spent 2.3x its MFMA time per batch)
+      f16x8_t fv[8];
+#pragma unroll
+      for (int f = 0; f < 8; ++f) fv[f] = *reinterpret_cast<const f16x8_t*>(vbase + f * 1024);
+#pragma unroll
+      for (int j = 0; j < WN_ROWS; ++j) {
+        const int s2 = (j + 2) % 3, s1 = j, s0 = (j + 1) % 3;
+        f32x4 done[4];
+#pragma unroll
+        for (int sc = 0; sc < 2; ++sc)
+#pragma unroll
+          for (int xi = 0; xi < 4; ++xi) {
+            const f16x8_t f = fv[xi * 2 + sc];
+            if (DBG & 1) { asm volatile("" :: "v"(f)); if (sc == 0) acc[s0][xi] = xi == 1 ? binit : zinit; continue; }
+            acc[s2][xi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[2][xi][sc], f, acc[s2][xi], 0, 0, 0);
+            acc[s1][xi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[1][xi][sc], f, acc[s1][xi], 0, 0, 0);
+            acc[s0][xi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[0][xi][sc], f, sc == 0 ? (xi == 1 ? binit : zinit) : acc[s0][xi], 0, 0, 0);
+          }
+#pragma unroll
+        for (int xi = 0; xi < 4; ++xi) done[xi] = acc[s2][xi];
+        __builtin_amdgcn_sched_barrier(0);
+        if (j + 1 < WN_ROWS) {
+#pragma unroll
+          for (int f = 0; f < 8; ++f) fv[f] = *reinterpret_cast<const f16x8_t*>(vbase + (j + 1) * WN_VROW + f * 1024);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        epilogue(done, ro, vo, row_offset(i0 + j - 1));
+        if (j == 0) mid();
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < WN_ROWS; ++j) {
+        // input row i0 + j: dy = 2 completes output row i0 + j - 1 (slot (j + 2) % 3), dy = 1 -> row i0 + j (slot j), dy = 0 opens
+        // row i0 + j + 1 (slot (j + 1) % 3)
+        const int r2 = i0 + j - 1, r1 = i0 + j, r0 = i0 + j + 1;
+        const bool v2 = r2 >= y0 && r2 < y1, v1 = r1 >= y0 && r1 < y1, v0 = r0 >= y0 && r0 < y1;
+        const int s2 = (j + 2) % 3, s1 = j, s0 = (j + 1) % 3;
+        if (v0 || v1 || v2) {
+#pragma unroll
+          for (int sc = 0; sc < 2; ++sc) {
+            f16x8_t fv[4];
+#pragma unroll
+            for (int xi = 0; xi < 4; ++xi) fv[xi] = *reinterpret_cast<const f16x8_t*>(vbase + j * WN_VROW + (xi * 2 + sc) * 1024);
+            if (v2) {
+#pragma unroll
+              for (int xi = 0; xi < 4; ++xi) acc[s2][xi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[2][xi][sc], fv[xi], acc[s2][xi], 0, 0, 0);
+            }
+            if (v1) {
+#pragma unroll
+              for (int xi = 0; xi < 4; ++xi) acc[s1][xi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[1][xi][sc], fv[xi], acc[s1][xi], 0, 0, 0);
+            }
+            if (v0) {
+#pragma unroll
+              for (int xi = 0; xi < 4; ++xi)
+                acc[s0][xi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[0][xi][sc], fv[xi], sc == 0 ? (xi == 1 ? binit : zinit) : acc[s0][xi], 0, 0, 0);
+            }
+          }
+        }
+        // (a row that is not stored still issues its store, out of range: every path then has the same vector-memory sequence)
+        epilogue(acc[s2], ro, v2 ? vo : 0x80000000u, row_offset(r2));
+        if (j == 0) mid();
+      }
+    }
+  };
+
+  auto sync = [&]() {
+    if (DBG & 16) return;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+  };
+  // the next batch's place in the unit sequence (clamped at the end: the last batch is re-loaded, harmlessly)
+  auto next_coords = [&](int n, int& b, int& x0, int& y0, int& y1, int& i0) {
+    n = min(n, T - 1);
+    const int ord = n / NB, m = n - ord * NB;
+    unit_coords(ord, b, x0, y0, y1);
+    i0 = y0 - 1 + m * WN_ROWS;
+  };
+
+  {
+    int b, x0, y0, y1, i0;
+    unsigned va, vb;
+    next_coords(0, b, x0, y0, y1, i0);
+    src_lane_offsets(x0, va, vb);
+    issue_loads(0, va, vb, b, y0, y1, i0);
+    write_v(0);
+    next_coords(1, b, x0, y0, y1, i0);
+    src_lane_offsets(x0, va, vb);
+    issue_loads(1, va, vb, b, y0, y1, i0);
+    if (!(DBG & 4)) {      // two out-of-range (dropped) stores stand for "the previous batch's rows 1 and 2" in the wait counts
+      const __amdgpu_buffer_rsrc_t r0 = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<unsigned char*>(a.out), 0, 0, 0x00020000);
+#pragma unroll
+      for (int i = 0; i < 2; ++i) __builtin_amdgcn_raw_buffer_store_b128(u32x4{0u, 0u, 0u, 0u}, r0, (int)0x80000000u, 0, 0);
+    }
+    sync();
+  }
+  int n = 0;
+  for (int ord = 0; ord < my_units; ++ord) {
+    int b, x0, y0, y1;
+    unit_coords(ord, b, x0, y0, y1);
+    // lane parts of the store addresses (columns 2t, 2t + 1 of the strip) and of the NEXT batches' loads within this unit
+    const int xo = x0 + 2 * t16 + (kg & 1);       // this lane stores column 2t + (kg & 1), channels 8 (kg >> 1) .. + 7 of the wave's 16
+    unsigned vo, va, vb;
+    if constexpr (S2D) vo = (unsigned)(xo >> 1) * 32u + (unsigned)(kg >> 1) * 16u + (unsigned)(kg & 1) * (unsigned)(nck * (H >> 1) * (W >> 1) * 32);
+    else vo = (unsigned)xo * 32u + (unsigned)(kg >> 1) * 16u;
+    if (xo >= W) vo = 0x80000000u;
+    src_lane_offsets(x0, va, vb);
+    // batch m covers input rows y0 - 1 + 3m ..+2; every output row it touches is inside the segment for 1 <= m < mf
+    const int mf = (y1 - y0) / 3;
+    // the V fragments of batch n + 1 and the loads of batch n + 2, issued after the batch's first row; inside the unit they need
+    // nothing but the row number
+    auto mid_same = [&](int nn, int m) {
+      return [&, nn, m]() {
+        write_v(nn + 1);
+        issue_loads(nn + 2, va, vb, b, y0, y1, y0 - 1 + (m + 2) * WN_ROWS);
+      };
+    };
+    auto mid_any = [&](int nn) {
+      return [&, nn]() {
+        write_v(nn + 1);
+        int b2, x2, y02, y12, i02;
+        unsigned va2, vb2;
+        next_coords(nn + 2, b2, x2, y02, y12, i02);
+        src_lane_offsets(x2, va2, vb2);
+        issue_loads(nn + 2, va2, vb2, b2, y02, y12, i02);
+      };
+    };
+    batch(std::false_type{}, n, b, y0, y1, y0 - 1, vo, mid_any(n));
+    sync();
+    ++n;
+    int m = 1;
+    // steady state; its last two batches prefetch across the unit boundary (m + 2 >= NB) through the general path
+    for (; m < mf && m + 2 < NB; ++m, ++n) {
+      batch(std::true_type{}, n, b, y0, y1, y0 - 1 + m * WN_ROWS, vo, mid_same(n, m));
+      sync();
+    }
+    for (; m < NB; ++m, ++n) {
+      batch(std::false_type{}, n, b, y0, y1, y0 - 1 + m * WN_ROWS, vo, mid_any(n));
+      sync();
+    }
+  }
+}
+
+// [Cout][64][3][3] fp32 -> [Cout/16][dy][xi][K half][lane = kg * 16 + i][8] fp16 (the MFMA A fragments of the kernel above)
+__global__ __launch_bounds__(256) void pack_wino_kernel(const float* __restrict__ w, _Float16* __restrict__ out, int Cout) {
+  const int total = Cout * 64 * 12;
+  for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+    const int e = idx & 7, ln = (idx >> 3) & 63, f = (idx >> 9) % 24, cb = idx / (512 * 24);
+    const int sc = f & 1, xi = (f >> 1) & 3, dy = f >> 3;
+    const int o = cb * 16 + (ln & 15), c = sc * 32 + (ln >> 4) * 8 + e;
+    const float* g = w + ((long long)o * 64 + c) * 9 + dy * 3;
+    const float g0 = g[0], g1 = g[1], g2 = g[2];
+    const float u = xi == 0 ? g0 : (xi == 1 ? 0.5f * (g0 + g1 + g2) : (xi == 2 ? 0.5f * (g0 - g1 + g2) : g2));
+    out[idx] = (_Float16)u;
+  }
+}
+
+}  // namespace
+
+extern "C" int cdfo_pack_conv3x3_wino(const float* w_oihw, void* packed, int Cout, void* stream) {
+  if (Cout <= 0 || Cout % 16) return CDFO_EINVAL;
+  hipLaunchKernelGGL(pack_wino_kernel, dim3((Cout * 64 * 12 + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream), w_oihw,
+                     static_cast<_Float16*>(packed), Cout);
+  CDFO_LAUNCH_CHECK();
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Host side.  Row segments are chosen so that the unit count fills the workgroup lanes evenly: a unit costs
+// 3 * ceil((seg_h + 2) / 3) row steps (+ one barrier per batch).
+namespace {
+template <int DBG>
+void wino_launch(const wino_args& a, int grid, hipStream_t st) {
+  if (a.s2d) hipLaunchKernelGGL((conv3x3_c64_wino_kernel<true, DBG>), dim3(grid), dim3(WN_THREADS), WN_LDS, st, a);
+  else hipLaunchKernelGGL((conv3x3_c64_wino_kernel<false, DBG>), dim3(grid), dim3(WN_THREADS), WN_LDS, st, a);
+}
+}  // namespace
+
+// dbg: 0 (developer ablation bits otherwise, WRONG results: 1 no MFMAs, 2 no global loads, 4 no stores, 8 no epilogue arithmetic,
+// 16 no barrier)
+extern "C" int cdfo_conv3x3_c64_wino_dbg(const void* src_cp16, int B, int H, int W, const void* w_wino, const float* bias, int Cout, int act,
+                                         void* out_cp16, int store_mode, int dbg, void* stream) {
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (B <= 0 || H <= 0 || W <= 0 || (W & 1) || Cout <= 0 || Cout % 128) return CDFO_EINVAL;
+  if (act == CDFO_ACT_SIGMOID || (store_mode != CDFO_STORE_PLAIN && store_mode != CDFO_STORE_S2D)) return CDFO_EINVAL;
+  if (store_mode == CDFO_STORE_S2D && (H & 1)) return CDFO_EINVAL;
+  if ((long long)H * W * 128 >= (1ll << 31) || (long long)(Cout / 16) * H * W * 32 >= (1ll << 31)) return CDFO_EINVAL;   // per-image 32-bit offsets
+  if (!aligned16(src_cp16) || !aligned16(w_wino) || !aligned16(out_cp16)) return CDFO_EALIGN;
+  const int cus = cdfo_num_cus();
+  const int nhalf = Cout / 128;
+  if (cus < 8 || cus / 8 < nhalf) return CDFO_EINVAL;
+  const int nslots = cus / 8, npairs = nslots / nhalf, lanes = npairs * 8;
+  const int nstrips = (W + 31) / 32;
+  int best_seg = H;
+  double best_cost = 1e30;
+  for (int nseg = 1; nseg <= (H + 7) / 8; ++nseg) {
+    const int seg_h = (H + nseg - 1) / nseg;
+    if ((seg_h * (nseg - 1)) >= H) continue;         // an empty last segment
+    const long long units = (long long)B * nstrips * nseg;
+    const long long rounds = (units + lanes - 1) / lanes;
+    const double cost = (double)rounds * (3.0 * ((seg_h + 2 + 2) / 3) + 1.0);
+    if (cost < best_cost - 1e-9) { best_cost = cost; best_seg = seg_h; }
+  }
+  wino_args a;
+  a.src = static_cast<const unsigned char*>(src_cp16); a.B = B; a.H = H; a.W = W;
+  a.w = static_cast<const f16x8_t*>(w_wino); a.bias = bias; a.Cout = Cout; a.act = act;
+  a.out = static_cast<_Float16*>(out_cp16); a.s2d = store_mode == CDFO_STORE_S2D;
+  a.seg_h = best_seg; a.nseg = (H + best_seg - 1) / best_seg; a.nstrips = nstrips; a.nb = (best_seg + 2 + 2) / 3;
+  const double px = (double)B * H * W;
+  CdfoProfScope prof(st, KID_CONV3_WINO, 2.0 * px * Cout * 64 * 9, 2.0 * (px * Cout + px * 64) + 2.0 * 12 * 64 * Cout);
+  switch (dbg) {
+    case 0: wino_launch<0>(a, nslots * 8, st); break;
+    case 1: wino_launch<1>(a, nslots * 8, st); break;
+    case 2: wino_launch<2>(a, nslots * 8, st); break;
+    case 4: wino_launch<4>(a, nslots * 8, st); break;
+    case 8: wino_launch<8>(a, nslots * 8, st); break;
+    case 12: wino_launch<12>(a, nslots * 8, st); break;
+    case 16: wino_launch<16>(a, nslots * 8, st); break;
+    case 6: wino_launch<6>(a, nslots * 8, st); break;
+    case 14: wino_launch<14>(a, nslots * 8, st); break;
+    case 30: wino_launch<30>(a, nslots * 8, st); break;
+    case 31: wino_launch<31>(a, nslots * 8, st); break;
+    default: return CDFO_EINVAL;
+  }
+  CDFO_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int cdfo_conv3x3_c64_wino(const void* src_cp16, int B, int H, int W, const void* w_wino, const float* bias, int Cout, int act,
+                                     void* out_cp16, int store_mode, void* stream) {
+  return cdfo_conv3x3_c64_wino_dbg(src_cp16, B, H, W, w_wino, bias, Cout, act, out_cp16, store_mode, 0, stream);
+}

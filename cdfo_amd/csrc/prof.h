@@ -7,7 +7,7 @@ enum CdfoKid {
   KID_CONV3_WIDE = 0, KID_CONV3_NARROW, KID_CONV1, KID_CONV3_S2, KID_STEM, KID_LAYERNORM, KID_DWCONV, KID_FLOW_WARP,
   KID_RESAMPLE, KID_SCALE, KID_CONV_LAST, KID_SMALL_CONV, KID_SPATIAL_GATE, KID_CHAN_SUM, KID_GRAM, KID_FOLD,
   KID_RDAB_PREP, KID_COLCONV9, KID_ATTN_ROW, KID_ATTN_COL, KID_ATTN_WIN, KID_LAYOUT, KID_PACK, KID_DCN, KID_CONV3_WS,
-  KID_CONV3_RING, KID_CONV3_RING4, KID_CONV3_WS_RES, KID_DCN_BWD, KID_COUNT
+  KID_CONV3_RING, KID_CONV3_RING4, KID_CONV3_WS_RES, KID_DCN_BWD, KID_CONV3_WINO, KID_COUNT
 };
 
 struct CdfoProfState {

@@ -467,7 +467,11 @@ class CVSR_V8(nn.Module):
             # body[0] on the weights-stationary kernel, body[2] / the composed stride-2 convolution on the LDS-DMA ring
             # kernel; the 64- and 256-channel tensors between them are fp16 chunk-planar [B,C/16,H,W,16].  Same
             # arithmetic as the single-pass fp16 mode of the tiled kernel: fp16 operands, fp32 accumulation
-            c1 = lambda src, **kw: K.conv3x3_ws(src, b0, act=K.ACT_LRELU, **kw)
+            # body[0]: the row-streaming Winograd F(2,3) kernel (2/3 of the direct product's MFMAs) unless CDFO_WINO=0
+            if b0.ww is not None and K.wino_enabled() and x.shape[2] % 4 == 0 and x.shape[1] * x.shape[2] * 8 * b0.Cout < (1 << 31):
+                c1 = lambda src, **kw: K.conv3x3_wino(src, b0, act=K.ACT_LRELU, **kw)
+            else:
+                c1 = lambda src, **kw: K.conv3x3_ws(src, b0, act=K.ACT_LRELU, **kw)
             # sources of the x2 and x1/2 branches (and, for a group's first block, of the 1x branch), one read of x
             if x16 is None:
                 u16, d16, x16 = K.block_prologue(x, w[p + "pro"], want_x16=True)

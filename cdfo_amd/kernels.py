@@ -6,6 +6,7 @@ pitch ``ld = t.stride(2)`` may exceed C, so a channel slice ``t[..., a:b]`` of a
 from __future__ import annotations
 
 import contextlib
+import os
 import ctypes as C
 from dataclasses import dataclass
 from typing import Optional, Sequence
@@ -101,6 +102,7 @@ class PackedConv:
     wh: Optional[torch.Tensor] = None   # fp16 packing (single block) for PREC_FP16X2
     CoutP16: int = 0                    # padded output channels of the 16-bit packings (multiple of 64)
     wh_sparse: Optional[torch.Tensor] = None   # fp16 packing of the four active taps per chunk (conv_ring + tap_mask)
+    ww: Optional[torch.Tensor] = None   # Winograd F(2,3) fp16 image for conv3x3_wino (3x3, Cin = 64, Cout % 128 == 0)
 
 
 def pack_conv(weight: torch.Tensor, bias: Optional[torch.Tensor], shuffle2: bool = False,
@@ -133,6 +135,11 @@ def pack_conv(weight: torch.Tensor, bias: Optional[torch.Tensor], shuffle2: bool
         check(_lib.lib().cdfo_pack_conv3x3_f16(C.c_void_p(w.data_ptr()), C.c_void_p(wh.data_ptr()), Cout, Cin, _stream()),
               "cdfo_pack_conv3x3_f16")
         pc.wh = wh
+        if Cin == 64 and Cout % 128 == 0:
+            ww = torch.empty(Cout * 64 * 12, dtype=torch.float16, device=w.device)
+            check(_lib.lib().cdfo_pack_conv3x3_wino(C.c_void_p(w.data_ptr()), C.c_void_p(ww.data_ptr()), Cout, _stream()),
+                  "cdfo_pack_conv3x3_wino")
+            pc.ww = ww
     return pc
 
 
@@ -340,6 +347,35 @@ def conv3x3_ws(src: torch.Tensor, pc: PackedConv, *, act: int = ACT_NONE, s2d: b
         check(_lib.lib().cdfo_conv3x3_c64_ws(_vp(src[b0:b0 + nb]), nb, H, W, _vp(pc.wh), pc.CoutP16, _vp(pc.bias), pc.Cout,
                                              act, _vp(out[b0:b0 + nb]), 2 if s2d else 0, dbg, _vp(clk), _stream()),
               "cdfo_conv3x3_c64_ws")
+    return out
+
+
+def wino_enabled() -> bool:
+    """CDFO_WINO=0 keeps Block_.body[0] on the direct weights-stationary kernel (developer A/B switch)."""
+    return os.environ.get("CDFO_WINO", "1") != "0"
+
+
+def conv3x3_wino(src: torch.Tensor, pc: PackedConv, *, act: int = ACT_NONE, s2d: bool = False,
+                 out: Optional[torch.Tensor] = None, dbg: int = 0) -> torch.Tensor:
+    """conv3x3_ws's operands and result on the row-streaming Winograd F(2,3) kernel (cdfo_conv3x3_c64_wino): Cout % 128 == 0, W even."""
+    if not src.is_cuda:
+        raise NotImplementedError("conv3x3_wino: the HIP path needs device tensors (no CPU fallback)")
+    if src.dtype != torch.float16 or src.dim() != 5 or src.shape[1] != 4 or src.shape[4] != 16 or not src.is_contiguous():
+        raise ValueError(f"conv3x3_wino: expected a contiguous fp16 [B,4,H,W,16] source, got {src.dtype} {tuple(src.shape)}")
+    if pc.ww is None:
+        raise ValueError("conv3x3_wino: needs a 3x3 weight with 64 input channels and Cout % 128 == 0")
+    B, _, H, W, _ = src.shape
+    shape = (B, pc.Cout // 4, H // 2, W // 2, 16) if s2d else (B, pc.Cout // 16, H, W, 16)
+    if out is None:
+        out = torch.empty(shape, dtype=torch.float16, device=src.device)
+    elif out.shape != shape or out.dtype != torch.float16 or not out.is_contiguous():
+        raise ValueError(f"conv3x3_wino: out must be a contiguous fp16 tensor of shape {shape}")
+    if dbg:      # developer ablations (tools/bench_wino.py): wrong results by construction
+        check(_lib.lib().cdfo_conv3x3_c64_wino_dbg(_vp(src), B, H, W, _vp(pc.ww), _vp(pc.bias), pc.Cout, act, _vp(out), 2 if s2d else 0,
+                                                   dbg, _stream()), "cdfo_conv3x3_c64_wino_dbg")
+        return out
+    check(_lib.lib().cdfo_conv3x3_c64_wino(_vp(src), B, H, W, _vp(pc.ww), _vp(pc.bias), pc.Cout, act, _vp(out), 2 if s2d else 0,
+                                           _stream()), "cdfo_conv3x3_c64_wino")
     return out
 
 

@@ -111,6 +111,20 @@ int cdfo_pack_conv3x3_f16(const float* w_oihw, void* packed, int Cout, int Cin, 
  * real-time ticks}: 3 x 8 x 256 words; else pass NULL).  */
 int cdfo_conv3x3_c64_ws(const void* src_cp16, int B, int H, int W, const void* w_f16, int CoutP, const float* bias,
                         int Cout, int act, void* out_cp16, int store_mode, int dbg, void* clk_probe, void* stream);
+/* The same convolution (Block_.body[0], arch/SIDECVSR_our.py:383-387: 3x3, 64 -> Cout, stride 1, pad 1, + bias + activation; fp16
+ * chunk-planar source and result exactly as cdfo_conv3x3_c64_ws) as a row-streaming Winograd F(2,3) product along x: 2/3 of the direct
+ * form's MFMAs, weights stationary in REGISTERS (csrc/conv3x3_wino.hip).  w_wino: cdfo_pack_conv3x3_wino image (Cout x 64 x 12 fp16:
+ * [Cout/16][dy 3][xi 4][K half 2][lane 64][8], element e of lane (kg, i) = U_xi[dy][channel 32 half + 8 kg + e][output channel 16 cb + i]
+ * with U0 = g0, U1 = (g0 + g1 + g2)/2, U2 = (g0 - g1 + g2)/2, U3 = g2 over the kernel row g = w[:, :, dy, 0..2], formed in fp32).
+ * Cout % 128 == 0, W even (H even for CDFO_STORE_S2D), one image of source / result smaller than 2 GiB; any B.  The transformed
+ * inputs are up to 2x the source's magnitude in fp16: |src| must stay below 32752.  */
+int cdfo_conv3x3_c64_wino(const void* src_cp16, int B, int H, int W, const void* w_wino, const float* bias, int Cout, int act,
+                          void* out_cp16, int store_mode, void* stream);
+int cdfo_pack_conv3x3_wino(const float* w_oihw, void* packed, int Cout, void* stream);
+/* the same call with developer ablation bits (dbg != 0: WRONG results; 1 no MFMAs, 2 no global loads, 4 no stores, 8 no epilogue
+ * arithmetic, 16 no barrier): tools/bench_wino.py */
+int cdfo_conv3x3_c64_wino_dbg(const void* src_cp16, int B, int H, int W, const void* w_wino, const float* bias, int Cout, int act,
+                              void* out_cp16, int store_mode, int dbg, void* stream);
 /* MVDualAttAlignment's conv_offset[2] (3x3, 64 -> Cout = 27 dg, arch/SIDECVSR_our.py:3285-3289) on the weights-stationary kernel with
  * the module's offset / mask assembly (arch.py:3336-3350) as its epilogue -- the CDFO_STORE_OFFMASK contract of cdfo_conv_args above,
  * single-pass fp16 operands (src fp16 chunk-planar [B][4][H][W][16], weights from cdfo_pack_conv3x3_f16 with CoutP padded channels):

@@ -271,6 +271,68 @@ def test_conv3x3_c64_ws(Cout, H, W, B, s2d, act):
     assert err <= 1.5e-3 * max(1.0, scale), f"ws conv: max-abs {err} (ref scale {scale})"
 
 
+WINO_CASES = [
+    # Cout, H, W, B, s2d, act      (ragged strips, segments shorter than a batch, one-row images, several units per workgroup)
+    (256, 24, 40, 1, False, 1),
+    (128, 16, 64, 2, False, 0),
+    (128, 6, 34, 3, False, 2),
+    (256, 36, 52, 2, True, 1),
+    (256, 272, 480, 2, True, 1),
+    (128, 2, 8, 1, False, 1),
+    (128, 1, 30, 2, False, 1),
+    (256, 8, 200, 3, False, 0),
+    (384, 20, 70, 2, True, 1),      # three 128-channel groups: the XCD's 32 workgroup slots do not divide evenly
+    (256, 136, 240, 8, False, 1),   # the half-resolution launch of c3: half-empty last strip, 17-row segments
+]
+
+
+@pytest.mark.parametrize("Cout,H,W,B,s2d,act", WINO_CASES)
+def test_conv3x3_c64_wino(Cout, H, W, B, s2d, act):
+    """Row-streaming Winograd F(2,3) kernel (Block_.body[0], arch.py:383-387) vs torch-cpu conv2d in float64 on the fp16-rounded
+    source and the UNROUNDED weights: the kernel rounds the transformed weights, not the weights.  Bound: the direct kernel's
+    (test_conv3x3_c64_ws) -- the fp16 rounding of the result dominates both."""
+    from cdfo_amd import kernels as K
+    g = torch.Generator().manual_seed(Cout + H + W)
+    x = torch.randn(B, 64, H, W, generator=g)
+    w = torch.randn(Cout, 64, 3, 3, generator=g) / 24.0
+    b = torch.randn(Cout, generator=g)
+    ref = F.conv2d(x.half().double(), w.double(), b.double(), padding=1)
+    ref = {0: ref, 1: F.leaky_relu(ref, 0.1), 2: F.relu(ref)}[act].float()
+    pc = K.pack_conv(w.cuda(), b.cuda())
+    assert pc.ww is not None
+    src = K.to_cp16(_nhwc(x).cuda())
+    out = K.conv3x3_wino(src, pc, act=act, s2d=s2d)
+    torch.cuda.synchronize()
+    got = K.from_cp16(out).float().cpu()
+    if s2d:   # [B,H/2,W/2,(py,px,c)] -> [B,H,W,c]
+        got = got.view(B, H // 2, W // 2, 2, 2, Cout).permute(0, 1, 3, 2, 4, 5).reshape(B, H, W, Cout)
+    got = got.permute(0, 3, 1, 2)
+    err = (got - ref).abs().max().item()
+    scale = ref.abs().max().item()
+    assert err <= 1.5e-3 * max(1.0, scale), f"wino conv: max-abs {err} (ref scale {scale})"
+    # and against the direct weights-stationary kernel on the same operands: two fp16 roundings of nearly the same number
+    if H % 2 == 0:
+        direct = K.from_cp16(K.conv3x3_ws(src, pc, act=act, s2d=s2d)).float().cpu()
+        if s2d:
+            direct = direct.view(B, H // 2, W // 2, 2, 2, Cout).permute(0, 1, 3, 2, 4, 5).reshape(B, H, W, Cout)
+        d = (got - direct.permute(0, 3, 1, 2)).abs().max().item()
+        assert d <= 3e-3 * max(1.0, scale), f"wino vs direct: {d}"
+
+
+def test_pack_conv3x3_wino_layout():
+    """cdfo_pack_conv3x3_wino against the layout include/cdfo_hip.h documents (torch arithmetic in float64)."""
+    from cdfo_amd import kernels as K
+    g = torch.Generator().manual_seed(5)
+    w = torch.randn(128, 64, 3, 3, generator=g)
+    pc = K.pack_conv(w.cuda(), None)
+    gg = w.double()
+    U = torch.stack([gg[..., 0], (gg[..., 0] + gg[..., 1] + gg[..., 2]) / 2, (gg[..., 0] - gg[..., 1] + gg[..., 2]) / 2, gg[..., 2]], -1)
+    # U [o, c, dy, xi] -> [cb, dy, xi, sc, kg, i, e]
+    exp = U.view(8, 16, 2, 4, 8, 3, 4).permute(0, 5, 6, 2, 3, 1, 4).reshape(-1)
+    got = pc.ww.cpu().double()
+    assert (got - exp).abs().max().item() <= 2.0 ** -11 * exp.abs().max().item()
+
+
 RING_CASES = [
     # Cin, Cout, H, W, B, res, out_f16
     (256, 64, 20, 40, 1, True, False),

@@ -44,7 +44,10 @@ def main():
         main_sym = next((m for m in ("dcn_win_kernel", "dcn_fast_kernel") if any(m in k for k in F)), "dcn_fwd_kernel")
         fm, wm = tot(lambda k: main_sym in k)
         fp, wp = tot(lambda k: main_sym not in k and ("dcn" in k.lower()))
-        json.dump({"kernel": main_sym, "workload": "C=Co=64 dg=16 3x3 272x480 B=8", "commit": commit, "fetch_kib_raw": fm, "write_kib_raw": wm,
+        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        import bench
+        json.dump({"kernel": main_sym, "workload": "C=Co=64 dg=16 3x3 272x480 B=8", "commit": commit, "source_sha256": bench.source_hashes("dcn"),
+                   "fetch_kib_raw": fm, "write_kib_raw": wm,
                    "fetch_correction": 2.0, "hbm_bytes_per_launch": round((2.0 * fm + wm) * 1024.0),
                    "prepass_hbm_bytes_per_launch": round((2.0 * fp + wp) * 1024.0),
                    "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) of tools/bench_dcn.py, tools/pmc_summary.py --dcn; "
@@ -77,7 +80,7 @@ def families(F, Wr, jpath, prec, commit):
         n = max(len(fk), len(wk))
         f, w = sum(fk) / max(1, len(fk)), sum(wk) / max(1, len(wk))
         out[fam] = {"kernel_symbol_contains": subs, "launches_averaged": [len(fk), len(wk)], "fetch_kib_raw": f, "write_kib_raw": w,
-                    "hbm_bytes_per_launch": round((2.0 * f + w) * 1024.0), "launches": n}
+                    "hbm_bytes_per_launch": round((2.0 * f + w) * 1024.0), "launches": n, "source_sha256": bench.source_hashes(fam)}
     json.dump({"precision": prec, "commit": commit, "fetch_correction": 2.0, "families": out,
                "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) of bench.py, tools/pmc_summary.py --families; HBM bytes "
                          "= (2 * FETCH_SIZE + WRITE_SIZE) KiB (gfx950: FETCH_SIZE counts half of a 16-B/lane stream, MI355X_MICROARCH.md)"},

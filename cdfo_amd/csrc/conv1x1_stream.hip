@@ -498,6 +498,12 @@ int cdfo_conv1x1_stream_try(const cdfo_conv_args& a, hipStream_t st) {
   const int scale_bytes = (a.res2 && a.res2_pixscale) ? 4 * 512 : 0;      // two tile-parity slots per wave
   int ns = (160 * 1024 - 256 - scale_bytes - w_bytes) / (4 * ST_STAGE);
   if (ns > ST_MAXNS) ns = ST_MAXNS;
+  if (scale_bytes) {
+    // the per-pixel factors of tile t + 2 are requested with item (t + 2, 0), NS - 1 items ahead of consumption, into the slot tile t
+    // used (two tile-parity slots): safe only while NS <= items_per_tile + 2, or tile t's residual stage would read tile t + 2's factors
+    const int items_per_tile = nkb + ((a.res1 ? 1 : 0) + 1) * ncb;      // as the kernel counts them: K blocks + residual stages
+    if (ns > items_per_tile + 2) ns = items_per_tile + 2;
+  }
   if (ns < 3) return 0;
   const long long P = (long long)a.H * a.W;
   st_args s{};

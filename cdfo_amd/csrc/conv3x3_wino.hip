@@ -44,7 +44,8 @@ constexpr int WN_THREADS = 512;
 constexpr int WN_ROWS = 3;                       // input rows per batch (= the period of the rolling accumulator sets)
 constexpr int WN_VROW = 8 * 1024;                // V of one input row: fragment xi * 2 + K half, 1 KiB each
 constexpr int WN_SLOT = WN_ROWS * WN_VROW;
-constexpr int WN_LDS = 2 * WN_SLOT;              // 48 KiB
+constexpr int WN_NSLOT = 3;                      // V ring: batch n lives in slot n % 3 (see the barrier's place in `batch`)
+constexpr int WN_LDS = WN_NSLOT * WN_SLOT;       // 72 KiB
 
 struct wino_args {
   const unsigned char* src; int B, H, W;
@@ -61,7 +62,7 @@ typedef int i32x4 __attribute__((ext_vector_type(4)));
 // wait-count pass, which merges the states of a loop's pre-header and back edge pessimistically: the loops below are arranged so
 // that every path into a batch has issued the SAME sequence [row-0 store, six loads, row-1 store, row-2 store] before it.
 // DBG (developer ablations, wrong results): 1 = no MFMAs, 2 = no global loads, 4 = no stores, 8 = no epilogue arithmetic,
-// 16 = no barrier / V exchange wait
+// 16 = no barrier / V exchange wait, 32 / 64 = loads / stores with lane-contiguous addresses (one cache line per four lanes)
 template <bool S2D, int DBG>
 __global__ __launch_bounds__(WN_THREADS) void conv3x3_c64_wino_kernel(wino_args a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -106,7 +107,8 @@ __global__ __launch_bounds__(WN_THREADS) void conv3x3_c64_wino_kernel(wino_args 
   }
   asm volatile("" : "+v"(binit));      // waited for here, not inside the loop (see the weights)
   const f32x4 zinit = {0.f, 0.f, 0.f, 0.f};
-  const float slope = a.act == CDFO_ACT_NONE ? 1.f : (a.act == CDFO_ACT_LRELU ? 0.1f : 0.f);
+  const _Float16 slope1 = a.act == CDFO_ACT_NONE ? (_Float16)1.f : (a.act == CDFO_ACT_LRELU ? (_Float16)0.1f : (_Float16)0.f);
+  const f16x4_t slope_h = {slope1, slope1, slope1, slope1};
 
   // ---- V production role of this wave: fragment wave = xi_p * 2 + sc_p; V = sA dA + sB dB with
   //      xi 0: d0 - d2, xi 1: d1 + d2, xi 2: d2 - d1, xi 3: d1 - d3   (d_j = pixel x0 + 2t + j - 1)
@@ -119,6 +121,7 @@ __global__ __launch_bounds__(WN_THREADS) void conv3x3_c64_wino_kernel(wino_args 
   const int nck = a.Cout >> 4;
   const unsigned out_img_bytes = (unsigned)nck * (unsigned)(H * W) * 32u;
   const unsigned lane16 = (unsigned)lane * 16u;
+  const bool grp_b = wave >= 4;        // the SIMD partners of waves 0-3 (see STAGGER below)
 
   auto unit_coords = [&](int ord, int& b, int& x0, int& y0, int& y1) {
     const int u = (ord * npairs + pair) * 8 + xcd;
@@ -133,6 +136,7 @@ __global__ __launch_bounds__(WN_THREADS) void conv3x3_c64_wino_kernel(wino_args 
     const int xa = x0 + 2 * t16 + jA - 1, xb = x0 + 2 * t16 + jB - 1;
     va = (xa >= 0 && xa < W) ? lane_src + (unsigned)xa * 32u : 0x80000000u;
     vb = (xb >= 0 && xb < W) ? lane_src + (unsigned)xb * 32u : 0x80000000u;
+    if (DBG & 32) { va = (unsigned)x0 * 32u + lane16; vb = va + 1024u; }      // ablation: line-contiguous loads (wrong data)
   };
 
   u32x4 raw[WN_ROWS][2];
@@ -154,7 +158,7 @@ __global__ __launch_bounds__(WN_THREADS) void conv3x3_c64_wino_kernel(wino_args 
     }
   };
   auto write_v = [&](int n) {
-    unsigned uoff = (unsigned)((n & 1) * WN_SLOT + wave * 1024);
+    unsigned uoff = (unsigned)((n % WN_NSLOT) * WN_SLOT + wave * 1024);
     asm volatile("" : "+s"(uoff));        // formed per batch from the lane part every LDS access shares (a hoisted copy gets spilled)
     unsigned char* dst = smem + lane16 + uoff;
 #pragma unroll
@@ -170,30 +174,48 @@ __global__ __launch_bounds__(WN_THREADS) void conv3x3_c64_wino_kernel(wino_args 
 #pragma unroll
     for (int xi = 0; xi < 4; ++xi) acc[s][xi] = zinit;
 
-  // one batch of three input rows.  ALL = every output row the batch touches is inside the segment (the steady state: straight-line
-  // code, 72 MFMAs); otherwise the rows are guarded one by one (first / last batches of a unit)
+  // The workgroup barrier of a batch sits behind its SECOND row: V of batch n + 1 (written by every wave after its first row) is then
+  // visible during the third row, whose MFMAs cover the first reads of the next batch; the three-slot ring makes that safe (the slot
+  // written in batch n + 1 was last read in batch n - 1, which every wave has left when it passes this barrier).
+  auto sync = [&]() {
+    if (DBG & 16) return;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+  };
+  f16x8_t fv[2][4];     // V fragments [K half][xi] of the row in flight (steady state; carried from batch to batch)
   // epilogue of a completed accumulator set: y[2t] = M0 + M1 + M2, y[2t+1] = M1 - M2 - M3 (4 output channels each), activation, fp16;
   // lanes kg and kg ^ 1 then trade halves (v_permlane16_swap: odd 16-lane rows of the first operand <-> even rows of the second) so
   // that an even kg holds channels 8 (kg >> 1) .. + 7 of column 2t and an odd kg those of column 2t + 1: ONE 16-byte store per lane
-  auto epilogue = [&](const f32x4 (&m)[4], __amdgpu_buffer_rsrc_t ro, unsigned vo, int so) {
+  auto epilogue_math = [&](const f32x4 (&m)[4], u32x2& x, u32x2& y) {
     f16x4_t h0, h1;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       float ye, yo;
       if (DBG & 8) { ye = m[0][k] + m[2][k]; yo = m[1][k] + m[3][k]; }
-      else {
-        ye = m[0][k] + (m[1][k] + m[2][k]); yo = (m[1][k] - m[2][k]) - m[3][k];
-        ye = fmaxf(ye, slope * ye); yo = fmaxf(yo, slope * yo);
-      }
+      else { ye = m[0][k] + (m[1][k] + m[2][k]); yo = (m[1][k] - m[2][k]) - m[3][k]; }
       h0[k] = (_Float16)ye;
       h1[k] = (_Float16)yo;
     }
-    const u32x2 x = __builtin_bit_cast(u32x2, h0), y = __builtin_bit_cast(u32x2, h1);
+    if (!(DBG & 8)) {
+      // activation on the packed fp16 values (8 vector instructions instead of 16): max(h, slope h).  The slope's own fp16 rounding
+      // (0.1 -> 0.09998) and the second rounding touch negative results only, whose magnitude is a tenth of their pre-activation's:
+      // their absolute error stays below that of the positive results
+      h0 = __builtin_elementwise_max(h0, h0 * slope_h);
+      h1 = __builtin_elementwise_max(h1, h1 * slope_h);
+    }
+    x = __builtin_bit_cast(u32x2, h0); y = __builtin_bit_cast(u32x2, h1);
+  };
+  auto epilogue_store = [&](u32x2 x, u32x2 y, __amdgpu_buffer_rsrc_t ro, unsigned vo, int so) {
     const auto s0 = __builtin_amdgcn_permlane16_swap(x[0], y[0], false, false);
     const auto s1 = __builtin_amdgcn_permlane16_swap(x[1], y[1], false, false);
     const u32x4 v = {s0[0], s1[0], s0[1], s1[1]};
     if (!(DBG & 4)) __builtin_amdgcn_raw_buffer_store_b128(v, ro, (int)vo, so, 0);
     else if (v[0] == 0x12345678u && v[3] == 0x9abcdef0u) __builtin_amdgcn_raw_buffer_store_b128(v, ro, (int)vo, so, 0);
+  };
+  auto epilogue = [&](const f32x4 (&m)[4], __amdgpu_buffer_rsrc_t ro, unsigned vo, int so) {
+    u32x2 x, y;
+    epilogue_math(m, x, y);
+    epilogue_store(x, y, ro, vo, so);
   };
   // scalar (row) part of a store address; the lane part `vo` carries the column, the channel half and (S2D) the x phase's plane
   auto row_offset = [&](int r) {
@@ -203,46 +225,66 @@ __global__ __launch_bounds__(WN_THREADS) void conv3x3_c64_wino_kernel(wino_args 
 
   // one batch of three input rows.  ALL = every output row the batch touches is inside the segment (the steady state: straight-line
   // code, 72 MFMAs); otherwise the rows are guarded one by one (first / last batches of a unit)
-  auto batch = [&](auto all_tag, int n, int b, int y0, int y1, int i0, unsigned vo, auto&& mid) {
+  // chain: a steady-state batch of the same unit follows (this batch then prefetches its first fragments and, in waves 4-7, leaves
+  // its last epilogue to it); fv_ready: the previous batch did so
+  auto batch = [&](auto all_tag, int n, int b, int y0, int y1, int i0, unsigned vo, bool chain, bool fv_ready, auto&& mid) {
     constexpr bool ALL = decltype(all_tag)::value;
-    unsigned voff = (unsigned)((n & 1) * WN_SLOT);
-    asm volatile("" : "+s"(voff));
+    unsigned voff = (unsigned)((n % WN_NSLOT) * WN_SLOT), voff_next = (unsigned)(((n + 1) % WN_NSLOT) * WN_SLOT);
+    asm volatile("" : "+s"(voff), "+s"(voff_next));
     const unsigned char* vbase = smem + lane16 + voff;
+    const unsigned char* vnext = smem + lane16 + voff_next;
     const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<unsigned char*>(a.out) + (long long)b * out_img_bytes,
                                                                         0, (int)out_img_bytes, 0x00020000);
     if constexpr (ALL) {
       // steady state.  The eight V fragments of a row are requested in one go -- those of row j + 1 right behind row j's MFMAs, i.e.
       // BEFORE row j's epilogue, whose vector work covers their latency (with reads only two fragments ahead of their MFMAs every
       // triple of MFMAs waited ~100 cycles for the LDS: the first build of this kernel spent 2.3x its MFMA time per batch)
-      f16x8_t fv[8];
+      // fragments of a row as two K halves of four (xi): fv[sc][xi].  Half `sc` of row j + 1 is requested right behind the MFMAs of
+      // half `sc` of row j (its registers are free then): every read runs twelve MFMAs ahead of its use without a second buffer
+      auto read_half = [&](const unsigned char* base, int jj, int sc) {
 #pragma unroll
-      for (int f = 0; f < 8; ++f) fv[f] = *reinterpret_cast<const f16x8_t*>(vbase + f * 1024);
+        for (int xi = 0; xi < 4; ++xi) fv[sc][xi] = *reinterpret_cast<const f16x8_t*>(base + jj * WN_VROW + (xi * 2 + sc) * 1024);
+      };
+      if (!fv_ready) {
+        read_half(vbase, 0, 0);
+        read_half(vbase, 0, 1);
+      }
+      // STAGGER (MI355X_MICROARCH.md, "two waves that run the same program with one barrier per block"): waves w and w + 4 share a
+      // SIMD and would otherwise reach their MFMA runs and their vector-only epilogues together.  Waves 4-7 keep the batch's last
+      // completed row in its accumulators across the barrier and convert / store it HERE, at the start of the next batch (the
+      // accumulator set is re-opened by this batch's first row only after that), while their SIMD partner is in its MFMAs.
+      if (grp_b) epilogue(acc[1], ro, vo, row_offset(i0 - 2));
+      __builtin_amdgcn_sched_barrier(0);
+      auto row = [&](auto jc) {
+        constexpr int j = decltype(jc)::value;
+        constexpr int s2 = (j + 2) % 3, s1 = j, s0 = (j + 1) % 3;
 #pragma unroll
-      for (int j = 0; j < WN_ROWS; ++j) {
-        const int s2 = (j + 2) % 3, s1 = j, s0 = (j + 1) % 3;
-        f32x4 done[4];
-#pragma unroll
-        for (int sc = 0; sc < 2; ++sc)
+        for (int sc = 0; sc < 2; ++sc) {
+          // dy = 2 first: it completes output row i0 + j - 1, whose results have then landed when the epilogue starts
 #pragma unroll
           for (int xi = 0; xi < 4; ++xi) {
-            const f16x8_t f = fv[xi * 2 + sc];
-            if (DBG & 1) { asm volatile("" :: "v"(f)); if (sc == 0) acc[s0][xi] = xi == 1 ? binit : zinit; continue; }
-            acc[s2][xi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[2][xi][sc], f, acc[s2][xi], 0, 0, 0);
-            acc[s1][xi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[1][xi][sc], f, acc[s1][xi], 0, 0, 0);
-            acc[s0][xi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[0][xi][sc], f, sc == 0 ? (xi == 1 ? binit : zinit) : acc[s0][xi], 0, 0, 0);
+            if (DBG & 1) { asm volatile("" :: "v"(fv[sc][xi])); continue; }
+            acc[s2][xi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[2][xi][sc], fv[sc][xi], acc[s2][xi], 0, 0, 0);
           }
 #pragma unroll
-        for (int xi = 0; xi < 4; ++xi) done[xi] = acc[s2][xi];
-        __builtin_amdgcn_sched_barrier(0);
-        if (j + 1 < WN_ROWS) {
-#pragma unroll
-          for (int f = 0; f < 8; ++f) fv[f] = *reinterpret_cast<const f16x8_t*>(vbase + (j + 1) * WN_VROW + f * 1024);
+          for (int xi = 0; xi < 4; ++xi) {
+            if (DBG & 1) { if (sc == 0) acc[s0][xi] = xi == 1 ? binit : zinit; continue; }
+            acc[s1][xi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[1][xi][sc], fv[sc][xi], acc[s1][xi], 0, 0, 0);
+            acc[s0][xi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[0][xi][sc], fv[sc][xi], sc == 0 ? (xi == 1 ? binit : zinit) : acc[s0][xi], 0, 0, 0);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+          if (j + 1 < WN_ROWS) read_half(vbase, j + 1, sc);
+          else if (chain) read_half(vnext, 0, sc);
+          __builtin_amdgcn_sched_barrier(0);
         }
-        __builtin_amdgcn_sched_barrier(0);
-        epilogue(done, ro, vo, row_offset(i0 + j - 1));
+        if (j < 2 || !(grp_b && chain)) epilogue(acc[s2], ro, vo, row_offset(i0 + j - 1));
         if (j == 0) mid();
+        if (j == 1) sync();
         __builtin_amdgcn_sched_barrier(0);
-      }
+      };
+      row(std::integral_constant<int, 0>{});
+      row(std::integral_constant<int, 1>{});
+      row(std::integral_constant<int, 2>{});
     } else {
 #pragma unroll
       for (int j = 0; j < WN_ROWS; ++j) {
@@ -273,17 +315,13 @@ __global__ __launch_bounds__(WN_THREADS) void conv3x3_c64_wino_kernel(wino_args 
           }
         }
         // (a row that is not stored still issues its store, out of range: every path then has the same vector-memory sequence)
-        epilogue(acc[s2], ro, v2 ? vo : 0x80000000u, row_offset(r2));
+        if (j < 2 || !(grp_b && chain)) epilogue(acc[s2], ro, v2 ? vo : 0x80000000u, row_offset(r2));
         if (j == 0) mid();
+        if (j == 1) sync();
       }
     }
   };
 
-  auto sync = [&]() {
-    if (DBG & 16) return;
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-  };
   // the next batch's place in the unit sequence (clamped at the end: the last batch is re-loaded, harmlessly)
   auto next_coords = [&](int n, int& b, int& x0, int& y0, int& y1, int& i0) {
     n = min(n, T - 1);
@@ -319,6 +357,7 @@ __global__ __launch_bounds__(WN_THREADS) void conv3x3_c64_wino_kernel(wino_args 
     if constexpr (S2D) vo = (unsigned)(xo >> 1) * 32u + (unsigned)(kg >> 1) * 16u + (unsigned)(kg & 1) * (unsigned)(nck * (H >> 1) * (W >> 1) * 32);
     else vo = (unsigned)xo * 32u + (unsigned)(kg >> 1) * 16u;
     if (xo >= W) vo = 0x80000000u;
+    if (DBG & 64) vo = (unsigned)x0 * 32u + lane16;                             // ablation: line-contiguous stores (wrong layout)
     src_lane_offsets(x0, va, vb);
     // batch m covers input rows y0 - 1 + 3m ..+2; every output row it touches is inside the segment for 1 <= m < mf
     const int mf = (y1 - y0) / 3;
@@ -340,19 +379,16 @@ __global__ __launch_bounds__(WN_THREADS) void conv3x3_c64_wino_kernel(wino_args 
         issue_loads(nn + 2, va2, vb2, b2, y02, y12, i02);
       };
     };
-    batch(std::false_type{}, n, b, y0, y1, y0 - 1, vo, mid_any(n));
-    sync();
+    // steady-state batches: 1 <= m < mfast (the last two batches of a unit prefetch across the unit boundary through the general
+    // path).  A batch defers its last row's epilogue (waves 4-7) exactly when a steady-state batch of the same unit follows it.
+    const int mfast = min(mf, NB - 2);
+    batch(std::false_type{}, n, b, y0, y1, y0 - 1, vo, 1 < mfast, false, mid_any(n));
     ++n;
     int m = 1;
-    // steady state; its last two batches prefetch across the unit boundary (m + 2 >= NB) through the general path
-    for (; m < mf && m + 2 < NB; ++m, ++n) {
-      batch(std::true_type{}, n, b, y0, y1, y0 - 1 + m * WN_ROWS, vo, mid_same(n, m));
-      sync();
-    }
-    for (; m < NB; ++m, ++n) {
-      batch(std::false_type{}, n, b, y0, y1, y0 - 1 + m * WN_ROWS, vo, mid_any(n));
-      sync();
-    }
+    for (; m < mfast; ++m, ++n)
+      batch(std::true_type{}, n, b, y0, y1, y0 - 1 + m * WN_ROWS, vo, m + 1 < mfast, m > 1, mid_same(n, m));
+    for (; m < NB; ++m, ++n)
+      batch(std::false_type{}, n, b, y0, y1, y0 - 1 + m * WN_ROWS, vo, false, false, mid_any(n));
   }
 }
 
@@ -385,9 +421,18 @@ extern "C" int cdfo_pack_conv3x3_wino(const float* w_oihw, void* packed, int Cou
 // 3 * ceil((seg_h + 2) / 3) row steps (+ one barrier per batch).
 namespace {
 template <int DBG>
-void wino_launch(const wino_args& a, int grid, hipStream_t st) {
-  if (a.s2d) hipLaunchKernelGGL((conv3x3_c64_wino_kernel<true, DBG>), dim3(grid), dim3(WN_THREADS), WN_LDS, st, a);
-  else hipLaunchKernelGGL((conv3x3_c64_wino_kernel<false, DBG>), dim3(grid), dim3(WN_THREADS), WN_LDS, st, a);
+int wino_launch(const wino_args& a, int grid, hipStream_t st) {
+  static CdfoAttrOnce once_s, once_p;       // 72 KiB of dynamic LDS: above the 64 KiB a kernel gets without asking
+  if (a.s2d) {
+    const hipError_t e = cdfo_set_max_lds(once_s, reinterpret_cast<const void*>(conv3x3_c64_wino_kernel<true, DBG>), WN_LDS);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL((conv3x3_c64_wino_kernel<true, DBG>), dim3(grid), dim3(WN_THREADS), WN_LDS, st, a);
+  } else {
+    const hipError_t e = cdfo_set_max_lds(once_p, reinterpret_cast<const void*>(conv3x3_c64_wino_kernel<false, DBG>), WN_LDS);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL((conv3x3_c64_wino_kernel<false, DBG>), dim3(grid), dim3(WN_THREADS), WN_LDS, st, a);
+  }
+  return 0;
 }
 }  // namespace
 
@@ -423,20 +468,25 @@ extern "C" int cdfo_conv3x3_c64_wino_dbg(const void* src_cp16, int B, int H, int
   a.seg_h = best_seg; a.nseg = (H + best_seg - 1) / best_seg; a.nstrips = nstrips; a.nb = (best_seg + 2 + 2) / 3;
   const double px = (double)B * H * W;
   CdfoProfScope prof(st, KID_CONV3_WINO, 2.0 * px * Cout * 64 * 9, 2.0 * (px * Cout + px * 64) + 2.0 * 12 * 64 * Cout);
+  int rc = 0;
   switch (dbg) {
-    case 0: wino_launch<0>(a, nslots * 8, st); break;
-    case 1: wino_launch<1>(a, nslots * 8, st); break;
-    case 2: wino_launch<2>(a, nslots * 8, st); break;
-    case 4: wino_launch<4>(a, nslots * 8, st); break;
-    case 8: wino_launch<8>(a, nslots * 8, st); break;
-    case 12: wino_launch<12>(a, nslots * 8, st); break;
-    case 16: wino_launch<16>(a, nslots * 8, st); break;
-    case 6: wino_launch<6>(a, nslots * 8, st); break;
-    case 14: wino_launch<14>(a, nslots * 8, st); break;
-    case 30: wino_launch<30>(a, nslots * 8, st); break;
-    case 31: wino_launch<31>(a, nslots * 8, st); break;
+    case 0: rc = wino_launch<0>(a, nslots * 8, st); break;
+    case 1: rc = wino_launch<1>(a, nslots * 8, st); break;
+    case 2: rc = wino_launch<2>(a, nslots * 8, st); break;
+    case 4: rc = wino_launch<4>(a, nslots * 8, st); break;
+    case 8: rc = wino_launch<8>(a, nslots * 8, st); break;
+    case 12: rc = wino_launch<12>(a, nslots * 8, st); break;
+    case 16: rc = wino_launch<16>(a, nslots * 8, st); break;
+    case 6: rc = wino_launch<6>(a, nslots * 8, st); break;
+    case 14: rc = wino_launch<14>(a, nslots * 8, st); break;
+    case 30: rc = wino_launch<30>(a, nslots * 8, st); break;
+    case 31: rc = wino_launch<31>(a, nslots * 8, st); break;
+    case 32: rc = wino_launch<32>(a, nslots * 8, st); break;
+    case 64: rc = wino_launch<64>(a, nslots * 8, st); break;
+    case 96: rc = wino_launch<96>(a, nslots * 8, st); break;
     default: return CDFO_EINVAL;
   }
+  if (rc) return rc;
   CDFO_LAUNCH_CHECK();
   return 0;
 }

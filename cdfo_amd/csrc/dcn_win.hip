@@ -97,7 +97,7 @@ __device__ __forceinline__ f32x4 wn_bload4(__amdgpu_buffer_rsrc_t r, unsigned vo
 }
 
 // MJ: 32-channel output tiles (Co = 32 MJ); AL4: W % 4 == 0 and a 16-byte aligned input; MASK: modulated (DCNv2)
-// DBG (developer ablations through CDFO_DCN_DBG, wrong results, tools/bench_dcn.py only): 1 = no MFMAs, 2 = no LDS reads of the
+// DBG (developer ablations through CDFO_DCN_DBG in -DCDFO_DEV_ABLATIONS builds, wrong results, tools/bench_dcn.py only): 1 = no MFMAs, 2 = no LDS reads of the
 // samples' corners, 4 = no window staging after the first chunk, 8 = no offset / mask loads after the first chunk, 16 = no
 // workgroup barriers
 template <int MJ, bool AL4, bool MASK, int DBG = 0>
@@ -512,7 +512,9 @@ int cdfo_dcn_forward_win(const float* in, const float* offset, const float* mask
     case 5: e = wn_launch<2, false, true>(a, grid, st); break;
     case 6: e = wn_launch<2, true, false>(a, grid, st); break;
     default: {
-      // developer ablations of the alignment module's variant (tools/bench_dcn.py; results are wrong by construction)
+#ifdef CDFO_DEV_ABLATIONS
+      // developer ablations of the alignment module's variant (tools/bench_dcn.py; results are wrong by construction): compiled only
+      // into developer builds (-DCDFO_DEV_ABLATIONS) -- the shipped library reads no environment variable on this path
       static const int dbg_sel = [] { const char* v = getenv("CDFO_DCN_DBG"); return v ? atoi(v) : 0; }();      // read once per process
       switch (dbg_sel) {
         case 1: e = wn_launch<2, true, true, 1>(a, grid, st); break;
@@ -526,6 +528,9 @@ int cdfo_dcn_forward_win(const float* in, const float* offset, const float* mask
         case 31: e = wn_launch<2, true, true, 31>(a, grid, st); break;
         default: e = wn_launch<2, true, true>(a, grid, st); break;
       }
+#else
+      e = wn_launch<2, true, true>(a, grid, st);
+#endif
       break;
     }
   }

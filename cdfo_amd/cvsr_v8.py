@@ -16,7 +16,11 @@ Differences, all deliberate:
     (fresh uniforms per call, never 0), by a Philox4x32-10 generator inside the mask kernel, keyed per forward from
     torch's default generator (``torch.manual_seed`` reproduces a run); ``capture_noise = []`` collects the values drawn.
   * ``range_guard`` (default True): in the default ``fp16x2`` mode a forward whose activations leave fp16's range is
-    detected (max |trunk input| outside [2^-6, 2^11], or a non-finite result) and repeated in ``bf16x3``.
+    detected (max |trunk input| outside [2^-6, 2^11], or a non-finite trunk input / result) and repeated in ``bf16x3``.  The
+    trunk-input check is settled before the call returns; the result's non-finite check is settled at the start of the next
+    forward, by ``finish_range_guard()`` or by reading ``last_range`` -- a result it rejects is recomputed INTO the returned
+    tensors (call ``finish_range_guard()`` before consuming the last result of a run).  ``range_guard = "sync"`` settles both
+    before returning (one host sync per forward).
   * ``precision`` attribute: "f32" | "bf16x3" | "fp16x2" (default) | "bf16" selects the matrix-core arithmetic of the
     wide 3x3 convolutions; "f32", "bf16x3" and "fp16x2" meet the 1e-3 max-abs parity bound against the fp32 reference
     (1e-6, 1e-5 and 3-5e-4 respectively), "bf16" does not (6e-3).
@@ -591,34 +595,110 @@ class CVSR_V8(nn.Module):
                 from .cvsr_v8_train import forward_train
                 return forward_train(self, x, mvs0, mvs1, pms, rms, ufs, noise)
             guard = self.precision == "fp16x2" and self.range_guard
-            self._probe = torch.zeros(4, dtype=torch.int32, device=x.device) if guard else None
-            res = self._forward(x, mvs0, mvs1, pms, rms, ufs, pre_L1_fea, noise)
+            # the previous forward's deferred output check (below) is settled first: it may repair that forward's tensors in place
+            self.finish_range_guard()
             if not guard:
-                return res
-            # fp16 range guard (one 16-byte readback per forward): the fp16x2 mode keeps the trunk's tensors (and the
-            # alignment's residual blocks) in fp16.  Outside fp16's comfortable range -- max |trunk input| not in
-            # [2^-6, 2^11], or a NaN / infinity in the result, which is what an overflowed fp16 store turns into --
-            # the forward is repeated in the split-bf16 mode (fp32 exponent range, fp32-grade products).
-            bits = self._probe.cpu()
-            self._probe = None
-            amax = bits[0:1].view(torch.float32).item()
-            self.last_range = {"trunk_input_amax": amax, "nonfinite": bool(bits[1].item() | bits[3].item()), "fallback": False}
-            if not self.last_range["nonfinite"] and (amax == 0.0 or self.FP16_WINDOW[0] <= amax <= self.FP16_WINDOW[1]):
-                return res
-            if not self._warned_range:
-                import warnings
-                warnings.warn(f"CVSR_V8 (HIP): activations leave the fp16 range (max |trunk input| = {amax:.3g}, non-finite "
-                              f"result: {self.last_range['nonfinite']}); this forward and others like it are recomputed with "
-                              "precision='bf16x3'.  Set model.precision = 'bf16x3' to avoid the repeated work.")
-                self._warned_range = True
-            self.last_range["fallback"] = True
-            # the retry's mode is an override visible to THIS thread only: another thread / stream sharing the module keeps
-            # reading the attribute the user set
-            CVSR_V8._tls.override = (self, "bf16x3")
-            try:
+                self._probe = None
                 return self._forward(x, mvs0, mvs1, pms, rms, ufs, pre_L1_fea, noise)
-            finally:
-                CVSR_V8._tls.override = None
+            if torch.cuda.is_current_stream_capturing():
+                raise RuntimeError("CVSR_V8 (HIP): the fp16 range guard reads probes back and cannot be captured; use model.capture(), "
+                                   "which checks an eager forward first and captures with the guard off")
+            # fp16 range guard: the fp16x2 mode keeps the trunk's tensors (and the alignment's residual blocks) in fp16.  Outside
+            # fp16's comfortable range -- max |trunk input| not in [2^-6, 2^11], or a NaN / infinity in the trunk input or in the
+            # result (what an overflowed fp16 store turns into) -- the forward is repeated in the split-bf16 mode (fp32 exponent range,
+            # fp32-grade products).  The two probes are read back WITHOUT draining the GPU (round 5; the synchronous 16-byte readback
+            # of rounds 2-4 left a ~0.7 ms bubble in front of every next forward):
+            #   * the trunk-input probe is copied to pinned host memory right behind the temporal fusion, i.e. with the whole trunk
+            #     (half of the forward) still queued behind it; waiting for THAT copy before returning costs no idle time;
+            #   * the result's non-finite probe is copied behind the last kernel and checked at the start of the NEXT forward (or by
+            #     finish_range_guard() / model.last_range): if it fires, the forward is recomputed in bf16x3 INTO the tensors that
+            #     were returned.  range_guard = "sync" restores the check-before-return behaviour.
+            self._probe = torch.zeros(4, dtype=torch.int32, device=x.device)
+            host = self._guard_host_buffers(x.device)
+            self._guard_events = [torch.cuda.Event(), torch.cuda.Event()]
+            res = self._forward(x, mvs0, mvs1, pms, rms, ufs, pre_L1_fea, noise)
+            probe, self._probe = self._probe, None
+            ev_in, ev_out = self._guard_events
+            self._guard_events = None
+            host[1].copy_(probe[2:4], non_blocking=True)
+            ev_out.record()
+            args = (x, mvs0, mvs1, pms, rms, ufs, pre_L1_fea, noise, self._noise_seed)
+            ev_in.synchronize()
+            amax = host[0][0:1].view(torch.float32).item()
+            self._last_range = {"trunk_input_amax": amax, "nonfinite": bool(host[0][1].item()), "fallback": False}
+            ok = not self._last_range["nonfinite"] and (amax == 0.0 or self.FP16_WINDOW[0] <= amax <= self.FP16_WINDOW[1])
+            if ok and self.range_guard != "sync":
+                import weakref
+                self._pending_guard = (ev_out, host[1], args, weakref.ref(res[0]), weakref.ref(res[1]), probe)
+                return res
+            if ok:
+                ev_out.synchronize()
+                if not host[1][1].item():
+                    return res
+                self._last_range["nonfinite"] = True
+            return self._range_fallback(args, None, None)
+
+    def _guard_host_buffers(self, device):
+        cache = self.__dict__.setdefault("_guard_pinned", {})
+        b = cache.get(device)
+        if b is None:
+            b = cache[device] = (torch.zeros(2, dtype=torch.int32).pin_memory(), torch.zeros(2, dtype=torch.int32).pin_memory())
+        return b
+
+    def _range_fallback(self, args, out_ref, l1_ref):
+        """Recompute a forward whose activations left fp16's range in the split-bf16 mode; with out_ref / l1_ref (the deferred
+        check) the results are written into the tensors the caller already holds."""
+        x, mvs0, mvs1, pms, rms, ufs, pre, noise, seed = args
+        lr = self._last_range
+        if not self._warned_range:
+            import warnings
+            warnings.warn(f"CVSR_V8 (HIP): activations leave the fp16 range (max |trunk input| = {lr['trunk_input_amax']:.3g}, non-finite "
+                          f"result: {lr['nonfinite']}); this forward and others like it are recomputed with "
+                          "precision='bf16x3'.  Set model.precision = 'bf16x3' to avoid the repeated work.")
+            self._warned_range = True
+        lr["fallback"] = True
+        # the retry's mode is an override visible to THIS thread only: another thread / stream sharing the module keeps
+        # reading the attribute the user set
+        CVSR_V8._tls.override = (self, "bf16x3")
+        keep_seed, keep_probe = self._noise_seed, self._probe
+        self._noise_seed, self._probe = seed, None
+        try:
+            with torch.no_grad():
+                res = self._forward(x, mvs0, mvs1, pms, rms, ufs, pre, noise)
+        finally:
+            CVSR_V8._tls.override = None
+            self._noise_seed, self._probe = keep_seed, keep_probe
+        if out_ref is not None:
+            out_ref.copy_(res[0])
+        if l1_ref is not None:
+            l1_ref.copy_(res[1])
+        return res
+
+    def finish_range_guard(self) -> None:
+        """Settle the deferred half of the fp16 range guard: wait for the previous guarded forward's result probe and, if the result
+        held a NaN / infinity, recompute that forward in bf16x3 into the tensors it returned (those still alive).  Called at the start
+        of every forward and by ``last_range``; call it yourself before consuming the LAST forward's result of a run."""
+        pend = self.__dict__.get("_pending_guard")
+        if pend is None:
+            return
+        self._pending_guard = None
+        ev, host, args, out_w, l1_w, _probe = pend
+        ev.synchronize()
+        if not host[1].item():
+            return
+        self._last_range["nonfinite"] = True
+        with K.on_device(args[0]):
+            self._range_fallback(args, out_w(), l1_w())
+
+    @property
+    def last_range(self):
+        """What the fp16 range guard saw in the most recent guarded forward (settles its deferred result check first)."""
+        self.finish_range_guard()
+        return self.__dict__.get("_last_range")
+
+    @last_range.setter
+    def last_range(self, value):
+        self._last_range = value
 
     FP16_WINDOW = (2.0 ** -6, 2.0 ** 11)
 
@@ -771,6 +851,10 @@ class CVSR_V8(nn.Module):
         fused = self._conv(aligned, w["tsa_fusion"], act=K.ACT_LRELU)
         if self._probe is not None:
             K.range_probe(fused, self._probe[0:2])
+            ev = getattr(self, "_guard_events", None)
+            if ev is not None:        # forward(): the probe travels to pinned host memory now, with the trunk still to be queued behind it
+                self._guard_host_buffers(fused.device)[0].copy_(self._probe[0:2], non_blocking=True)
+                ev[0].record()
         return fused, L1, x
 
     def _back(self, fused, x, L1=None):

@@ -25,6 +25,7 @@ a non-4D input ``ValueError`` (:26-29), an empty output ``ValueError`` (:182-183
 from __future__ import annotations
 
 import ctypes as C
+import threading
 import math
 import os
 from dataclasses import dataclass
@@ -86,30 +87,40 @@ class Geometry:
 
 
 class _Scratch:
-    """Grow-only device scratch per (device index, stream handle).  Launches on one stream are ordered, so the next
-    launch may overwrite what the previous one left; two streams never share a buffer.  Plumbing, no arithmetic."""
+    """Device scratch per (device index, stream handle).  Launches on one stream are ordered, so the next launch may
+    overwrite what the previous one left; two streams never share a buffer.  Plumbing, no arithmetic.
+    Only SMALL workspaces are cached (the forward's weight image and flags: a few MB): a request above ``CACHE_LIMIT`` -- the
+    backward's per-tile column / grad_output copies, 2.7 GB at the alignment module's c3 shape -- is a plain allocation that torch's
+    caching allocator recycles and ``torch.cuda.empty_cache()`` can give back.  The table is bounded (``MAX_ENTRIES`` streams, oldest
+    evicted) and guarded by a lock: DCN calls may come from several threads / side streams."""
+    CACHE_LIMIT = 64 << 20
+    MAX_ENTRIES = 16
     _bufs: dict = {}
+    _lock = threading.Lock()
 
     @classmethod
     def get(cls, device, nbytes: int):
-        if torch.cuda.is_current_stream_capturing():     # a graph's private pool must not leak into the cache
+        if nbytes > cls.CACHE_LIMIT or torch.cuda.is_current_stream_capturing():     # (a graph's private pool must not leak into the cache)
             return torch.empty(max(nbytes, 16), dtype=torch.uint8, device=device)
         key = (device.index, int(torch.cuda.current_stream(device).cuda_stream))
-        buf = cls._bufs.get(key)
-        if buf is None or buf.numel() < nbytes:
-            buf = None
-            cls._bufs.pop(key, None)
-            buf = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=device)
-            cls._bufs[key] = buf
-        return buf
+        with cls._lock:
+            buf = cls._bufs.get(key)
+            if buf is None or buf.numel() < nbytes:
+                cls._bufs.pop(key, None)
+                while len(cls._bufs) >= cls.MAX_ENTRIES:
+                    cls._bufs.pop(next(iter(cls._bufs)))
+                buf = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=device)
+                cls._bufs[key] = buf
+            return buf
 
     @classmethod
     def release(cls):
-        cls._bufs.clear()
+        with cls._lock:
+            cls._bufs.clear()
 
 
 def release_workspaces() -> None:
-    """Give the cached operator scratch (up to 2.7 GB after a backward at the alignment module's c3 shape) back."""
+    """Drop the cached (small) operator workspaces; the large backward scratch is never cached."""
     _Scratch.release()
 
 

@@ -379,6 +379,11 @@ def conv3x3_wino(src: torch.Tensor, pc: PackedConv, *, act: int = ACT_NONE, s2d:
     return out
 
 
+def conv_offset_mask_ws_fits(B: int, H: int, W: int, third: int) -> bool:
+    """The 32-bit addressing limits of cdfo_conv3x3_c64_ws_offmask: the whole fp16 source and one image's offset planes below 2 GiB."""
+    return 4 * H * W * 32 * B < (1 << 31) and H * W * 2 * third * 4 < (1 << 31)
+
+
 def conv_offset_mask_ws(src: torch.Tensor, pc: PackedConv, offset: torch.Tensor, mask: torch.Tensor, flow: torch.Tensor, mag: float,
                         accumulate: bool) -> None:
     """conv_offset_mask on the weights-stationary kernel (single-pass fp16 operands): src fp16 chunk-planar [B,4,H,W,16]; the rest as
@@ -390,7 +395,7 @@ def conv_offset_mask_ws(src: torch.Tensor, pc: PackedConv, offset: torch.Tensor,
     if (pc.wh is None or pc.Cin != 64 or pc.ks != 3 or pc.Cout % 3 or H % 2 or (2 * third) % 32 or pc.Cout % 8
             or tuple(offset.shape) != (B, 2 * third, H, W) or tuple(mask.shape) != (B, third, H, W) or tuple(flow.shape) != (B, 2, H, W)
             or not (offset.is_contiguous() and mask.is_contiguous() and flow.is_contiguous())
-            or any(t.dtype != torch.float32 for t in (offset, mask, flow)) or 4 * H * W * 32 * B >= (1 << 31)):
+            or any(t.dtype != torch.float32 for t in (offset, mask, flow)) or not conv_offset_mask_ws_fits(B, H, W, third)):
         raise ValueError("conv_offset_mask_ws: unsupported configuration")
     check(_lib.lib().cdfo_conv3x3_c64_ws_offmask(_vp(src), B, H, W, _vp(pc.wh), pc.CoutP16, _vp(pc.bias), pc.Cout, _vp(offset), _vp(mask),
                                                  _vp(flow), C.c_longlong(2 * H * W), float(mag), int(accumulate), _stream()),
@@ -921,7 +926,11 @@ def fold_scale_inputs(fold: PackedConv, gate: torch.Tensor) -> PackedConv:
     cin = _FOLD_CIN.get(gate.device)
     if cin is None:       # packed layout [Cin/16][4][CoutP = 64][4]: input channel of every element
         i = torch.arange(4096, device=gate.device)
-        cin = _FOLD_CIN[gate.device] = (i // 1024) * 16 + ((i // 256) % 4) * 4 + i % 4
+        cin = (i // 1024) * 16 + ((i // 256) % 4) * 4 + i % 4
+        # cached only outside stream capture: a table built while capturing lives in the graph's private pool and is merely RECORDED,
+        # so a later eager call would read uninitialised indices
+        if not (gate.is_cuda and torch.cuda.is_current_stream_capturing()):
+            _FOLD_CIN[gate.device] = cin
     return PackedConv(fold.w * gate[:, cin], None, 64, 64, 1, 64, False, 4096)
 
 

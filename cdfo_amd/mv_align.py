@@ -122,10 +122,12 @@ class MVDualAttAlignment(ModulatedDeformConvPack):
         mask = torch.empty((B, third, H, W), dtype=torch.float32, device=x.device)
         # the 16-bit head writes the DCN's NCHW offset / mask planes from its own epilogue (first head: tanh + flow / raw mask sums,
         # second head: in-place accumulate + sigmoid); the exact-fp32 head and widths that are no multiple of 4 assemble separately
-        fused = self.fuse_assembly and prec != K.PREC_F32 and W % 4 == 0
+        fuse_epilogue = self.fuse_assembly and prec != K.PREC_F32 and W % 4 == 0
+        # the weights-stationary head addresses its source and the offset planes of ONE image with 32-bit buffer offsets
+        # (cdfo_conv3x3_c64_ws_offmask): larger frames (e.g. 1920x1080 at dg = 16) take the tiled head below
         ws_head = (self.ws_head and prec == K.PREC_FP16X2 and self.head_one_pass and self.off0_one_pass and H % 2 == 0
-                   and (2 * third) % 32 == 0 and B * H * W * 128 < (1 << 31))
-        fused = fused or ws_head
+                   and (2 * third) % 32 == 0 and K.conv_offset_mask_ws_fits(B, H, W, third))
+        fuse_epilogue = fuse_epilogue or ws_head
         outs = []
         for n_head, v in enumerate((warped, pred)):
             part, n = K.chan_sum_partial(v)
@@ -143,14 +145,14 @@ class MVDualAttAlignment(ModulatedDeformConvPack):
                 continue
             o = K.conv(o, w["off0"], pad=1, act=K.ACT_LRELU,
                        prec=K.PREC_FP16X1 if (prec == K.PREC_FP16X2 and self.off0_one_pass) else prec)
-            if fused:
+            if fuse_epilogue:
                 # fp16x2: the head's weights are rounded once to fp16 in that mode; rounding its input once as well (one MFMA pass
                 # instead of two) adds an error of the same size -- CVSR_V7's parity moves inside its 10x margin
                 hp = K.PREC_FP16X1 if (prec == K.PREC_FP16X2 and self.head_one_pass) else prec
                 K.conv_offset_mask(o, w["off2"], offset, mask, flow, self.max_residue_magnitude, n_head == 1, hp)
             else:
                 outs.append(K.conv(o, w["off2"], pad=1, prec=prec))       # [B,H,W,27*dg]
-        if not fused:
+        if not fuse_epilogue:
             vp = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
             check(_lib.lib().cdfo_mv_offset_mask(vp(outs[0]), vp(outs[1]), outs[0].stride(2), vp(flow), C.c_longlong(2 * P),
                                                  B, C.c_longlong(P), third, float(self.max_residue_magnitude), vp(offset),

@@ -38,6 +38,86 @@ static REAL NAME(bilinear)(const REAL* im, int H, int W, REAL h, REAL w) {
   return hh * hw * v1 + hh * lw * v2 + lh * hw * v3 + lh * lw * v4;
 }
 
+/* The forward runs its two loops (columns, then the per-group product) over a few host threads: the oracle is also the checker at the
+ * benchmark's frame size (36 calls per CVSR_V7 forward at up to 272x480).  The arithmetic of every output element is unchanged --
+ * the same products accumulated in double in the same order (k ascending); the product loop is merely interchanged so that it
+ * streams over `columns` rows instead of striding through them. */
+#ifndef DCN_REF_THREADS_DEFINED
+#define DCN_REF_THREADS_DEFINED
+#include <pthread.h>
+#include <unistd.h>
+typedef struct { void (*fn)(void*, int); void* ctx; int begin, end; } dcn_ref_task;
+static void* dcn_ref_worker(void* a) {
+  dcn_ref_task* t = (dcn_ref_task*)a;
+  for (int i = t->begin; i < t->end; ++i) t->fn(t->ctx, i);
+  return NULL;
+}
+static int dcn_ref_nthreads(void) {
+  const char* e = getenv("ORACLE_DCN_THREADS");
+  long n = e ? atol(e) : sysconf(_SC_NPROCESSORS_ONLN);
+  if (n < 1) n = 1;
+  if (n > 32) n = 32;
+  return (int)n;
+}
+static void dcn_ref_parallel_for(int n, void (*fn)(void*, int), void* ctx) {
+  int nt = dcn_ref_nthreads();
+  if (nt > n) nt = n;
+  if (nt <= 1) { for (int i = 0; i < n; ++i) fn(ctx, i); return; }
+  pthread_t th[32];
+  dcn_ref_task tk[32];
+  for (int t = 0; t < nt; ++t) {
+    tk[t].fn = fn; tk[t].ctx = ctx; tk[t].begin = (int)((long)n * t / nt); tk[t].end = (int)((long)n * (t + 1) / nt);
+    if (t && pthread_create(&th[t], NULL, dcn_ref_worker, &tk[t]) != 0) { dcn_ref_worker(&tk[t]); th[t] = 0; tk[t].begin = tk[t].end; }
+  }
+  dcn_ref_worker(&tk[0]);
+  for (int t = 1; t < nt; ++t) if (tk[t].begin != tk[t].end || th[t]) { if (th[t]) pthread_join(th[t], NULL); }
+}
+#endif
+
+typedef struct {
+  const REAL *in, *offset, *mask, *weight, *bias;
+  REAL *out, *col;
+  int b, C, H, W, Co, kh, kw, sh, sw, ph, pw, dh, dw, groups, dg, Ho, Wo;
+} NAME(dcn_fwd_ctx);
+
+static void NAME(dcn_fwd_columns)(void* vc, int c) {          /* one input channel of image b -> its kh*kw rows of `columns` */
+  const NAME(dcn_fwd_ctx)* q = (const NAME(dcn_fwd_ctx)*)vc;
+  const int H = q->H, W = q->W, kh = q->kh, kw = q->kw, T = kh * kw, P = q->Ho * q->Wo, Cdg = q->C / q->dg, d = c / Cdg;
+  const REAL* im = q->in + ((size_t)q->b * q->C + c) * H * W;
+  const REAL* off = q->offset + ((size_t)q->b * q->dg + d) * 2 * T * P;
+  const REAL* msk = q->mask ? q->mask + ((size_t)q->b * q->dg + d) * T * P : NULL;
+  for (int i = 0; i < kh; ++i)
+    for (int j = 0; j < kw; ++j) {
+      const int t = i * kw + j;
+      for (int ho = 0; ho < q->Ho; ++ho)
+        for (int wo = 0; wo < q->Wo; ++wo) {
+          const int p = ho * q->Wo + wo;
+          const REAL h_im = (REAL)(ho * q->sh - q->ph + i * q->dh) + off[(size_t)(2 * t) * P + p];
+          const REAL w_im = (REAL)(wo * q->sw - q->pw + j * q->dw) + off[(size_t)(2 * t + 1) * P + p];
+          REAL v = 0.f;
+          if (h_im > -1 && w_im > -1 && h_im < H && w_im < W) v = NAME(bilinear)(im, H, W, h_im, w_im);
+          if (msk) v *= msk[(size_t)t * P + p];
+          q->col[((size_t)c * T + t) * P + p] = v;
+        }
+    }
+}
+
+static void NAME(dcn_fwd_product)(void* vc, int oc) {        /* one output channel of image b: weight row x columns[group] + bias */
+  const NAME(dcn_fwd_ctx)* q = (const NAME(dcn_fwd_ctx)*)vc;
+  const int T = q->kh * q->kw, P = q->Ho * q->Wo, Cg = q->C / q->groups, Cog = q->Co / q->groups, g = oc / Cog;
+  const REAL* wr = q->weight + (size_t)oc * Cg * T;
+  REAL* orow = q->out + ((size_t)q->b * q->Co + oc) * P;
+  double* s = (double*)calloc((size_t)P, sizeof(double));
+  if (!s) return;
+  for (int k = 0; k < Cg * T; ++k) {
+    const double w = (double)wr[k];
+    const REAL* cr = q->col + ((size_t)g * Cg * T + k) * P;
+    for (int p = 0; p < P; ++p) s[p] += w * (double)cr[p];
+  }
+  for (int p = 0; p < P; ++p) orow[p] = (REAL)s[p] + (q->bias ? q->bias[oc] : 0.f);
+  free(s);
+}
+
 /* mask == NULL -> DCNv1 (no modulation); bias == NULL -> no bias.  Returns 0, or -1 on a bad shape. */
 int NAME(dcn_forward_ref)(const REAL* in, const REAL* offset, const REAL* mask, const REAL* weight, const REAL* bias,
                     REAL* out, int B, int C, int H, int W, int Co, int kh, int kw, int sh, int sw, int ph, int pw,
@@ -46,41 +126,14 @@ int NAME(dcn_forward_ref)(const REAL* in, const REAL* offset, const REAL* mask, 
   const int Ho = (H + 2 * ph - (dh * (kh - 1) + 1)) / sh + 1;
   const int Wo = (W + 2 * pw - (dw * (kw - 1) + 1)) / sw + 1;
   if (Ho <= 0 || Wo <= 0) return -1;
-  const int T = kh * kw, P = Ho * Wo, Cg = C / groups, Cog = Co / groups, Cdg = C / dg;
+  const int T = kh * kw, P = Ho * Wo;
   REAL* col = (REAL*)malloc(sizeof(REAL) * (size_t)C * T * P); /* the reference's `columns` buffer */
   if (!col) return -1;
+  NAME(dcn_fwd_ctx) q = {in, offset, mask, weight, bias, out, col, 0, C, H, W, Co, kh, kw, sh, sw, ph, pw, dh, dw, groups, dg, Ho, Wo};
   for (int b = 0; b < B; ++b) {
-    for (int c = 0; c < C; ++c) {
-      const int d = c / Cdg;
-      const REAL* im = in + ((size_t)b * C + c) * H * W;
-      const REAL* off = offset + ((size_t)b * dg + d) * 2 * T * P;
-      const REAL* msk = mask ? mask + ((size_t)b * dg + d) * T * P : NULL;
-      for (int i = 0; i < kh; ++i)
-        for (int j = 0; j < kw; ++j) {
-          const int t = i * kw + j;
-          for (int ho = 0; ho < Ho; ++ho)
-            for (int wo = 0; wo < Wo; ++wo) {
-              const int p = ho * Wo + wo;
-              const REAL h_im = (REAL)(ho * sh - ph + i * dh) + off[(size_t)(2 * t) * P + p];
-              const REAL w_im = (REAL)(wo * sw - pw + j * dw) + off[(size_t)(2 * t + 1) * P + p];
-              REAL v = 0.f;
-              if (h_im > -1 && w_im > -1 && h_im < H && w_im < W) v = NAME(bilinear)(im, H, W, h_im, w_im);
-              if (msk) v *= msk[(size_t)t * P + p];
-              col[((size_t)c * T + t) * P + p] = v;
-            }
-        }
-    }
-    for (int g = 0; g < groups; ++g)
-      for (int o = 0; o < Cog; ++o) {
-        const int oc = g * Cog + o;
-        const REAL* wr = weight + (size_t)oc * Cg * T;
-        REAL* orow = out + ((size_t)b * Co + oc) * P;
-        for (int p = 0; p < P; ++p) {
-          double s = 0.0;
-          for (int k = 0; k < Cg * T; ++k) s += (double)wr[k] * (double)col[((size_t)g * Cg * T + k) * P + p];
-          orow[p] = (REAL)s + (bias ? bias[oc] : 0.f);
-        }
-      }
+    q.b = b;
+    dcn_ref_parallel_for(C, NAME(dcn_fwd_columns), &q);
+    dcn_ref_parallel_for(Co, NAME(dcn_fwd_product), &q);
   }
   free(col);
   return 0;

@@ -54,6 +54,24 @@ def test_world_size_mismatch_is_an_error():
 
 
 @pytest.mark.gpu
+def test_four_rank_rehearsal_over_gloo():
+    """The N = 4 control flow on this one-GPU box: four ranks share the GPU (within the box's process limit), gloo
+    carries the barriers and the single all_gather; every rank checks c1, nobody runs the full-size oracle clip."""
+    import json
+    from conftest import clean_process_run
+    env = dict(os.environ, CDFO_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--batch", "1", "--steps", "1", "--warmup", "1",
+           "--height", "64", "--width", "64", "--no-extra-modes", "--no-cpu-baseline", "--no-full-size-parity"]
+    rc, out, err = clean_process_run(cmd, env=env, cwd=ROOT, timeout=900)
+    assert rc == 0, (rc, out[-2000:], err[-4000:])
+    res = json.loads([ln for ln in out.splitlines() if ln.startswith("{")][-1])
+    assert res["n_gpus"] == 4 and res["world"] == 4 and res["backend"] == "gloo" and [r["rank"] for r in res["ranks"]] == [0, 1, 2, 3]
+    assert res["parity"]["verified"] and len(res["parity"]["per_rank_max_abs"]) == 4
+
+
+@pytest.mark.gpu
 def test_two_rank_bench_line_reports_every_rank():
     """`python bench.py --gpus 2` as a fresh program (its launcher path: the parent starts the ranks before any GPU call), ranks
     sharing this box's GPU with the all_gather over gloo (CDFO_BENCH_BACKEND=gloo; the measured configuration is RCCL, one GPU

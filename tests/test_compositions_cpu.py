@@ -72,3 +72,13 @@ def test_stride_two_convolution_as_tap_masked_convolution_over_space_to_depth():
     got = F.conv2d(s2d, ws.view(5, 4 * Cc, 3, 3), b, padding=1)
     assert got.shape == ref.shape
     assert (got - ref).abs().max().item() <= 1e-10
+
+
+def test_offset_head_fallback_selection_by_frame_size():
+    """the weights-stationary offset head addresses one image's offset planes with 32-bit offsets; a 1920x1080 frame at
+    dg = 16 (third = 144) exceeds them and must fall through to the tiled head instead of raising CDFO_EINVAL."""
+    from cdfo_amd import kernels as K
+    assert K.conv_offset_mask_ws_fits(8, 272, 480, 144)
+    assert K.conv_offset_mask_ws_fits(1, 544, 960, 144)
+    assert not K.conv_offset_mask_ws_fits(1, 1080, 1920, 144)          # 1080*1920*288*4 = 2.39e9 >= 2^31
+    assert not K.conv_offset_mask_ws_fits(64, 544, 960, 144)           # the fp16 source of the whole batch >= 2 GiB

@@ -283,6 +283,8 @@ WINO_CASES = [
     (256, 8, 200, 3, False, 0),
     (384, 20, 70, 2, True, 1),      # three 128-channel groups: the XCD's 32 workgroup slots do not divide evenly
     (256, 136, 240, 8, False, 1),   # the half-resolution launch of c3: half-empty last strip, 17-row segments
+    (256, 48, 672, 13, True, 1),    # several units per workgroup (unit transitions inside the persistent loop), odd unit count
+    (128, 44, 100, 30, False, 1),   # one 128-channel group: 256 workgroup lanes, ragged last strip, several units each
 ]
 
 

@@ -33,6 +33,7 @@ ORACLE_JOBS = {
     "c3_w2": (3, 272, 480, 1022, 2, False, 0),
     "strip": (1, 272, 960, 1004, 0, True, 0),
     "c5": (1, 544, 960, 1005, 0, True, 0),
+    "v7_c3": (3, 272, 480, 2001, 0, True, 0),        # CVSR_V7 (arch.py:4215-4367) at the size bench.py times it at
 }
 _pool = None
 _futures = {}
@@ -41,6 +42,14 @@ _futures = {}
 def _oracle_job(key):
     from oracle.cvsr_v8_ref import cvsr_v8_forward, make_inputs, make_state_dict
     B, H, W, seed, wseed, perturb, clip = ORACLE_JOBS[key]
+    if key.startswith("v7"):
+        from oracle.cvsr_v7_ref import cvsr_v7_forward, make_inputs_v7, make_state_dict_v7
+        inp = make_inputs_v7(B, H, W, seed)
+        one = {k: (v[clip:clip + 1] if k != "gumbel_u" else [u[clip:clip + 1] for u in v]) for k, v in inp.items()}
+        del inp
+        with torch.no_grad():
+            return cvsr_v7_forward(make_state_dict_v7(wseed), one["x"], one["mvs0"], one["mvs1"], one["pms"], one["rms"], one["ufs"], None,
+                                   one["gumbel_u"])
     sd = make_state_dict(wseed, perturb=perturb)
     inp = make_inputs(B, H, W, seed, pad_rows={272: 2, 544: 4}.get(H, 0))
     one = {k: (v[clip:clip + 1] if k != "gumbel_u" else [u[clip:clip + 1] for u in v]) for k, v in inp.items()}
@@ -56,7 +65,7 @@ def prefetch():
         return
     torch.set_num_threads(max(2, (os.cpu_count() or 4) // 2) if torch.get_num_threads() > 4 else torch.get_num_threads())
     _pool = cf.ThreadPoolExecutor(max_workers=2, thread_name_prefix="oracle")
-    for key in ("c5", "c3", "c2", "c3_w1", "c3_w2", "strip"):        # the long one (c5: minutes) first on one worker, the others on the second
+    for key in ("c5", "c3", "c2", "c3_w1", "c3_w2", "strip", "v7_c3"):        # the long one (c5: minutes) first on one worker, the others on the second
         _futures[key] = _pool.submit(_oracle_job, key)
 
 
@@ -270,3 +279,28 @@ def test_fp16_margin_on_trained_like_and_rescaled_weights():
             assert rng is not None and not rng["fallback"]
         assert e <= TOL and el <= TOL, name
     print(f"fp16 margin: worst fp16x2 case {worst:.2e} of the {TOL:.0e} bound")
+
+
+@pytest.mark.parametrize("precision", ["fp16x2", "bf16x3"])
+def test_v7_c3_batch_against_the_oracle(precision):
+    """CVSR_V7 (arch/SIDECVSR_our.py:4215-4367) where bench.py times it: clip 0 of a 3-clip batch of 272x480 in both 16-bit modes against
+    oracle/cvsr_v7_ref.py (whose DCN is the C restatement oracle/dcn_ref.c) run on that clip alone; bound 1e-3 on `out` and `L1_fea`.
+    The small goldens (test_gpu_cvsr_v7.py) cannot see an index error that only shows above one tile per level."""
+    from arch.SIDECVSR_our import CVSR_V7
+    from oracle.cvsr_v7_ref import make_inputs_v7, make_state_dict_v7
+    B, H, W, seed, wseed, _, clip = ORACLE_JOBS["v7_c3"]
+    m = CVSR_V7()
+    m.load_state_dict(make_state_dict_v7(wseed), strict=True)
+    m = m.cuda().eval()
+    m.precision = precision
+    inp = make_inputs_v7(B, H, W, seed)
+    dev = {k: v.cuda() for k, v in inp.items() if k != "gumbel_u"}
+    with torch.no_grad():
+        out, L1 = m(dev["x"], dev["mvs0"], dev["mvs1"], dev["pms"], dev["rms"], dev["ufs"], gumbel_uniform=[u.cuda() for u in inp["gumbel_u"]])
+    torch.cuda.synchronize()
+    ref, L1_ref = oracle_reference("v7_c3")
+    e_out = (out[clip:clip + 1].cpu() - ref).abs().max().item()
+    e_l1 = (L1[7 * clip:7 * clip + 7].cpu() - L1_ref).abs().max().item()
+    print(f"CVSR_V7 B={B} {H}x{W} clip {clip}, {precision} vs CPU oracle: out {e_out:.2e}  L1_fea {e_l1:.2e}")
+    assert out.shape == (B, 1, 4 * H, 4 * W) and L1.shape == (7 * B, 64, H, W)
+    assert e_out <= TOL and e_l1 <= TOL

@@ -73,6 +73,50 @@ def test_fp16_range_guard(log2s):
         assert not (bad <= 1e-5)       # NaN / inf / visibly wrong: the scaling really leaves fp16's range
 
 
+def test_fp16_range_guard_deferred_result_check():
+    """Round 5: the result's non-finite probe is read at the start of the NEXT forward (or by finish_range_guard / last_range), not
+    behind a host sync at the end of this one.  Scenario the trunk-input window cannot see: ONE Block_ body re-parametrised by 2^24
+    (body.0 weight and bias x 2^24, body.2 weight x 2^-24: the same function, LeakyReLU is positively homogeneous) -- its fp16
+    weights and 256-channel fp16 intermediate overflow while max |trunk input| stays in the window.  The forward returns non-finite values; settling the
+    guard must warn, recompute in bf16x3 INTO the returned tensors and report the fallback; the next forwards are guarded the same way."""
+    from arch.SIDECVSR_our import CVSR_V8
+    from oracle.cvsr_v8_ref import cvsr_v8_forward, make_inputs, make_state_dict
+    sd = make_state_dict(3)
+    inp = make_inputs(1, 16, 24, 78)
+    with torch.no_grad():
+        ref, L1_ref = cvsr_v8_forward(sd, inp["x"], None, inp["mvs1"], inp["pms"], inp["rms"], inp["ufs"], None, inp["gumbel_u"])
+    bad = {k: v.clone() for k, v in sd.items()}
+    p = "recon_trunk.body.2.body.1.body."
+    bad[p + "0.weight"] *= 2.0 ** 24
+    bad[p + "0.bias"] *= 2.0 ** 24
+    bad[p + "2.weight"] *= 2.0 ** -24
+    m = CVSR_V8()
+    m.load_state_dict(bad, strict=True)
+    m = m.cuda().eval()
+    d = {k: v.cuda() for k, v in inp.items() if k != "gumbel_u"}
+    noise = [u.cuda() for u in inp["gumbel_u"]]
+    with torch.no_grad():
+        out, L1 = m(d["x"], d["mvs0"], d["mvs1"], d["pms"], d["rms"], d["ufs"], gumbel_uniform=noise)
+    assert m.__dict__.get("_pending_guard") is not None                     # the trunk-input window saw nothing: the result check is pending
+    with pytest.warns(UserWarning, match="fp16 range"):
+        m.finish_range_guard()
+    torch.cuda.synchronize()
+    assert m.last_range["fallback"] and m.last_range["nonfinite"]
+    err, err_l1 = (out.cpu() - ref).abs().max().item(), (L1.cpu() - L1_ref).abs().max().item()
+    print(f"deferred guard: repaired in place, out {err:.2e} L1_fea {err_l1:.2e}; {m.last_range}")
+    assert err <= TOL and err_l1 <= TOL
+    # the second forward settles nothing (no pending check) and is itself caught when ITS check is settled through last_range
+    with torch.no_grad():
+        out2, _ = m(d["x"], d["mvs0"], d["mvs1"], d["pms"], d["rms"], d["ufs"], gumbel_uniform=noise)
+    assert m.last_range["fallback"]
+    assert (out2.cpu() - ref).abs().max().item() <= TOL
+    # range_guard = "sync": the check-before-return behaviour of rounds 2-4
+    m.range_guard = "sync"
+    with torch.no_grad():
+        out3, _ = m(d["x"], d["mvs0"], d["mvs1"], d["pms"], d["rms"], d["ufs"], gumbel_uniform=noise)
+    assert m.__dict__.get("_pending_guard") is None and (out3.cpu() - ref).abs().max().item() <= TOL
+
+
 class _nullcontext:
     def __enter__(self):
         return None

@@ -624,6 +624,22 @@ def cvsr_v7_line(device, d, H, W, B, steps=2):
         if prec == "fp16x2":
             got0 = o[0:1].cpu()
         del o
+    # the same fp16x2 forward replayed from a HIP graph (CVSR_V7.capture): ~1 000 launches per forward are partly launch-bound
+    try:
+        with torch.no_grad():
+            g = m.capture(d["x"], -d["mvs1"], d["mvs1"], d["pms"], d["rms"], d["ufs"], gumbel_uniform=noise)
+            g.replay()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                g.replay()
+            torch.cuda.synchronize()
+        gms = (time.perf_counter() - t0) / steps * 1e3
+        out["fp16x2_hip_graph"] = {"ms_per_forward": round(gms, 2), "frames_per_s": round(B / gms * 1e3, 2)}
+        del g
+    except Exception as e:
+        out["fp16x2_hip_graph"] = {"error": repr(e)[:200]}
+    torch.cuda.empty_cache()
     # dominant kernel family of the fp16x2 forward: one more forward with one HIP-event pair per launch
     nk = lib.cdfo_prof_kid_count()
     _lib.check(lib.cdfo_prof_begin(8000), "cdfo_prof_begin")
@@ -657,7 +673,7 @@ def cvsr_v7_line(device, d, H, W, B, steps=2):
     t0 = time.perf_counter()
     with torch.no_grad():
         ref, _ = cvsr_v7_forward(sd, d["x"][0:1].cpu(), -d["mvs1"][0:1].cpu(), d["mvs1"][0:1].cpu(), d["pms"][0:1].cpu(), d["rms"][0:1].cpu(),
-                                 d["ufs"][0:1].cpu(), [u[0:1].cpu() for u in noise])
+                                 d["ufs"][0:1].cpu(), None, [u[0:1].cpu() for u in noise])
     e = (got0 - ref).abs().max().item()
     res["parity"] = {"config": f"clip 0 of the fp16x2 batch ({H}x{W}) vs oracle/cvsr_v7_ref.py (C DCN oracle)", "max_abs": e, "bound": PARITY_BOUND,
                      "verified": bool(e <= PARITY_BOUND), "oracle_seconds": round(time.perf_counter() - t0, 1)}

@@ -119,7 +119,9 @@ def conv_wgrad(S: torch.Tensor, L: torch.Tensor, ks: int, stride: int, pad: int,
     nsplit = max(1, min(N * Hs // 4 if N * Hs >= 4 else 1, 1024 // nblk if nblk < 1024 else 1, 256))
     n = int(_lib.lib().cdfo_conv_wgrad_slab_floats(A, Bc, ks, nsplit))
     slab = torch.empty(n, dtype=torch.float32, device=S.device)
-    prec = CONV_PREC if (ks == 3 and A >= 16 and Bc >= 16) else F32      # the 16-bit form where the convolutions themselves use it
+    # the 16-bit form where the convolutions themselves use it: the 3x3 convolutions (tiled split-bf16 kernel) and, since round 5, the 1x1
+    # ones (cdfo_conv1x1_bf16x3 in the forward): their exact-fp32 MFMA weight gradients were 15 ms of a 160 ms backward at 1/16 of the rate
+    prec = CONV_PREC if (ks in (1, 3) and stride == 1 and A >= 16 and Bc >= 16) else F32
     check(_lib.lib().cdfo_conv_wgrad_prec(_vp(S), S.stride(-2), A, _vp(L), L.stride(-2), Bc, N, Hs, Ws, Hl, Wl, ks, stride, pad, nsplit,
                                           _vp(slab), _vp(dw), Btot, b_off, prec, _stream()), "cdfo_conv_wgrad_prec")
 

@@ -66,13 +66,17 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(wg_args g) {
     if (yl < 0 || yl >= g.Hl) continue;
     const float* Sr = g.S + ((long long)n * g.Hs + y) * g.Ws * g.lds_;
     const float* Lr = g.L + (((long long)n * g.Hl + yl) * g.Wl + (kx - g.pad)) * g.ldl;
+    // (unconditional loads from clamped addresses, masked afterwards -- a predicated load is a branch of its own; four steps'
+    // requests leave together)
+#pragma unroll 4
     for (int x = x_lo; x < x_hi; x += 2) {
       const int xx = x + kk;
       const bool v = xx < x_hi;
-      const float* sp_ = Sr + (long long)xx * g.lds_;
-      const float* lp = Lr + (long long)xx * g.stride * g.ldl;
-      const float sa0 = (v && am0) ? sp_[a0] : 0.f, sa1 = (v && am1) ? sp_[a0 + 32] : 0.f;
-      const float lb0 = (v && bm0) ? lp[b0] : 0.f, lb1 = (v && bm1) ? lp[b0 + 32] : 0.f;
+      const float* sp_ = Sr + (long long)(v ? xx : x_lo) * g.lds_;
+      const float* lp = Lr + (long long)(v ? xx : x_lo) * g.stride * g.ldl;
+      const float t0 = sp_[am0 ? a0 : 0], t1 = sp_[am1 ? a0 + 32 : 0], u0 = lp[bm0 ? b0 : 0], u1 = lp[bm1 ? b0 + 32 : 0];
+      const float sa0 = (v && am0) ? t0 : 0.f, sa1 = (v && am1) ? t1 : 0.f;
+      const float lb0 = (v && bm0) ? u0 : 0.f, lb1 = (v && bm1) ? u1 : 0.f;
       acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(sa0, lb0, acc[0][0], 0, 0, 0);
       acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(sa0, lb1, acc[0][1], 0, 0, 0);
       acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(sa1, lb0, acc[1][0], 0, 0, 0);
@@ -133,27 +137,59 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16x3_kernel(wg_args g) {
     const int lim = g.Wl - 1 - off;
     x_hi = lim < 0 ? 0 : min(g.Ws, lim / g.stride + 1);
   }
-  for (long long row = r0 + wave; row < r1; row += 4) {
-    const int n = (int)(row / g.Hs), y = (int)(row - (long long)n * g.Hs);
-    const int yl = y * g.stride + ky - g.pad;
-    if (yl < 0 || yl >= g.Hl) continue;
-    const float* Sr = g.S + ((long long)n * g.Hs + y) * g.Ws * g.lds_;
-    const float* Lr = g.L + (((long long)n * g.Hl + yl) * g.Wl + (kx - g.pad)) * g.ldl;
-    for (int x = x_lo; x < x_hi; x += 16) {
+  // The (row, 16-pixel step) sequence of this wave, flattened, with the NEXT step's 32 operand values requested before the current
+  // step's splits and MFMAs (round 5: every step used to wait a full memory latency for its own loads -- 47 of the 160 ms of a
+  // backward at the training script's crop size went here at ~15 % of the matrix rate).
+  long long row = r0 + wave;
+  int x = x_lo;
+  const float *Sr = nullptr, *Lr = nullptr;
+  auto seek = [&]() {          // first valid (row, x) at or after the current one; false when the slice is exhausted
+    for (; row < r1; row += 4, x = x_lo) {
+      if (x >= x_hi) continue;
+      const int n = (int)(row / g.Hs), y = (int)(row - (long long)n * g.Hs);
+      const int yl = y * g.stride + ky - g.pad;
+      if (yl < 0 || yl >= g.Hl) continue;
+      Sr = g.S + ((long long)n * g.Hs + y) * g.Ws * g.lds_;
+      Lr = g.L + (((long long)n * g.Hl + yl) * g.Wl + (kx - g.pad)) * g.ldl;
+      return true;
+    }
+    return false;
+  };
+  auto fetch = [&](float (&sv)[2][8], float (&lv)[2][8]) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int xx = x + 8 * kk + j;
+      const bool v = xx < x_hi;
+      const float* sp_ = Sr + (long long)(v ? xx : x_lo) * g.lds_;
+      const float* lp = Lr + (long long)(v ? xx : x_lo) * g.stride * g.ldl;
+      // unconditional loads from clamped (valid) addresses, masked afterwards: a predicated load is a branch of its own and the 32
+      // loads of a step then leave one at a time
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const float ts = sp_[am[i] ? a0 + 32 * i : 0], tl = lp[bm[i] ? b0 + 32 * i : 0];
+        sv[i][j] = (v && am[i]) ? ts : 0.f;
+        lv[i][j] = (v && bm[i]) ? tl : 0.f;
+      }
+    }
+  };
+  float sv[2][8], lv[2][8];
+  bool have = x_lo < x_hi && seek();
+  if (have) fetch(sv, lv);
+  while (have) {
+    float sn[2][8], ln[2][8];
+    x += 16;
+    const bool more = seek();
+    if (more) fetch(sn, ln);
+    __builtin_amdgcn_sched_barrier(0);      // the requests stay ahead of this step's arithmetic (the scheduler would sink them to their uses)
+    {
       wg_bf16x8 sh[2], sl[2], lh[2], ll[2];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const int xx = x + 8 * kk + j;
-        const bool v = xx < x_hi;
-        const float* sp_ = Sr + (long long)(v ? xx : x_lo) * g.lds_;
-        const float* lp = Lr + (long long)(v ? xx : x_lo) * g.stride * g.ldl;
+      for (int j = 0; j < 8; ++j)
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-          const float sv = (v && am[i]) ? sp_[a0 + 32 * i] : 0.f, lv = (v && bm[i]) ? lp[b0 + 32 * i] : 0.f;
-          sh[i][j] = (__bf16)sv; sl[i][j] = (__bf16)(sv - (float)sh[i][j]);
-          lh[i][j] = (__bf16)lv; ll[i][j] = (__bf16)(lv - (float)lh[i][j]);
+          sh[i][j] = (__bf16)sv[i][j]; sl[i][j] = (__bf16)(sv[i][j] - (float)sh[i][j]);
+          lh[i][j] = (__bf16)lv[i][j]; ll[i][j] = (__bf16)(lv[i][j] - (float)lh[i][j]);
         }
-      }
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -163,6 +199,11 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16x3_kernel(wg_args g) {
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sh[i], lh[j], acc[i][j], 0, 0, 0);
         }
     }
+    have = more;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { sv[i][j] = sn[i][j]; lv[i][j] = ln[i][j]; }
   }
   if (wave > 0) {
 #pragma unroll

@@ -234,7 +234,7 @@ class CVSR_V7(nn.Module):
         if self.precision == "fp16x2" and b0.wh is not None and all(z.shape[1] % 4 == 0 for z in xs):
             # the body on CVSR_V8's Block_ kernels: 64->256 weights-stationary, 256->64 on the LDS-DMA ring kernel, fp16
             # chunk-planar tensors in between, single-pass fp16 MFMA with fp32 accumulation
-            res = [K.conv_ring(K.conv3x3_ws(K.to_cp16(z), b0, act=K.ACT_LRELU), b2) for z in xs]
+            res = [K.conv_ring(K.conv3x3_body0(K.to_cp16(z), b0, act=K.ACT_LRELU), b2) for z in xs]
         else:
             res = [self._conv(self._conv(z, b0, pad=1, act=K.ACT_LRELU), b2, pad=1) for z in xs]
         outs = []
@@ -268,6 +268,12 @@ class CVSR_V7(nn.Module):
             raise NotImplementedError("CVSR_V7 (HIP): CPU tensors are not supported; there is no CPU fallback")
         with K.on_device(x):     # the operands' device becomes the current one: streams, per-device caches of the library
             return self._forward(x, mvs0, mvs1, pms, rms, ufs, pre_L1_fea, gumbel_uniform)
+
+    def capture(self, x, mvs0, mvs1, pms, rms, ufs, pre_L1_fea=None, gumbel_uniform=None):
+        """One inference forward at these operands' shapes as a HIP graph (``cdfo_amd.graph.CapturedForward``, as ``CVSR_V8.capture``):
+        ~1 000 launches on up to three streams replayed from one ``hipGraphLaunch``.  The model has no fp16 range guard to settle."""
+        from .graph import CapturedForward
+        return CapturedForward(self, x, mvs0, mvs1, pms, rms, ufs, pre_L1_fea, gumbel_uniform, check_range=False)
 
     def _forward(self, x, mvs0, mvs1, pms, rms, ufs, pre_L1_fea=None, gumbel_uniform=None):
         B, N, C, H, W = x.shape

@@ -472,10 +472,7 @@ class CVSR_V8(nn.Module):
             # kernel; the 64- and 256-channel tensors between them are fp16 chunk-planar [B,C/16,H,W,16].  Same
             # arithmetic as the single-pass fp16 mode of the tiled kernel: fp16 operands, fp32 accumulation
             # body[0]: the row-streaming Winograd F(2,3) kernel (2/3 of the direct product's MFMAs) unless CDFO_WINO=0
-            if b0.ww is not None and K.wino_enabled() and x.shape[2] % 4 == 0 and x.shape[1] * x.shape[2] * 8 * b0.Cout < (1 << 31):
-                c1 = lambda src, **kw: K.conv3x3_wino(src, b0, act=K.ACT_LRELU, **kw)
-            else:
-                c1 = lambda src, **kw: K.conv3x3_ws(src, b0, act=K.ACT_LRELU, **kw)
+            c1 = lambda src, **kw: K.conv3x3_body0(src, b0, act=K.ACT_LRELU, **kw)
             # sources of the x2 and x1/2 branches (and, for a group's first block, of the 1x branch), one read of x
             if x16 is None:
                 u16, d16, x16 = K.block_prologue(x, w[p + "pro"], want_x16=True)
@@ -604,13 +601,13 @@ class CVSR_V8(nn.Module):
                 raise RuntimeError("CVSR_V8 (HIP): the fp16 range guard reads probes back and cannot be captured; use model.capture(), "
                                    "which checks an eager forward first and captures with the guard off")
             # fp16 range guard: the fp16x2 mode keeps the trunk's tensors (and the alignment's residual blocks) in fp16.  Outside
-            # fp16's comfortable range -- max |trunk input| not in [2^-6, 2^11], or a NaN / infinity in the trunk input or in the
-            # result (what an overflowed fp16 store turns into) -- the forward is repeated in the split-bf16 mode (fp32 exponent range,
+            # fp16's comfortable range -- max |trunk input| not in [2^-6, 2^11], or a NaN / infinity in the trunk's input or output
+            # (what an overflowed fp16 store turns into) -- the forward is repeated in the split-bf16 mode (fp32 exponent range,
             # fp32-grade products).  The two probes are read back WITHOUT draining the GPU (round 5; the synchronous 16-byte readback
             # of rounds 2-4 left a ~0.7 ms bubble in front of every next forward):
             #   * the trunk-input probe is copied to pinned host memory right behind the temporal fusion, i.e. with the whole trunk
             #     (half of the forward) still queued behind it; waiting for THAT copy before returning costs no idle time;
-            #   * the result's non-finite probe is copied behind the last kernel and checked at the start of the NEXT forward (or by
+            #   * the trunk-output probe is copied behind the last kernel and checked at the start of the NEXT forward (or by
             #     finish_range_guard() / model.last_range): if it fires, the forward is recomputed in bf16x3 INTO the tensors that
             #     were returned.  range_guard = "sync" restores the check-before-return behaviour.
             self._probe = torch.zeros(4, dtype=torch.int32, device=x.device)
@@ -864,6 +861,11 @@ class CVSR_V8(nn.Module):
         raw = w["raw"]
         ctr, P = self.center, H * W
         t = self._trunk(w, fused)
+        if self._probe is not None:
+            # the second probe of the fp16 range guard sits on the trunk's OUTPUT (round 5; rounds 2-4 probed the final image): the
+            # up-sampler's fused tail turns a non-finite trunk result into finite garbage (its block scale comes from an integer maximum of
+            # bit patterns), so the image itself can look healthy when a Block_'s fp16 intermediate has overflowed
+            K.range_probe(t, self._probe[2:4])
         if self.debug_taps is not None:
             self.debug_taps.update(L1_fea=L1, fused=fused, trunk=t)
         t = self._conv(t, w["upconv1"], act=K.ACT_LRELU)
@@ -872,8 +874,6 @@ class CVSR_V8(nn.Module):
             out = K.conv_last(t, raw["conv_last.weight"], raw["conv_last.bias"], x[:, ctr], N * P)
         else:   # upconv2 writes conv_last's nine per-tap channel sums instead of the 64-channel HR map
             out = K.upconv_last(t, w["upconv2"], raw["conv_last.weight"], raw["conv_last.bias"], x[:, ctr], N * P)
-        if self._probe is not None:
-            K.range_probe(out, self._probe[2:4])
         return out
 
     def _neighbour_group(self, w, raw, Lf, idxs, xcG, ufs, rms, mvs1, noise, draw0, B, H, W, P, N, keep):

@@ -61,8 +61,11 @@ class CapturedForward:
                 raise RuntimeError("CapturedForward: the example's activations leave the fp16 range (the eager forward fell back to "
                                    "bf16x3); a captured forward has no range guard -- set model.precision = 'bf16x3' and capture again")
         cur.wait_stream(side)
-        if self.draws_noise:
-            model.refresh_noise_key(self.dev)
+        # CVSR_V8 draws its noise in-kernel from a device-side Philox key; CVSR_V7 draws with torch.rand, whose graph-safe generator
+        # state torch advances per replay by itself
+        self._refresh = getattr(model, "refresh_noise_key", None) if self.draws_noise else None
+        if self._refresh is not None:
+            self._refresh(self.dev)
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph), torch.no_grad():
             self.out, self.L1_fea = call(guard=False)
@@ -84,8 +87,8 @@ class CapturedForward:
 
     def replay(self):
         """One forward on whatever the input buffers hold.  Returns the graph-owned (out, L1_fea)."""
-        if self.draws_noise:
-            self.model.refresh_noise_key(self.dev)
+        if self._refresh is not None:
+            self._refresh(self.dev)
         self.graph.replay()
         return self.out, self.L1_fea
 

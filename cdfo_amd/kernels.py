@@ -379,6 +379,15 @@ def conv3x3_wino(src: torch.Tensor, pc: PackedConv, *, act: int = ACT_NONE, s2d:
     return out
 
 
+def conv3x3_body0(src: torch.Tensor, pc: PackedConv, *, act: int = ACT_NONE, s2d: bool = False) -> torch.Tensor:
+    """Block_.body[0]-shaped convolution (fp16 chunk-planar in and out): the Winograd F(2,3) kernel where it applies (Cout % 128 == 0,
+    even width, one image of source / result below 2 GiB, CDFO_WINO != 0), the direct weights-stationary kernel otherwise."""
+    _, _, H, W, _ = src.shape
+    if pc.ww is not None and wino_enabled() and W % 2 == 0 and (not s2d or H % 2 == 0) and H * W * 2 * pc.Cout < (1 << 31):
+        return conv3x3_wino(src, pc, act=act, s2d=s2d)
+    return conv3x3_ws(src, pc, act=act, s2d=s2d)
+
+
 def conv_offset_mask_ws_fits(B: int, H: int, W: int, third: int) -> bool:
     """The 32-bit addressing limits of cdfo_conv3x3_c64_ws_offmask: the whole fp16 source and one image's offset planes below 2 GiB."""
     return 4 * H * W * 32 * B < (1 << 31) and H * W * 2 * third * 4 < (1 << 31)

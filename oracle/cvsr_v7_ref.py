@@ -262,6 +262,9 @@ def make_inputs_v7(B: int, H: int, W: int, seed: int, layout: str = "b1n"):
         for _ in range(12):
             u = rs.random_sample((B, NF, H >> lv, W >> lv)).astype(np.float32)
             u[u == 0] = 0.5
+            # float64 draws just below 1 round to 1.0f (about 3e-8 of them: a dozen per clip at 272x480): -log(-log 1) = +inf and the
+            # soft Gumbel softmax of RDAB turns into NaN -- torch.rand_like, what the reference draws with, never returns 1
+            u[u >= 1.0] = 0.5
             gum.append(torch.from_numpy(u))
     d["gumbel_u"] = gum
     return d

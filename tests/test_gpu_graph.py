@@ -90,3 +90,28 @@ def test_capture_is_the_inference_schedule_and_refuses_out_of_range_examples():
     with torch.no_grad():
         want, _ = m(*args, gumbel_uniform=n)
     assert torch.equal(cap.replay()[0], want)
+
+
+def test_v7_replay_with_injected_noise_matches_eager():
+    """`CVSR_V7.capture` (round 5): the ~1 000 launches of a V7 forward (three pyramid levels x twelve neighbour pipelines on side
+    streams) replayed from one HIP graph give the eager forward's result on the captured and on new operands."""
+    from arch.SIDECVSR_our import CVSR_V7
+    from oracle.cvsr_v7_ref import make_inputs_v7, make_state_dict_v7
+    m = CVSR_V7()
+    m.load_state_dict(make_state_dict_v7(5), strict=True)
+    m = m.cuda().eval()
+
+    def inputs(seed):
+        a = make_inputs_v7(2, 16, 24, seed)
+        return {k: v.cuda() for k, v in a.items() if k != "gumbel_u"}, [u.cuda() for u in a["gumbel_u"]]
+
+    d0, n0 = inputs(600)
+    d1, n1 = inputs(601)
+    with torch.no_grad():
+        cap = m.capture(d0["x"], d0["mvs0"], d0["mvs1"], d0["pms"], d0["rms"], d0["ufs"], gumbel_uniform=n0)
+        for d, n in ((d0, n0), (d1, n1)):
+            want, want_l1 = m(d["x"], d["mvs0"], d["mvs1"], d["pms"], d["rms"], d["ufs"], gumbel_uniform=n)
+            got, got_l1 = cap(d["x"], d["mvs0"], d["mvs1"], d["pms"], d["rms"], d["ufs"], gumbel_uniform=n)
+            torch.cuda.synchronize()
+            # the attention Gram sums of the alignment are atomics-free and fixed-order: the replay is the eager arithmetic
+            assert (got - want).abs().max().item() <= 1e-6 and (got_l1 - want_l1).abs().max().item() <= 1e-6

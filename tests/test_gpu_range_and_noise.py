@@ -77,8 +77,8 @@ def test_fp16_range_guard_deferred_result_check():
     """Round 5: the result's non-finite probe is read at the start of the NEXT forward (or by finish_range_guard / last_range), not
     behind a host sync at the end of this one.  Scenario the trunk-input window cannot see: ONE Block_ body re-parametrised by 2^24
     (body.0 weight and bias x 2^24, body.2 weight x 2^-24: the same function, LeakyReLU is positively homogeneous) -- its fp16
-    weights and 256-channel fp16 intermediate overflow while max |trunk input| stays in the window.  The forward returns non-finite values; settling the
-    guard must warn, recompute in bf16x3 INTO the returned tensors and report the fallback; the next forwards are guarded the same way."""
+    weights and 256-channel fp16 intermediate overflow while max |trunk input| stays in the window.  The forward returns garbage (the trunk's output is non-finite; the up-sampler's tail turns that
+    into finite values, which is why the guard probes the trunk and not the image); settling the guard must warn, recompute in bf16x3 INTO the returned tensors and report the fallback; the next forwards are guarded the same way."""
     from arch.SIDECVSR_our import CVSR_V8
     from oracle.cvsr_v8_ref import cvsr_v8_forward, make_inputs, make_state_dict
     sd = make_state_dict(3)

@@ -1,6 +1,6 @@
 # Developer script (GPU box): full GPU suite, default bench line, smoke, and the 2-rank rehearsal of bench.py's launcher path
 set -o pipefail
-R=${R:-r04}
+R=${R:-r05}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT && O=gpurun_out/final && mkdir -p $O
 python3 -m pytest tests -x -q -m gpu > $O/gputests.log 2>&1; rc=$?; tail -3 $O/gputests.log
 if [ $rc -ne 0 ]; then exit $rc; fi

@@ -122,6 +122,8 @@ __global__ __launch_bounds__(WN_THREADS) void conv3x3_c64_wino_kernel(wino_args 
   const unsigned out_img_bytes = (unsigned)nck * (unsigned)(H * W) * 32u;
   const unsigned lane16 = (unsigned)lane * 16u;
   const bool grp_b = wave >= 4;        // the SIMD partners of waves 0-3 (see STAGGER below)
+  if ((DBG & 128) && grp_b) __builtin_amdgcn_s_setprio(1);      // experiment: static priority for the second-dispatched half
+  if ((DBG & 256) && !grp_b) __builtin_amdgcn_s_setprio(1);     // experiment: ... or for the first half
 
   auto unit_coords = [&](int ord, int& b, int& x0, int& y0, int& y1) {
     const int u = (ord * npairs + pair) * 8 + xcd;
@@ -484,6 +486,8 @@ extern "C" int cdfo_conv3x3_c64_wino_dbg(const void* src_cp16, int B, int H, int
     case 32: rc = wino_launch<32>(a, nslots * 8, st); break;
     case 64: rc = wino_launch<64>(a, nslots * 8, st); break;
     case 96: rc = wino_launch<96>(a, nslots * 8, st); break;
+    case 128: rc = wino_launch<128>(a, nslots * 8, st); break;
+    case 256: rc = wino_launch<256>(a, nslots * 8, st); break;
     default: return CDFO_EINVAL;
   }
   if (rc) return rc;

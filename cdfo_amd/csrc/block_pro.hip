@@ -35,7 +35,9 @@ struct bp_args {
   int B, H, W;
   const unsigned short* w;      // bf16 [hi|lo][4][2][128][8]: rows 0-63 = up.0, 64-127 = down.0; k = 16 s + 8 h + j
   const float* bias;            // [128]
-  _Float16* u16;                // [B][4][2H][2W][16]
+  _Float16* u16;                // [B][4][2H][2W][16]   (NULL when t16 is given)
+  _Float16* t16;                // optional [B][4][H][W][16]: up.0(x) itself at the block's resolution -- the Winograd kernel's
+                                // on-the-fly x2 form interpolates it while it builds its transformed inputs (conv3x3_wino.hip, UP)
   _Float16* d16;                // [B][4][H/2][W/2][16]
   _Float16* x16;                // optional [B][4][H][W][16]: fp16 chunk-planar copy of x itself (the 1x branch's source)
 };
@@ -125,7 +127,20 @@ __global__ __launch_bounds__(BP_THREADS, 4) void block_pro_kernel(bp_args a) {
           sY[(wave * 32 + (e & 3) + 8 * (e >> 2) + 4 * h) * BP_YP + r] = acc[e] + bn;
       }
       __syncthreads();
-      if (nb == 0) {
+      if (nb == 0 && a.t16) {
+        // y = up.0(x) leaves as it is (fp16 chunk-planar, the tile's own 6 x 30 pixels): the consumer interpolates
+        for (int i = tid; i < BP_TR * BP_TC * 8; i += BP_THREADS) {
+          const int q = i & 7, px = (i >> 3) % BP_TC, py = (i >> 3) / BP_TC;
+          const int cq = nt * 8 + q;
+          const int gy = oy0 + py, gx = ox0 + px;
+          if (gy >= H || gx >= W) continue;
+          const f32x4 v = *reinterpret_cast<const f32x4*>(sY + ((1 + py) * 32 + 1 + px) * BP_YP + q * 4);
+          bp_f16x4 hv;
+#pragma unroll
+          for (int k = 0; k < 4; ++k) hv[k] = (_Float16)v[k];
+          *reinterpret_cast<bp_f16x4*>(a.t16 + ((((long long)b * 4 + (cq >> 2)) * H + gy) * W + gx) * 16 + (cq & 3) * 4) = hv;
+        }
+      } else if (nb == 0) {
         // bilinear x2: thread = 4 channels (quad q of this half) of the 2x2 output block (2Q-1..2Q, 2P-1..2P) fed by source
         // rows Q-1..Q, columns P-1..P (halo-local rows qq..qq+1, columns pp..pp+1; the clamped replicas are already in the
         // tile).  7 x 31 blocks cover the tile's 12 x 60 outputs (+ the shared edge with the neighbouring tiles, written by
@@ -181,11 +196,11 @@ __global__ __launch_bounds__(BP_THREADS, 4) void block_pro_kernel(bp_args a) {
 
 }  // namespace
 
-extern "C" int cdfo_block_prologue(const float* x, int ldx, int B, int H, int W, const void* w_bf16, const float* bias128,
-                                   void* u16, void* d16, void* x16, void* stream) {
-  if (B <= 0 || H <= 0 || W <= 0 || (H & 1) || (W & 1) || ldx % 4 || ldx < 64) return CDFO_EINVAL;
+extern "C" int cdfo_block_prologue2(const float* x, int ldx, int B, int H, int W, const void* w_bf16, const float* bias128,
+                                    void* u16, void* t16, void* d16, void* x16, void* stream) {
+  if (B <= 0 || H <= 0 || W <= 0 || (H & 1) || (W & 1) || ldx % 4 || ldx < 64 || (!u16 == !t16)) return CDFO_EINVAL;
   if ((long long)B * H * W * 4 >= (1ll << 31)) return CDFO_EINVAL;
-  if (!aligned16(x) || !aligned16(w_bf16) || !aligned16(u16) || !aligned16(d16) || !aligned16(x16) || !bias128) return CDFO_EALIGN;
+  if (!aligned16(x) || !aligned16(w_bf16) || !aligned16(u16) || !aligned16(t16) || !aligned16(d16) || !aligned16(x16) || !bias128) return CDFO_EALIGN;
   hipStream_t st = static_cast<hipStream_t>(stream);
   static CdfoAttrOnce once;
   const hipError_t e = cdfo_set_max_lds(once, reinterpret_cast<const void*>(block_pro_kernel), BP_LDS);
@@ -197,10 +212,16 @@ extern "C" int cdfo_block_prologue(const float* x, int ldx, int B, int H, int W,
   bp_args a;
   a.x = x; a.ldx = ldx; a.B = B; a.H = H; a.W = W;
   a.w = static_cast<const unsigned short*>(w_bf16); a.bias = bias128;
-  a.u16 = static_cast<_Float16*>(u16); a.d16 = static_cast<_Float16*>(d16); a.x16 = static_cast<_Float16*>(x16);
+  a.u16 = static_cast<_Float16*>(u16); a.t16 = static_cast<_Float16*>(t16); a.d16 = static_cast<_Float16*>(d16);
+  a.x16 = static_cast<_Float16*>(x16);
   const double px = (double)B * H * W;
-  CdfoProfScope prof(st, KID_RESAMPLE, 2.0 * px * 128 * 64, px * (4.0 * 64 + 2.0 * 64 * 4 + 2.0 * 16));
+  CdfoProfScope prof(st, KID_RESAMPLE, 2.0 * px * 128 * 64, px * (4.0 * 64 + 2.0 * 64 * (u16 ? 4 : 1) + 2.0 * 16));
   hipLaunchKernelGGL(block_pro_kernel, dim3(grid), dim3(BP_THREADS), BP_LDS, st, a);
   CDFO_LAUNCH_CHECK();
   return 0;
+}
+
+extern "C" int cdfo_block_prologue(const float* x, int ldx, int B, int H, int W, const void* w_bf16, const float* bias128,
+                                   void* u16, void* d16, void* x16, void* stream) {
+  return cdfo_block_prologue2(x, ldx, B, H, W, w_bf16, bias128, u16, nullptr, d16, x16, stream);
 }

@@ -46,6 +46,9 @@ constexpr int WN_VROW = 8 * 1024;                // V of one input row: fragment
 constexpr int WN_SLOT = WN_ROWS * WN_VROW;
 constexpr int WN_NSLOT = 3;                      // V ring: batch n lives in slot n % 3 (see the barrier's place in `batch`)
 constexpr int WN_LDS = WN_NSLOT * WN_SLOT;       // 72 KiB
+// UP (on-the-fly bilinear x2 of a low-resolution source): the three low-resolution rows a batch interpolates from, staged for the
+// workgroup as 432 16-byte units [row 3][plane 4][pixel 18][half 2] of a 512-unit slot; two slots behind the V ring
+constexpr int WN_RAW_SLOT = 8192, WN_RAW_OFF = WN_LDS, WN_LDS_UP = WN_LDS + 2 * WN_RAW_SLOT;
 
 struct wino_args {
   const unsigned char* src; int B, H, W;
@@ -63,7 +66,16 @@ typedef int i32x4 __attribute__((ext_vector_type(4)));
 // that every path into a batch has issued the SAME sequence [row-0 store, six loads, row-1 store, row-2 store] before it.
 // DBG (developer ablations, wrong results): 1 = no MFMAs, 2 = no global loads, 4 = no stores, 8 = no epilogue arithmetic,
 // 16 = no barrier / V exchange wait, 32 / 64 = loads / stores with lane-contiguous addresses (one cache line per four lanes)
-template <bool S2D, int DBG>
+// UP: a.src is the LOW-resolution tensor [B][4][H/2][W/2][16] and the convolution runs on its bilinear x2 (align_corners = False:
+// out[2i] = 1/4 in[i-1] + 3/4 in[i], out[2i+1] = 3/4 in[i] + 1/4 in[i+1], clamped taps) WITHOUT that image ever existing.  The
+// transformed inputs are linear in the low-resolution rows:  V(y) = 3/4 Vh(i) + 1/4 Vh(i -+ 1)  with, per column pair t (= low-
+// resolution column t),  Vh_0 = 3/4 L[t-1] - 1/2 L[t] - 1/4 L[t+1],  Vh_1 = 1/4 L[t-1] + 3/2 L[t] + 1/4 L[t+1],
+// Vh_2 = 1/4 (L[t+1] - L[t-1]),  Vh_3 = 1/4 L[t-1] + 1/2 L[t] - 3/4 L[t+1]  (clamped columns); two exceptions where the convolution's
+// ZERO padding of the x2 image meets the interpolation's clamping: Vh_0 = -(3/4 L[0] + 1/4 L[1]) at t = 0 and Vh_3 = 1/4 L[t-1] +
+// 3/4 L[t] at the last column.  Rows -1 and H of the x2 image are zero.  Data path: every lane fetches ONE 16-byte unit of the
+// batch's three low-resolution rows (18 pixels x 4 planes: contiguous 576-byte runs, against 16 bytes of every second record in the
+// plain form), the rows go through a two-slot LDS stage, wave (xi, K half) reads its three shifted fragments per row from there.
+template <bool S2D, int DBG, bool UP = false>
 __global__ __launch_bounds__(WN_THREADS) void conv3x3_c64_wino_kernel(wino_args a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, t16 = lane & 15, kg = lane >> 4;
@@ -116,7 +128,7 @@ __global__ __launch_bounds__(WN_THREADS) void conv3x3_c64_wino_kernel(wino_args 
   const int jA = xi_p == 0 ? 0 : (xi_p == 2 ? 2 : 1), jB = xi_p == 0 ? 2 : (xi_p == 1 ? 2 : (xi_p == 2 ? 1 : 3));
   const _Float16 vsg = xi_p == 1 ? (_Float16)1.f : (_Float16)-1.f;
   const f16x8_t vsgn = {vsg, vsg, vsg, vsg, vsg, vsg, vsg, vsg};
-  const unsigned img_bytes = (unsigned)(H * W) * 128u;                   // 4 planes x 32 bytes per pixel
+  const unsigned img_bytes = UP ? (unsigned)((H >> 1) * (W >> 1)) * 128u : (unsigned)(H * W) * 128u;      // 4 planes x 32 bytes per pixel
   const unsigned lane_src = (unsigned)(sc_p * 2 + (kg >> 1)) * (unsigned)(H * W) * 32u + (unsigned)(kg & 1) * 16u;
   const int nck = a.Cout >> 4;
   const unsigned out_img_bytes = (unsigned)nck * (unsigned)(H * W) * 32u;
@@ -168,6 +180,59 @@ __global__ __launch_bounds__(WN_THREADS) void conv3x3_c64_wino_kernel(wino_args 
       const f16x8_t va = __builtin_bit_cast(f16x8_t, raw[j][0]), vb = __builtin_bit_cast(f16x8_t, raw[j][1]);
       *reinterpret_cast<f16x8_t*>(dst + j * WN_VROW) = __builtin_elementwise_fma(vb, vsgn, va);      // one rounding: exact sum, rounded
     }
+  };
+
+  // ---- UP: staging role of this lane (unit su of a raw slot), the staged load of a batch, and the V fragments formed from a slot
+  const int Hl = H >> 1, Wl = W >> 1;
+  const int su = wave * 64 + lane;
+  const int s_px = (su >> 1) % 18, s_pl = ((su >> 1) / 18) & 3, s_r = (su >> 1) / 72;
+  const unsigned s_const = (unsigned)s_pl * (unsigned)(Hl * Wl) * 32u + (unsigned)(su & 1) * 16u;
+  u32x4 sreg = {0u, 0u, 0u, 0u};      // the staged unit in flight (requested one batch before it is written to LDS)
+  auto stage_load = [&](int b, int x0, int i0) {
+    const int base = (i0 - 1) >> 1;       // rows base .. base + 2 of the low-resolution image (clamped: the interpolation's edge rule)
+    const int row = min(max(base + s_r, 0), Hl - 1), col = min(max((x0 >> 1) - 1 + s_px, 0), Wl - 1);
+    const unsigned vo = su < 432 ? s_const + (unsigned)(row * Wl + col) * 32u : 0x80000000u;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(a.src) + (long long)b * img_bytes, 0,
+                                                                        (int)img_bytes, 0x00020000);
+    if (DBG & 2) sreg = u32x4{vo, vo, vo, vo};
+    else sreg = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)vo, 0, 0));
+  };
+  auto stage_write = [&](int n) {
+    unsigned roff = (unsigned)(WN_RAW_OFF + (n & 1) * WN_RAW_SLOT);
+    asm volatile("" : "+s"(roff));
+    *reinterpret_cast<u32x4*>(smem + roff + (unsigned)su * 16u) = sreg;
+  };
+  auto form_v = [&](int n, int x0, int i0) {
+    // this lane's column pair = low-resolution column tg; coefficients of its xi (all exact in fp16), with the two edge exceptions
+    const int tg = (x0 >> 1) + t16;
+    float ca = xi_p == 0 ? 0.75f : (xi_p == 2 ? -0.25f : 0.25f);
+    float cb_ = xi_p == 0 ? -0.5f : (xi_p == 1 ? 1.5f : (xi_p == 2 ? 0.f : 0.5f));
+    float cc = xi_p == 0 ? -0.25f : (xi_p == 3 ? -0.75f : 0.25f);
+    if (xi_p == 0 && tg == 0) { ca = 0.f; cb_ = -0.75f; cc = -0.25f; }
+    if (xi_p == 3 && tg == Wl - 1) { ca = 0.25f; cb_ = 0.75f; cc = 0.f; }
+    const _Float16 ha = (_Float16)ca, hb = (_Float16)cb_, hc = (_Float16)cc;
+    const f16x8_t va = {ha, ha, ha, ha, ha, ha, ha, ha}, vb = {hb, hb, hb, hb, hb, hb, hb, hb}, vc = {hc, hc, hc, hc, hc, hc, hc, hc};
+    unsigned roff = (unsigned)(WN_RAW_OFF + (n & 1) * WN_RAW_SLOT);
+    asm volatile("" : "+s"(roff));
+    const unsigned char* rb = smem + roff + (unsigned)(((sc_p * 2 + (kg >> 1)) * 18 + t16) * 32 + (kg & 1) * 16);
+    f16x8_t vh[3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      const f16x8_t f0 = *reinterpret_cast<const f16x8_t*>(rb + r * 2304), f1 = *reinterpret_cast<const f16x8_t*>(rb + r * 2304 + 32),
+                    f2 = *reinterpret_cast<const f16x8_t*>(rb + r * 2304 + 64);
+      vh[r] = __builtin_elementwise_fma(va, f0, __builtin_elementwise_fma(vb, f1, vc * f2));
+    }
+    unsigned uoff = (unsigned)((n % WN_NSLOT) * WN_SLOT + wave * 1024);
+    asm volatile("" : "+s"(uoff));
+    unsigned char* dst = smem + lane16 + uoff;
+    auto put = [&](int j, const f16x8_t& pa, const f16x8_t& pb) {      // row i0 + j of the x2 image: 3/4 pa + 1/4 pb, or zero padding
+      const int y = i0 + j;
+      const _Float16 wa = (y >= 0 && y < H) ? (_Float16)0.75f : (_Float16)0.f, wb = (y >= 0 && y < H) ? (_Float16)0.25f : (_Float16)0.f;
+      const f16x8_t qa = {wa, wa, wa, wa, wa, wa, wa, wa}, qb = {wb, wb, wb, wb, wb, wb, wb, wb};
+      *reinterpret_cast<f16x8_t*>(dst + j * WN_VROW) = __builtin_elementwise_fma(qa, pa, qb * pb);
+    };
+    if (i0 & 1) { put(0, vh[0], vh[1]); put(1, vh[1], vh[0]); put(2, vh[1], vh[2]); }
+    else { put(0, vh[1], vh[0]); put(1, vh[1], vh[2]); put(2, vh[2], vh[1]); }
   };
 
   f32x4 acc[3][4];      // [row slot][xi]
@@ -334,14 +399,29 @@ __global__ __launch_bounds__(WN_THREADS) void conv3x3_c64_wino_kernel(wino_args 
 
   {
     int b, x0, y0, y1, i0;
-    unsigned va, vb;
-    next_coords(0, b, x0, y0, y1, i0);
-    src_lane_offsets(x0, va, vb);
-    issue_loads(0, va, vb, b, y0, y1, i0);
-    write_v(0);
-    next_coords(1, b, x0, y0, y1, i0);
-    src_lane_offsets(x0, va, vb);
-    issue_loads(1, va, vb, b, y0, y1, i0);
+    if constexpr (UP) {
+      // raw rows of batches 0 and 1 staged, V of batch 0 formed, the unit of batch 2 in flight: the state `mid` expects
+      next_coords(0, b, x0, y0, y1, i0);
+      const int x00 = x0, i00 = i0;
+      stage_load(b, x0, i0);
+      stage_write(0);
+      next_coords(1, b, x0, y0, y1, i0);
+      stage_load(b, x0, i0);
+      stage_write(1);
+      sync();
+      form_v(0, x00, i00);
+      next_coords(2, b, x0, y0, y1, i0);
+      stage_load(b, x0, i0);
+    } else {
+      unsigned va, vb;
+      next_coords(0, b, x0, y0, y1, i0);
+      src_lane_offsets(x0, va, vb);
+      issue_loads(0, va, vb, b, y0, y1, i0);
+      write_v(0);
+      next_coords(1, b, x0, y0, y1, i0);
+      src_lane_offsets(x0, va, vb);
+      issue_loads(1, va, vb, b, y0, y1, i0);
+    }
     if (!(DBG & 4)) {      // two out-of-range (dropped) stores stand for "the previous batch's rows 1 and 2" in the wait counts
       const __amdgpu_buffer_rsrc_t r0 = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<unsigned char*>(a.out), 0, 0, 0x00020000);
 #pragma unroll
@@ -367,18 +447,36 @@ __global__ __launch_bounds__(WN_THREADS) void conv3x3_c64_wino_kernel(wino_args 
     // nothing but the row number
     auto mid_same = [&](int nn, int m) {
       return [&, nn, m]() {
-        write_v(nn + 1);
-        issue_loads(nn + 2, va, vb, b, y0, y1, y0 - 1 + (m + 2) * WN_ROWS);
+        if constexpr (UP) {
+          // the unit of batch nn + 2 goes to its LDS slot, the one of batch nn + 3 is requested, V of batch nn + 1 is formed from
+          // the slot written one batch ago (visible since the last barrier)
+          stage_write(nn + 2);
+          int b3, x3, y03, y13, i03;
+          next_coords(nn + 3, b3, x3, y03, y13, i03);
+          stage_load(b3, x3, i03);
+          form_v(nn + 1, x0, y0 - 1 + (m + 1) * WN_ROWS);
+        } else {
+          write_v(nn + 1);
+          issue_loads(nn + 2, va, vb, b, y0, y1, y0 - 1 + (m + 2) * WN_ROWS);
+        }
       };
     };
     auto mid_any = [&](int nn) {
       return [&, nn]() {
-        write_v(nn + 1);
         int b2, x2, y02, y12, i02;
-        unsigned va2, vb2;
-        next_coords(nn + 2, b2, x2, y02, y12, i02);
-        src_lane_offsets(x2, va2, vb2);
-        issue_loads(nn + 2, va2, vb2, b2, y02, y12, i02);
+        if constexpr (UP) {
+          stage_write(nn + 2);
+          next_coords(nn + 3, b2, x2, y02, y12, i02);
+          stage_load(b2, x2, i02);
+          next_coords(nn + 1, b2, x2, y02, y12, i02);
+          form_v(nn + 1, x2, i02);
+        } else {
+          write_v(nn + 1);
+          unsigned va2, vb2;
+          next_coords(nn + 2, b2, x2, y02, y12, i02);
+          src_lane_offsets(x2, va2, vb2);
+          issue_loads(nn + 2, va2, vb2, b2, y02, y12, i02);
+        }
       };
     };
     // steady-state batches: 1 <= m < mfast (the last two batches of a unit prefetch across the unit boundary through the general
@@ -422,6 +520,14 @@ extern "C" int cdfo_pack_conv3x3_wino(const float* w_oihw, void* packed, int Cou
 // Host side.  Row segments are chosen so that the unit count fills the workgroup lanes evenly: a unit costs
 // 3 * ceil((seg_h + 2) / 3) row steps (+ one barrier per batch).
 namespace {
+int wino_launch_up(const wino_args& a, int grid, hipStream_t st) {
+  static CdfoAttrOnce once;
+  const hipError_t e = cdfo_set_max_lds(once, reinterpret_cast<const void*>(conv3x3_c64_wino_kernel<true, 0, true>), WN_LDS_UP);
+  if (e != hipSuccess) return (int)e;
+  hipLaunchKernelGGL((conv3x3_c64_wino_kernel<true, 0, true>), dim3(grid), dim3(WN_THREADS), WN_LDS_UP, st, a);
+  return 0;
+}
+
 template <int DBG>
 int wino_launch(const wino_args& a, int grid, hipStream_t st) {
   static CdfoAttrOnce once_s, once_p;       // 72 KiB of dynamic LDS: above the 64 KiB a kernel gets without asking
@@ -471,6 +577,12 @@ extern "C" int cdfo_conv3x3_c64_wino_dbg(const void* src_cp16, int B, int H, int
   const double px = (double)B * H * W;
   CdfoProfScope prof(st, KID_CONV3_WINO, 2.0 * px * Cout * 64 * 9, 2.0 * (px * Cout + px * 64) + 2.0 * 12 * 64 * Cout);
   int rc = 0;
+  if (dbg == -1) {       // cdfo_conv3x3_c64_wino_up2
+    rc = wino_launch_up(a, nslots * 8, st);
+    if (rc) return rc;
+    CDFO_LAUNCH_CHECK();
+    return 0;
+  }
   switch (dbg) {
     case 0: rc = wino_launch<0>(a, nslots * 8, st); break;
     case 1: rc = wino_launch<1>(a, nslots * 8, st); break;
@@ -498,4 +610,12 @@ extern "C" int cdfo_conv3x3_c64_wino_dbg(const void* src_cp16, int B, int H, int
 extern "C" int cdfo_conv3x3_c64_wino(const void* src_cp16, int B, int H, int W, const void* w_wino, const float* bias, int Cout, int act,
                                      void* out_cp16, int store_mode, void* stream) {
   return cdfo_conv3x3_c64_wino_dbg(src_cp16, B, H, W, w_wino, bias, Cout, act, out_cp16, store_mode, 0, stream);
+}
+
+// Block_'s double-resolution branch without its double-resolution source: src_lr_cp16 [B][4][H/2][W/2][16] = up.0(x) (cdfo_block_prologue2's
+// t16), H x W = the x2 image's size; result = cdfo_conv3x3_c64_wino(bilinear_x2(src), ..., CDFO_STORE_S2D) up to fp16 rounding points
+extern "C" int cdfo_conv3x3_c64_wino_up2(const void* src_lr_cp16, int B, int H, int W, const void* w_wino, const float* bias, int Cout, int act,
+                                         void* out_cp16, void* stream) {
+  if ((H & 3) || (W & 3)) return CDFO_EINVAL;
+  return cdfo_conv3x3_c64_wino_dbg(src_lr_cp16, B, H, W, w_wino, bias, Cout, act, out_cp16, CDFO_STORE_S2D, -1, stream);
 }

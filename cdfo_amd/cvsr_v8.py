@@ -473,11 +473,15 @@ class CVSR_V8(nn.Module):
             # arithmetic as the single-pass fp16 mode of the tiled kernel: fp16 operands, fp32 accumulation
             # body[0]: the row-streaming Winograd F(2,3) kernel (2/3 of the direct product's MFMAs) unless CDFO_WINO=0
             c1 = lambda src, **kw: K.conv3x3_body0(src, b0, act=K.ACT_LRELU, **kw)
-            # sources of the x2 and x1/2 branches (and, for a group's first block, of the 1x branch), one read of x
+            # sources of the x2 and x1/2 branches (and, for a group's first block, of the 1x branch), one read of x.  up2: the x2 branch's
+            # source stays at the block's resolution (up.0(x), a quarter of the bytes) and the Winograd kernel interpolates it on the fly
+            up2 = (b0.ww is not None and K.wino_up2_enabled() and x.shape[1] % 2 == 0 and x.shape[2] % 2 == 0
+                   and x.shape[1] * x.shape[2] * 8 * b0.Cout < (1 << 31))
             if x16 is None:
-                u16, d16, x16 = K.block_prologue(x, w[p + "pro"], want_x16=True)
+                u16, d16, x16 = K.block_prologue(x, w[p + "pro"], want_x16=True, lowres_up=up2)
             else:
-                u16, d16 = K.block_prologue(x, w[p + "pro"])
+                u16, d16 = K.block_prologue(x, w[p + "pro"], lowres_up=up2)
+            c2 = (lambda src: K.conv3x3_wino_up2(src, b0, act=K.ACT_LRELU)) if up2 else (lambda src: c1(src, s2d=True))
             # The x1/2 branch (two launches on a quarter of the pixels: 72 tiles per clip at 272x480, a fraction of the GPU for one
             # or two clips and a ragged last round for eight) runs on a side stream beside the x1 and x2 branches; the last
             # convolution joins the three.
@@ -488,13 +492,13 @@ class CVSR_V8(nn.Module):
                 with torch.cuda.stream(side):
                     d = K.conv_ring(c1(d16), w[p + "body.2_up"])      # = up.0(body.2(.)) of the x1/2 branch
                 out = K.conv_ring(c1(x16), b2, res1=x)
-                t = c1(u16, s2d=True)
+                t = c2(u16)
                 main.wait_stream(side)
                 d.record_stream(main)
             else:
                 out = K.conv_ring(c1(x16), b2, res1=x)
                 d = K.conv_ring(c1(d16), w[p + "body.2_up"])      # = up.0(body.2(.)) of the x1/2 branch
-                t = c1(u16, s2d=True)
+                t = c2(u16)
             # want16: the next block's fp16 source; want_hl (a group's last block): fp16 hi | lo planes for the group convolution
             y16 = torch.empty_like(x16) if want16 else None
             if want_hl:

@@ -379,6 +379,28 @@ def conv3x3_wino(src: torch.Tensor, pc: PackedConv, *, act: int = ACT_NONE, s2d:
     return out
 
 
+def wino_up2_enabled() -> bool:
+    """CDFO_WINO_UP2=0 keeps Block_'s x2 branch on a materialised double-resolution source (developer A/B switch)."""
+    return wino_enabled() and os.environ.get("CDFO_WINO_UP2", "1") != "0"
+
+
+def conv3x3_wino_up2(src_lr: torch.Tensor, pc: PackedConv, *, act: int = ACT_NONE) -> torch.Tensor:
+    """Block_.body[0] on the bilinear x2 of src_lr (fp16 chunk-planar [B,4,h,w,16], h and w even) without materialising it: the
+    interpolation is folded into the Winograd kernel's input transform (cdfo_conv3x3_c64_wino_up2).  Result: the space-to-depth form
+    [B, 4*Cout/16, h, w, 16] of the [B, Cout/16, 2h, 2w, 16] convolution output, as conv3x3_wino(..., s2d=True)."""
+    if not src_lr.is_cuda:
+        raise NotImplementedError("conv3x3_wino_up2: the HIP path needs device tensors (no CPU fallback)")
+    if src_lr.dtype != torch.float16 or src_lr.dim() != 5 or src_lr.shape[1] != 4 or src_lr.shape[4] != 16 or not src_lr.is_contiguous():
+        raise ValueError(f"conv3x3_wino_up2: expected a contiguous fp16 [B,4,h,w,16] source, got {src_lr.dtype} {tuple(src_lr.shape)}")
+    B, _, h, w, _ = src_lr.shape
+    if pc.ww is None or h % 2 or w % 2:
+        raise ValueError("conv3x3_wino_up2: needs a Winograd weight image (Cout % 128 == 0) and even low-resolution sizes")
+    out = torch.empty((B, pc.Cout // 4, h, w, 16), dtype=torch.float16, device=src_lr.device)
+    check(_lib.lib().cdfo_conv3x3_c64_wino_up2(_vp(src_lr), B, 2 * h, 2 * w, _vp(pc.ww), _vp(pc.bias), pc.Cout, act, _vp(out), _stream()),
+          "cdfo_conv3x3_c64_wino_up2")
+    return out
+
+
 def conv3x3_body0(src: torch.Tensor, pc: PackedConv, *, act: int = ACT_NONE, s2d: bool = False) -> torch.Tensor:
     """Block_.body[0]-shaped convolution (fp16 chunk-planar in and out): the Winograd F(2,3) kernel where it applies (Cout % 128 == 0,
     even width, one image of source / result below 2 GiB, CDFO_WINO != 0), the direct weights-stationary kernel otherwise."""
@@ -650,16 +672,18 @@ def pack_block_prologue(w_up: torch.Tensor, b_up: torch.Tensor, w_dn: torch.Tens
     return torch.cat([pack(hi), pack(lo)]).contiguous(), torch.cat([b_up.detach().float(), b_dn.detach().float()]).contiguous()
 
 
-def block_prologue(x: torch.Tensor, packed, want_x16: bool = False):
+def block_prologue(x: torch.Tensor, packed, want_x16: bool = False, lowres_up: bool = False):
     """(u16, d16): fp16 chunk-planar bilinear_x2(up.0(x)) [B,4,2H,2W,16] and down.0(mean2x2(x)) [B,4,H/2,W/2,16];
-    want_x16: also (third) the fp16 chunk-planar copy [B,4,H,W,16] of x itself, from the same read of x."""
+    want_x16: also (third) the fp16 chunk-planar copy [B,4,H,W,16] of x itself, from the same read of x.
+    lowres_up: the first result is up.0(x) at the block's OWN resolution [B,4,H,W,16] (not resampled): the source of
+    conv3x3_wino(..., up2=True), which interpolates it on the fly."""
     B, H, W, Cc, ld = _chk_act(x)
     assert Cc == 64 and H % 2 == 0 and W % 2 == 0
-    u16 = torch.empty((B, 4, 2 * H, 2 * W, 16), dtype=torch.float16, device=x.device)
+    u16 = torch.empty((B, 4, H, W, 16) if lowres_up else (B, 4, 2 * H, 2 * W, 16), dtype=torch.float16, device=x.device)
     d16 = torch.empty((B, 4, H // 2, W // 2, 16), dtype=torch.float16, device=x.device)
     x16 = torch.empty((B, 4, H, W, 16), dtype=torch.float16, device=x.device) if want_x16 else None
-    check(_lib.lib().cdfo_block_prologue(_vp(x), ld, B, H, W, _vp(packed[0]), _vp(packed[1]), _vp(u16), _vp(d16),
-                                         _vp(x16), _stream()), "cdfo_block_prologue")
+    check(_lib.lib().cdfo_block_prologue2(_vp(x), ld, B, H, W, _vp(packed[0]), _vp(packed[1]), _vp(None if lowres_up else u16),
+                                          _vp(u16 if lowres_up else None), _vp(d16), _vp(x16), _stream()), "cdfo_block_prologue2")
     return (u16, d16, x16) if want_x16 else (u16, d16)
 
 

@@ -123,6 +123,12 @@ int cdfo_conv3x3_c64_wino(const void* src_cp16, int B, int H, int W, const void*
 int cdfo_pack_conv3x3_wino(const float* w_oihw, void* packed, int Cout, void* stream);
 /* the same call with developer ablation bits (dbg != 0: WRONG results; 1 no MFMAs, 2 no global loads, 4 no stores, 8 no epilogue
  * arithmetic, 16 no barrier): tools/bench_wino.py */
+/* Block_'s double-resolution branch (arch.py:398-404: body(up(x))) without its double-resolution source: src_lr_cp16
+ * [B][4][H/2][W/2][16] = up.0(x) at the block's resolution (cdfo_block_prologue2's t16); H x W (multiples of 4) = the size of the x2
+ * image the convolution runs on.  The bilinear x2 (align_corners = False, clamped taps; the convolution pads the x2 image with zeros)
+ * is folded into the F(2,3) input transform.  Result as cdfo_conv3x3_c64_wino(..., CDFO_STORE_S2D): [B][4 Cout/16][H/2][W/2][16].  */
+int cdfo_conv3x3_c64_wino_up2(const void* src_lr_cp16, int B, int H, int W, const void* w_wino, const float* bias, int Cout, int act,
+                              void* out_cp16, void* stream);
 int cdfo_conv3x3_c64_wino_dbg(const void* src_cp16, int B, int H, int W, const void* w_wino, const float* bias, int Cout, int act,
                               void* out_cp16, int store_mode, int dbg, void* stream);
 /* MVDualAttAlignment's conv_offset[2] (3x3, 64 -> Cout = 27 dg, arch/SIDECVSR_our.py:3285-3289) on the weights-stationary kernel with
@@ -274,6 +280,11 @@ int cdfo_metric_partials(const float* a, const float* b, int N, int H, int W, in
  * copy [B][4][H][W][16] of x itself, the source of the block's own-resolution branch.  */
 int cdfo_block_prologue(const float* x, int ldx, int B, int H, int W, const void* w_bf16, const float* bias128, void* u16,
                         void* d16, void* x16, void* stream);
+/* The same with the double-resolution source left to its consumer: exactly one of u16 / t16 is given; t16 [B][4][H][W][16] receives
+ * up.0(x) itself (fp16 chunk-planar, NOT resampled), which cdfo_conv3x3_c64_wino_up2 interpolates while it builds its transformed
+ * inputs -- the 4x larger u16 is then never written or read.  */
+int cdfo_block_prologue2(const float* x, int ldx, int B, int H, int W, const void* w_bf16, const float* bias128, void* u16, void* t16,
+                         void* d16, void* x16, void* stream);
 /* MDTA front end in one pass (arch.py:1169-1198 LayerNorm, :1551-1552 qkv + qkv_dwconv): out[B][H][W][192] =
  * depthwise3x3(conv1x1(LayerNorm64(x))).  w_bf16: split-bf16 weights [hi|lo][4][2][192][8], element (s,h,n,j) =
  * W[n][16s+8h+j] * gamma[16s+8h+j]; bias[192] = W @ beta (may be NULL); dw_w: raw [192][1][3][3] taps.

@@ -690,3 +690,28 @@ def test_conv1x1_with_its_fp16_chunk_planar_copy():
     ref = K.conv(x, pc, prec=K.PREC_BF16X3)
     assert torch.equal(out, ref)
     assert tuple(copy.shape) == (B, 4, H, W, 16) and torch.equal(copy, K.to_cp16(ref))
+
+
+@pytest.mark.parametrize("Cout,h,w,B,act", [(256, 12, 20, 1, 1), (128, 8, 32, 2, 0), (256, 18, 26, 2, 1), (256, 2, 2, 1, 1),
+                                            (256, 136, 240, 2, 1), (256, 24, 336, 13, 1)])
+def test_conv3x3_c64_wino_up2(Cout, h, w, B, act):
+    """Block_'s x2 branch with the bilinear x2 folded into the Winograd input transform (cdfo_conv3x3_c64_wino_up2) vs torch-cpu
+    float64: conv2d(F.interpolate(src, scale 2, bilinear, align_corners=False), padding=1) on the fp16-rounded low-resolution source --
+    the arch.py:398-404 operator chain; clamped interpolation taps, zero padding of the x2 image, every edge tile, several units per
+    workgroup.  Also against the materialised form (block_prologue's x2 image through conv3x3_wino)."""
+    from cdfo_amd import kernels as K
+    g = torch.Generator().manual_seed(Cout + h + w)
+    x = torch.randn(B, 64, h, w, generator=g)
+    wt = torch.randn(Cout, 64, 3, 3, generator=g) / 24.0
+    b = torch.randn(Cout, generator=g)
+    up = F.interpolate(x.half().double(), scale_factor=2.0, mode="bilinear", align_corners=False)
+    ref = F.conv2d(up, wt.double(), b.double(), padding=1)
+    ref = {0: ref, 1: F.leaky_relu(ref, 0.1)}[act].float()
+    pc = K.pack_conv(wt.cuda(), b.cuda())
+    src = K.to_cp16(_nhwc(x).cuda())
+    out = K.conv3x3_wino_up2(src, pc, act=act)
+    torch.cuda.synchronize()
+    got = K.from_cp16(out).float().cpu().view(B, h, w, 2, 2, Cout).permute(0, 1, 3, 2, 4, 5).reshape(B, 2 * h, 2 * w, Cout).permute(0, 3, 1, 2)
+    err = (got - ref).abs().max().item()
+    scale = ref.abs().max().item()
+    assert err <= 2.5e-3 * max(1.0, scale), f"wino up2: max-abs {err} (ref scale {scale})"

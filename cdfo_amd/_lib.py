@@ -45,6 +45,7 @@ class ConvArgs(C.Structure):
         ("mask_out", C.c_void_p), ("flow", C.c_void_p), ("flow_bstride", C.c_longlong), ("off_mag", C.c_float),
         ("off_accumulate", C.c_int),
         ("res2_pixscale", C.c_void_p),
+        ("src_halfsplit", C.c_int),
     ]
 
 

@@ -61,6 +61,8 @@ struct ring_extra {
   int plane_wrap;             // chunk c reads source plane c % plane_wrap (0: plane c)
   int src_planes;             // planes per image in the source tensor
   int touch;                  // wave-specialised form: producers touch the tile's res1 lines ahead of the epilogue
+  int halfsplit;              // source rows are [8-channel half][W][8] (cdfo_conv_args.src_halfsplit): the two 16-byte halves of a pixel's
+                              // record lie W * 16 bytes apart instead of side by side
 };
 __device__ __forceinline__ bool rg_touch_on(const ring_extra& e) { return e.touch != 0; }
 
@@ -147,7 +149,7 @@ __global__ __launch_bounds__(RG_THREADS) void conv3x3_ring_kernel(cdfo_conv_args
       const int iy = p / RG_IW, ix = p - iy * RG_IW;
       d_iy[j] = p < RG_NPIX ? iy : 1 << 20;
       d_ix[j] = ix;
-      d_rel[j] = (iy * W + ix) * 32 + half * 16;
+      d_rel[j] = e.halfsplit ? ((iy * 2 + half) * W + ix) * 16 : (iy * W + ix) * 32 + half * 16;
       dst_off[j] = q * 1024;
     } else {
       const int q = (wave - ACT_WAVES) * PPW + j;
@@ -198,7 +200,7 @@ __global__ __launch_bounds__(RG_THREADS) void conv3x3_ring_kernel(cdfo_conv_args
       unit_coords(iu, b, oy0, ox0, n0);
       if (!loader_w) {
         rsrc_i = rg_rsrc(static_cast<const unsigned char*>(e.src) + (unsigned long long)b * img_bytes, img_bytes);
-        const int base = ((oy0 - 1) * W + (ox0 - 1)) * 32;
+        const int base = e.halfsplit ? ((oy0 - 1) * 2 * W + (ox0 - 1)) * 16 : ((oy0 - 1) * W + (ox0 - 1)) * 32;
 #pragma unroll
         for (int j = 0; j < PPW; ++j) {
           const int gy = oy0 - 1 + d_iy[j], gx = ox0 - 1 + d_ix[j];
@@ -605,7 +607,7 @@ __global__ __launch_bounds__(RG_THREADS) void conv3x3_ring_split_kernel(cdfo_con
         const int iy = p / RG_IW, ix = p - iy * RG_IW;
         d_iy[j] = (real && p < RG_NPIX) ? iy : 1 << 20;
         d_ix[j] = ix;
-        d_rel[j] = (iy * W + ix) * 32 + half * 16;
+        d_rel[j] = e.halfsplit ? ((iy * 2 + half) * W + ix) * 16 : (iy * W + ix) * 32 + half * 16;
         dst_off[j] = real ? q * 1024 : -1;
       } else {
         const int q = (pw - ACT_PW) * WGT_PER + j;
@@ -633,7 +635,7 @@ __global__ __launch_bounds__(RG_THREADS) void conv3x3_ring_split_kernel(cdfo_con
         unit_coords(iu, b, oy0, ox0, n0);
         if (!loader_w) {
           rsrc_i = rg_rsrc(static_cast<const unsigned char*>(e.src) + (unsigned long long)b * img_bytes, img_bytes);
-          const int base = ((oy0 - 1) * W + (ox0 - 1)) * 32;
+          const int base = e.halfsplit ? ((oy0 - 1) * 2 * W + (ox0 - 1)) * 16 : ((oy0 - 1) * W + (ox0 - 1)) * 32;
 #pragma unroll
           for (int j = 0; j < PPW; ++j) {
             const int gy = oy0 - 1 + d_iy[j], gx = ox0 - 1 + d_ix[j];
@@ -1272,6 +1274,7 @@ extern "C" int cdfo_conv3x3_ring(const cdfo_conv_args* pa, void* stream) {
   ring_extra e;
   e.src = a.src[0]; e.nc = nc; e.w = a.w; e.CoutP = a.CoutP; e.tap_mask = a.tap_mask; e.w_bytes = (int)w_bytes;
   e.plane_wrap = a.src_plane_wrap;
+  e.halfsplit = a.src_halfsplit ? 1 : 0;
   // (off by default: the touched lines do not survive until the epilogue -- FETCH_SIZE of the launch rose by exactly the res1
   // tile bytes, 3.10 -> 3.44 GB, i.e. the epilogue fetched them again -- and the epilogue got 7 % shorter at best; CDFO_RING_TOUCH=1)
   static const int touch = [] { const char* v = getenv("CDFO_RING_TOUCH"); return (v && v[0] == '1') ? 1 : 0; }();

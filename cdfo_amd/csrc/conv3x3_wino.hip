@@ -53,7 +53,7 @@ constexpr int WN_RAW_SLOT = 8192, WN_RAW_OFF = WN_LDS, WN_LDS_UP = WN_LDS + 2 * 
 struct wino_args {
   const unsigned char* src; int B, H, W;
   const f16x8_t* w; const float* bias; int Cout, act;
-  _Float16* out; int s2d;
+  _Float16* out; int s2d, halfsplit;
   int seg_h, nseg, nstrips, nb;                  // rows per segment, segments per strip, strips per image row, batches per unit
 };
 
@@ -436,7 +436,10 @@ __global__ __launch_bounds__(WN_THREADS) void conv3x3_c64_wino_kernel(wino_args 
     // lane parts of the store addresses (columns 2t, 2t + 1 of the strip) and of the NEXT batches' loads within this unit
     const int xo = x0 + 2 * t16 + (kg & 1);       // this lane stores column 2t + (kg & 1), channels 8 (kg >> 1) .. + 7 of the wave's 16
     unsigned vo, va, vb;
-    if constexpr (S2D) vo = (unsigned)(xo >> 1) * 32u + (unsigned)(kg >> 1) * 16u + (unsigned)(kg & 1) * (unsigned)(nck * (H >> 1) * (W >> 1) * 32);
+    // (half-split rows: a row's first 8-channel halves, then its second halves -- 16 lanes then store 256 contiguous bytes)
+    if constexpr (S2D) vo = (a.halfsplit ? (unsigned)(xo >> 1) * 16u + (unsigned)(kg >> 1) * (unsigned)((W >> 1) * 16)
+                                         : (unsigned)(xo >> 1) * 32u + (unsigned)(kg >> 1) * 16u) +
+                            (unsigned)(kg & 1) * (unsigned)(nck * (H >> 1) * (W >> 1) * 32);
     else vo = (unsigned)xo * 32u + (unsigned)(kg >> 1) * 16u;
     if (xo >= W) vo = 0x80000000u;
     if (DBG & 64) vo = (unsigned)x0 * 32u + lane16;                             // ablation: line-contiguous stores (wrong layout)
@@ -550,8 +553,8 @@ extern "C" int cdfo_conv3x3_c64_wino_dbg(const void* src_cp16, int B, int H, int
                                          void* out_cp16, int store_mode, int dbg, void* stream) {
   hipStream_t st = static_cast<hipStream_t>(stream);
   if (B <= 0 || H <= 0 || W <= 0 || (W & 1) || Cout <= 0 || Cout % 128) return CDFO_EINVAL;
-  if (act == CDFO_ACT_SIGMOID || (store_mode != CDFO_STORE_PLAIN && store_mode != CDFO_STORE_S2D)) return CDFO_EINVAL;
-  if (store_mode == CDFO_STORE_S2D && (H & 1)) return CDFO_EINVAL;
+  if (act == CDFO_ACT_SIGMOID || (store_mode != CDFO_STORE_PLAIN && store_mode != CDFO_STORE_S2D && store_mode != CDFO_STORE_S2D_HS)) return CDFO_EINVAL;
+  if (store_mode != CDFO_STORE_PLAIN && (H & 1)) return CDFO_EINVAL;
   if ((long long)H * W * 128 >= (1ll << 31) || (long long)(Cout / 16) * H * W * 32 >= (1ll << 31)) return CDFO_EINVAL;   // per-image 32-bit offsets
   if (!aligned16(src_cp16) || !aligned16(w_wino) || !aligned16(out_cp16)) return CDFO_EALIGN;
   const int cus = cdfo_num_cus();
@@ -572,7 +575,7 @@ extern "C" int cdfo_conv3x3_c64_wino_dbg(const void* src_cp16, int B, int H, int
   wino_args a;
   a.src = static_cast<const unsigned char*>(src_cp16); a.B = B; a.H = H; a.W = W;
   a.w = static_cast<const f16x8_t*>(w_wino); a.bias = bias; a.Cout = Cout; a.act = act;
-  a.out = static_cast<_Float16*>(out_cp16); a.s2d = store_mode == CDFO_STORE_S2D;
+  a.out = static_cast<_Float16*>(out_cp16); a.s2d = store_mode != CDFO_STORE_PLAIN; a.halfsplit = store_mode == CDFO_STORE_S2D_HS;
   a.seg_h = best_seg; a.nseg = (H + best_seg - 1) / best_seg; a.nstrips = nstrips; a.nb = (best_seg + 2 + 2) / 3;
   const double px = (double)B * H * W;
   CdfoProfScope prof(st, KID_CONV3_WINO, 2.0 * px * Cout * 64 * 9, 2.0 * (px * Cout + px * 64) + 2.0 * 12 * 64 * Cout);
@@ -615,7 +618,7 @@ extern "C" int cdfo_conv3x3_c64_wino(const void* src_cp16, int B, int H, int W, 
 // Block_'s double-resolution branch without its double-resolution source: src_lr_cp16 [B][4][H/2][W/2][16] = up.0(x) (cdfo_block_prologue2's
 // t16), H x W = the x2 image's size; result = cdfo_conv3x3_c64_wino(bilinear_x2(src), ..., CDFO_STORE_S2D) up to fp16 rounding points
 extern "C" int cdfo_conv3x3_c64_wino_up2(const void* src_lr_cp16, int B, int H, int W, const void* w_wino, const float* bias, int Cout, int act,
-                                         void* out_cp16, void* stream) {
-  if ((H & 3) || (W & 3)) return CDFO_EINVAL;
-  return cdfo_conv3x3_c64_wino_dbg(src_lr_cp16, B, H, W, w_wino, bias, Cout, act, out_cp16, CDFO_STORE_S2D, -1, stream);
+                                         void* out_cp16, int store_mode, void* stream) {
+  if ((H & 3) || (W & 3) || (store_mode != CDFO_STORE_S2D && store_mode != CDFO_STORE_S2D_HS)) return CDFO_EINVAL;
+  return cdfo_conv3x3_c64_wino_dbg(src_lr_cp16, B, H, W, w_wino, bias, Cout, act, out_cp16, store_mode, -1, stream);
 }

@@ -231,6 +231,11 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16x3_kernel(wg_args g) {
   }
 }
 
+// (Round 5 also built a form with one workgroup per (tile, kernel ROW, split) that serves the three kx taps from one ten-pixel window --
+// a third of the operand loads and splits per MFMA.  Measured on the training step (backward, 20 x 64 x 64): 326 ms with a 64 x 64
+// tile (192 accumulators: one wave per SIMD, every step's load latency exposed) and 223 ms with a 64 x 32 tile (two waves per SIMD)
+// against 153 ms for the per-tap kernel above at three waves per SIMD; removed again.  What the per-tap kernel lacks is not fewer
+// loads but a software pipeline that hipcc does not collapse: see DESIGN.md section 5.000 #6.)
 // dw[(a * Btot + b_off + b) * T + tap] = scale * sum_sp slab[sp][tap][a][b]   (fixed order)
 __global__ __launch_bounds__(256) void conv_wgrad_reduce_kernel(const float* __restrict__ slab, int nsplit, int T, int A, int Bc,
                                                                 int Apad, int Bpad, int Btot, int b_off, float* __restrict__ dw) {

@@ -481,7 +481,9 @@ class CVSR_V8(nn.Module):
                 u16, d16, x16 = K.block_prologue(x, w[p + "pro"], want_x16=True, lowres_up=up2)
             else:
                 u16, d16 = K.block_prologue(x, w[p + "pro"], lowres_up=up2)
-            c2 = (lambda src: K.conv3x3_wino_up2(src, b0, act=K.ACT_LRELU)) if up2 else (lambda src: c1(src, s2d=True))
+            # (the x2 branch's 256-channel intermediate in half-split rows: the Winograd kernel's lanes then store contiguous runs)
+            hs = up2 and os.environ.get("CDFO_WINO_HS", "0") != "0"      # measured: no gain in the forward (105.2 vs 105.3 ms), off by default
+            c2 = (lambda src: K.conv3x3_wino_up2(src, b0, act=K.ACT_LRELU, halfsplit=hs)) if up2 else (lambda src: c1(src, s2d=True))
             # The x1/2 branch (two launches on a quarter of the pixels: 72 tiles per clip at 272x480, a fraction of the GPU for one
             # or two clips and a ragged last round for eight) runs on a side stream beside the x1 and x2 branches; the last
             # convolution joins the three.
@@ -504,7 +506,7 @@ class CVSR_V8(nn.Module):
             if want_hl:
                 y16 = torch.empty((x16.shape[0], 8) + tuple(x16.shape[2:]), dtype=torch.float16, device=x16.device)
             # the x1/2 branch (bilinear x2 of d) is added by the last convolution's epilogue
-            y = K.conv_ring(t, w[p + "down_fused"], res1=out, res_up2=d, out2_cp16=y16, out2_hl=want_hl)
+            y = K.conv_ring(t, w[p + "down_fused"], res1=out, res_up2=d, out2_cp16=y16, out2_hl=want_hl, src_halfsplit=hs)
             return (y, y16) if (want16 or want_hl) else y
         out = self._conv(self._conv(x, b0, pad=1, act=K.ACT_LRELU, out_f16=t16, inner=True), b2, pad=1, res1=x)
         # half-resolution branch

@@ -355,8 +355,14 @@ def wino_enabled() -> bool:
     return os.environ.get("CDFO_WINO", "1") != "0"
 
 
+def halfsplit_to_rows(t: torch.Tensor) -> torch.Tensor:
+    """[B, planes, H, W, 16] stored with half-split rows ([H][2][W][8], CDFO_STORE_S2D_HS) -> the natural [B, planes, H, W, 16] (tests)."""
+    B, P, H, W, _ = t.shape
+    return t.reshape(B, P, H, 2, W, 8).permute(0, 1, 2, 4, 3, 5).reshape(B, P, H, W, 16)
+
+
 def conv3x3_wino(src: torch.Tensor, pc: PackedConv, *, act: int = ACT_NONE, s2d: bool = False,
-                 out: Optional[torch.Tensor] = None, dbg: int = 0) -> torch.Tensor:
+                 out: Optional[torch.Tensor] = None, dbg: int = 0, halfsplit: bool = False) -> torch.Tensor:
     """conv3x3_ws's operands and result on the row-streaming Winograd F(2,3) kernel (cdfo_conv3x3_c64_wino): Cout % 128 == 0, W even."""
     if not src.is_cuda:
         raise NotImplementedError("conv3x3_wino: the HIP path needs device tensors (no CPU fallback)")
@@ -370,11 +376,14 @@ def conv3x3_wino(src: torch.Tensor, pc: PackedConv, *, act: int = ACT_NONE, s2d:
         out = torch.empty(shape, dtype=torch.float16, device=src.device)
     elif out.shape != shape or out.dtype != torch.float16 or not out.is_contiguous():
         raise ValueError(f"conv3x3_wino: out must be a contiguous fp16 tensor of shape {shape}")
+    if halfsplit and not s2d:
+        raise ValueError("conv3x3_wino: half-split rows exist for the space-to-depth store only")
+    mode = (5 if halfsplit else 2) if s2d else 0
     if dbg:      # developer ablations (tools/bench_wino.py): wrong results by construction
-        check(_lib.lib().cdfo_conv3x3_c64_wino_dbg(_vp(src), B, H, W, _vp(pc.ww), _vp(pc.bias), pc.Cout, act, _vp(out), 2 if s2d else 0,
+        check(_lib.lib().cdfo_conv3x3_c64_wino_dbg(_vp(src), B, H, W, _vp(pc.ww), _vp(pc.bias), pc.Cout, act, _vp(out), mode,
                                                    dbg, _stream()), "cdfo_conv3x3_c64_wino_dbg")
         return out
-    check(_lib.lib().cdfo_conv3x3_c64_wino(_vp(src), B, H, W, _vp(pc.ww), _vp(pc.bias), pc.Cout, act, _vp(out), 2 if s2d else 0,
+    check(_lib.lib().cdfo_conv3x3_c64_wino(_vp(src), B, H, W, _vp(pc.ww), _vp(pc.bias), pc.Cout, act, _vp(out), mode,
                                            _stream()), "cdfo_conv3x3_c64_wino")
     return out
 
@@ -384,7 +393,7 @@ def wino_up2_enabled() -> bool:
     return wino_enabled() and os.environ.get("CDFO_WINO_UP2", "1") != "0"
 
 
-def conv3x3_wino_up2(src_lr: torch.Tensor, pc: PackedConv, *, act: int = ACT_NONE) -> torch.Tensor:
+def conv3x3_wino_up2(src_lr: torch.Tensor, pc: PackedConv, *, act: int = ACT_NONE, halfsplit: bool = False) -> torch.Tensor:
     """Block_.body[0] on the bilinear x2 of src_lr (fp16 chunk-planar [B,4,h,w,16], h and w even) without materialising it: the
     interpolation is folded into the Winograd kernel's input transform (cdfo_conv3x3_c64_wino_up2).  Result: the space-to-depth form
     [B, 4*Cout/16, h, w, 16] of the [B, Cout/16, 2h, 2w, 16] convolution output, as conv3x3_wino(..., s2d=True)."""
@@ -396,8 +405,8 @@ def conv3x3_wino_up2(src_lr: torch.Tensor, pc: PackedConv, *, act: int = ACT_NON
     if pc.ww is None or h % 2 or w % 2:
         raise ValueError("conv3x3_wino_up2: needs a Winograd weight image (Cout % 128 == 0) and even low-resolution sizes")
     out = torch.empty((B, pc.Cout // 4, h, w, 16), dtype=torch.float16, device=src_lr.device)
-    check(_lib.lib().cdfo_conv3x3_c64_wino_up2(_vp(src_lr), B, 2 * h, 2 * w, _vp(pc.ww), _vp(pc.bias), pc.Cout, act, _vp(out), _stream()),
-          "cdfo_conv3x3_c64_wino_up2")
+    check(_lib.lib().cdfo_conv3x3_c64_wino_up2(_vp(src_lr), B, 2 * h, 2 * w, _vp(pc.ww), _vp(pc.bias), pc.Cout, act, _vp(out),
+                                               5 if halfsplit else 2, _stream()), "cdfo_conv3x3_c64_wino_up2")
     return out
 
 
@@ -499,7 +508,7 @@ def conv_ring(src: torch.Tensor, pc: PackedConv, *, act: int = ACT_NONE, res1: O
               res2: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None,
               out_f16: bool = False, out2_cp16: Optional[torch.Tensor] = None,
               res_up2: Optional[torch.Tensor] = None, plane_wrap: int = 0, dbg: int = 0,
-              out2_hl: bool = False) -> torch.Tensor:
+              out2_hl: bool = False, src_halfsplit: bool = False) -> torch.Tensor:
     """3x3/s1/p1 convolution of an fp16 chunk-planar source [B,Cin/16,H,W,16] on the LDS-DMA ring kernel
     (Block_.body[2] and the composed stride-2 convolution).  Result: pixel-major fp32 (or fp16) [B,H,W,Cout]."""
     if not src.is_cuda:
@@ -528,6 +537,7 @@ def conv_ring(src: torch.Tensor, pc: PackedConv, *, act: int = ACT_NONE, res1: O
     a.out, a.store_mode, a.prec = out.data_ptr(), 0, PREC_FP16 | (dbg << 8)
     a.src_f16, a.out_f16 = 1, int(out_f16)
     a.src_plane_wrap = plane_wrap
+    a.src_halfsplit = int(src_halfsplit)
     for nm, r in (("res1", res1), ("res2", None if dbg & 16 else res2)):
         if r is not None:
             rb, rh, rw, rc, rld = _chk_act(r, nm)

@@ -24,7 +24,8 @@ extern "C" {
 #define CDFO_MAXSRC 8
 
 enum { CDFO_ACT_NONE = 0, CDFO_ACT_LRELU = 1, CDFO_ACT_RELU = 2, CDFO_ACT_SIGMOID = 3 };
-enum { CDFO_STORE_PLAIN = 0, CDFO_STORE_SHUFFLE2 = 1, CDFO_STORE_S2D = 2, CDFO_STORE_TAPS9 = 3, CDFO_STORE_OFFMASK = 4 };
+enum { CDFO_STORE_PLAIN = 0, CDFO_STORE_SHUFFLE2 = 1, CDFO_STORE_S2D = 2, CDFO_STORE_TAPS9 = 3, CDFO_STORE_OFFMASK = 4,
+       CDFO_STORE_S2D_HS = 5 /* cdfo_conv3x3_c64_wino[_up2]: CDFO_STORE_S2D with half-split rows, see cdfo_conv_args.src_halfsplit */ };
 enum { CDFO_DTYPE_F32 = 0, CDFO_DTYPE_F16 = 1, CDFO_DTYPE_F64 = 2 };   /* element type tag of the *_dt entry points */
 enum { CDFO_PREC_F32 = 0, CDFO_PREC_BF16X3 = 1, CDFO_PREC_BF16 = 2, CDFO_PREC_FP16X2 = 3, CDFO_PREC_FP16 = 4, CDFO_PREC_FP16X1 = 5 };
 
@@ -74,6 +75,9 @@ typedef struct {
   float* mask_out; const float* flow; long long flow_bstride; float off_mag; int off_accumulate;
   const float* res2_pixscale;  /* optional, cdfo_conv1x1_bf16x3 only (its streaming form): res2 enters the sum as res2[p][c] * res2_pixscale[p],
                                  one factor per pixel [B][H*W] -- a spatial gate applied to the residual without writing the gated tensor */
+  int src_halfsplit;           /* cdfo_conv3x3_ring only: the fp16 chunk-planar source's rows are stored as [8-channel half][W][8]
+                                 (a row's first halves, then its second halves: what cdfo_conv3x3_c64_wino writes with
+                                 CDFO_STORE_S2D_HS, 16 contiguous bytes per lane and pixel) instead of [W][16] */
 } cdfo_conv_args;
 int cdfo_sizeof_conv_args(void);   /* sizeof(cdfo_conv_args) as the library was built: a binding checks its own mirror against it */
 int cdfo_conv_igemm(const cdfo_conv_args* a, void* stream);
@@ -126,9 +130,10 @@ int cdfo_pack_conv3x3_wino(const float* w_oihw, void* packed, int Cout, void* st
 /* Block_'s double-resolution branch (arch.py:398-404: body(up(x))) without its double-resolution source: src_lr_cp16
  * [B][4][H/2][W/2][16] = up.0(x) at the block's resolution (cdfo_block_prologue2's t16); H x W (multiples of 4) = the size of the x2
  * image the convolution runs on.  The bilinear x2 (align_corners = False, clamped taps; the convolution pads the x2 image with zeros)
- * is folded into the F(2,3) input transform.  Result as cdfo_conv3x3_c64_wino(..., CDFO_STORE_S2D): [B][4 Cout/16][H/2][W/2][16].  */
+ * is folded into the F(2,3) input transform.  Result as cdfo_conv3x3_c64_wino(..., store_mode) with store_mode = CDFO_STORE_S2D
+ * ([B][4 Cout/16][H/2][W/2][16]) or CDFO_STORE_S2D_HS (the same planes with half-split rows [H/2][2][W/2][8]).  */
 int cdfo_conv3x3_c64_wino_up2(const void* src_lr_cp16, int B, int H, int W, const void* w_wino, const float* bias, int Cout, int act,
-                              void* out_cp16, void* stream);
+                              void* out_cp16, int store_mode, void* stream);
 int cdfo_conv3x3_c64_wino_dbg(const void* src_cp16, int B, int H, int W, const void* w_wino, const float* bias, int Cout, int act,
                               void* out_cp16, int store_mode, int dbg, void* stream);
 /* MVDualAttAlignment's conv_offset[2] (3x3, 64 -> Cout = 27 dg, arch/SIDECVSR_our.py:3285-3289) on the weights-stationary kernel with

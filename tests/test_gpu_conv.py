@@ -366,6 +366,32 @@ def test_conv3x3_ring_dense(Cin, Cout, H, W, B, res, out_f16):
     _cmp(out.float(), ref, 1.5e-3 if out_f16 else 1e-4, "ring conv")
 
 
+def test_conv3x3_ring_sparse_taps_halfsplit_source():
+    """cdfo_conv_args.src_halfsplit: the four-tap ring kernel on a source whose rows are [half][W][8] gives the natural layout's result."""
+    from cdfo_amd import kernels as K
+    g = torch.Generator().manual_seed(12)
+    B, H, W, Cin, Cout = 2, 36, 44, 128, 64
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / (Cin * 4) ** 0.5
+    masks = []
+    for c in range(Cin // 16):
+        y0, x0 = (c >> 1) & 1, c & 1
+        m = 0
+        for dy in range(2):
+            for dx in range(2):
+                m |= 1 << ((y0 + dy) * 3 + x0 + dx)
+        masks.append(m)
+    pc = K.pack_conv(w.cuda(), None)
+    pc.tap_mask = torch.tensor(masks, dtype=torch.int32).cuda()
+    src = K.to_cp16(_nhwc(x).cuda())                                                   # [B, 8, H, W, 16]
+    hs = src.view(B, Cin // 16, H, W, 2, 8).permute(0, 1, 2, 4, 3, 5).contiguous().view(B, Cin // 16, H, W, 16)
+    assert torch.equal(K.halfsplit_to_rows(hs), src)
+    want = K.conv_ring(src, pc)
+    got = K.conv_ring(hs, pc, src_halfsplit=True)
+    torch.cuda.synchronize()
+    assert torch.equal(got, want)
+
+
 def test_conv3x3_ring_sparse_taps():
     """Four-taps-per-chunk form (the composed stride-2 convolution): weights zero outside a per-chunk 2x2 tap window."""
     from cdfo_amd import kernels as K
@@ -710,7 +736,9 @@ def test_conv3x3_c64_wino_up2(Cout, h, w, B, act):
     pc = K.pack_conv(wt.cuda(), b.cuda())
     src = K.to_cp16(_nhwc(x).cuda())
     out = K.conv3x3_wino_up2(src, pc, act=act)
+    out_hs = K.halfsplit_to_rows(K.conv3x3_wino_up2(src, pc, act=act, halfsplit=True))      # CDFO_STORE_S2D_HS: the same values, rows half-split
     torch.cuda.synchronize()
+    assert torch.equal(out_hs, out)
     got = K.from_cp16(out).float().cpu().view(B, h, w, 2, 2, Cout).permute(0, 1, 3, 2, 4, 5).reshape(B, 2 * h, 2 * w, Cout).permute(0, 3, 1, 2)
     err = (got - ref).abs().max().item()
     scale = ref.abs().max().item()

@@ -44,6 +44,9 @@ constexpr int WN_THREADS = 512;
 constexpr int WN_ROWS = 3;                       // input rows per batch (= the period of the rolling accumulator sets)
 constexpr int WN_VROW = 8 * 1024;                // V of one input row: fragment xi * 2 + K half, 1 KiB each
 constexpr int WN_SLOT = WN_ROWS * WN_VROW;
+#ifndef WN_BSYNC
+#define WN_BSYNC 1      // the row of a batch behind which waves 4-7 pass its barrier (their V fragments are written behind row 0)
+#endif
 constexpr int WN_NSLOT = 3;                      // V ring: batch n lives in slot n % 3 (see the barrier's place in `batch`)
 constexpr int WN_LDS = WN_NSLOT * WN_SLOT;       // 72 KiB
 // UP (on-the-fly bilinear x2 of a low-resolution source): the three low-resolution rows a batch interpolates from, staged for the
@@ -55,6 +58,7 @@ struct wino_args {
   const f16x8_t* w; const float* bias; int Cout, act;
   _Float16* out; int s2d, halfsplit;
   int seg_h, nseg, nstrips, nb;                  // rows per segment, segments per strip, strips per image row, batches per unit
+  unsigned long long* clk;                       // dbg 512: s_memtime stamps [workgroup][wave][8] of one steady-state batch
 };
 
 typedef int i32x4 __attribute__((ext_vector_type(4)));
@@ -241,9 +245,11 @@ __global__ __launch_bounds__(WN_THREADS) void conv3x3_c64_wino_kernel(wino_args 
 #pragma unroll
     for (int xi = 0; xi < 4; ++xi) acc[s][xi] = zinit;
 
-  // The workgroup barrier of a batch sits behind its SECOND row: V of batch n + 1 (written by every wave after its first row) is then
-  // visible during the third row, whose MFMAs cover the first reads of the next batch; the three-slot ring makes that safe (the slot
-  // written in batch n + 1 was last read in batch n - 1, which every wave has left when it passes this barrier).
+  // The workgroup barrier of a batch sits behind its SECOND row for waves 4-7 (V of batch n + 1, written by every wave after its first
+  // row, is then visible during their third row, whose MFMAs cover the first reads of the next batch) and behind the THIRD row for waves
+  // 0-3.  Either way a wave has written its V fragments of batch n + 1 before it arrives, reads them only after it has passed, and
+  // the slot a wave writes in batch n + 1 (V of n + 2, slot (n + 2) % 3) was last read in batch n - 1, which every wave has left when
+  // any wave passes barrier n; a wave that is still in batch n's third row reads slot n % 3.
   auto sync = [&]() {
     if (DBG & 16) return;
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -278,6 +284,13 @@ __global__ __launch_bounds__(WN_THREADS) void conv3x3_c64_wino_kernel(wino_args 
     const u32x4 v = {s0[0], s1[0], s0[1], s1[1]};
     if (!(DBG & 4)) __builtin_amdgcn_raw_buffer_store_b128(v, ro, (int)vo, so, 0);
     else if (v[0] == 0x12345678u && v[3] == 0x9abcdef0u) __builtin_amdgcn_raw_buffer_store_b128(v, ro, (int)vo, so, 0);
+    // HAZARD (measured, gfx950): a vector instruction that overwrites a data register of a 128-bit buffer store within two wait states of
+    // it reaches the store in some lanes.  hipcc pads that case only for stores WITHOUT a scalar offset register (it takes the offset's
+    // extra issue cycle to cover it), this store has one, and the compiler did put a v_cndmask of the first data register right behind
+    // it in one path: the first store of a unit, issued into an idle memory pipeline, then wrote that 0 / 1 in lanes 12-15 of every
+    // row (tests/probe_wino_case.py; tools/check_store_hazard.py scans the assembly for the pattern).  The registers stay live, and two
+    // wait states pass, through this statement.
+    asm volatile("s_nop 1" : : "v"(v));
   };
   auto epilogue = [&](const f32x4 (&m)[4], __amdgpu_buffer_rsrc_t ro, unsigned vo, int so) {
     u32x2 x, y;
@@ -312,7 +325,12 @@ __global__ __launch_bounds__(WN_THREADS) void conv3x3_c64_wino_kernel(wino_args 
 #pragma unroll
         for (int xi = 0; xi < 4; ++xi) fv[sc][xi] = *reinterpret_cast<const f16x8_t*>(base + jj * WN_VROW + (xi * 2 + sc) * 1024);
       };
-      if (!fv_ready) {
+      unsigned long long ts[8] = {0, 0, 0, 0, 0, 0, 0, 0};      // dbg 512: batch entry, row 0 MFMAs issued, its epilogue done, mid done,
+      auto stamp = [&](int k) {                                  // row 1 + epilogue done, barrier passed, row 2 MFMAs issued, batch end
+        if (DBG & 512) asm volatile("s_memtime %0" : "=s"(ts[k]) : : "memory");
+      };
+      stamp(0);
+      if (!fv_ready || !grp_b) {      // (waves 0-3 pass the batch's barrier only at its end: nothing of this batch was theirs to prefetch)
         read_half(vbase, 0, 0);
         read_half(vbase, 0, 1);
       }
@@ -320,11 +338,15 @@ __global__ __launch_bounds__(WN_THREADS) void conv3x3_c64_wino_kernel(wino_args 
       // SIMD and would otherwise reach their MFMA runs and their vector-only epilogues together.  Waves 4-7 keep the batch's last
       // completed row in its accumulators across the barrier and convert / store it HERE, at the start of the next batch (the
       // accumulator set is re-opened by this batch's first row only after that), while their SIMD partner is in its MFMAs.
+      if (DBG & 1024) __builtin_amdgcn_s_setprio(1);
       if (grp_b) epilogue(acc[1], ro, vo, row_offset(i0 - 2));
       __builtin_amdgcn_sched_barrier(0);
       auto row = [&](auto jc) {
         constexpr int j = decltype(jc)::value;
         constexpr int s2 = (j + 2) % 3, s1 = j, s0 = (j + 1) % 3;
+        // dbg 1024 (experiment): MFMA runs at LOW issue priority, the vector / memory work behind them at HIGH priority -- the SIMD's
+        // arbiter serves priority, then age, so without this the older wave of a SIMD wins every slot and its partner trails it
+        if (DBG & 1024) __builtin_amdgcn_s_setprio(0);
 #pragma unroll
         for (int sc = 0; sc < 2; ++sc) {
           // dy = 2 first: it completes output row i0 + j - 1, whose results have then landed when the epilogue starts
@@ -341,17 +363,37 @@ __global__ __launch_bounds__(WN_THREADS) void conv3x3_c64_wino_kernel(wino_args 
           }
           __builtin_amdgcn_sched_barrier(0);
           if (j + 1 < WN_ROWS) read_half(vbase, j + 1, sc);
-          else if (chain) read_half(vnext, 0, sc);
+          else if (chain && grp_b) read_half(vnext, 0, sc);
           __builtin_amdgcn_sched_barrier(0);
         }
+        if (j == 0) stamp(1);
+        if (j == 2) stamp(6);
+        if (DBG & 1024) __builtin_amdgcn_s_setprio(1);
         if (j < 2 || !(grp_b && chain)) epilogue(acc[s2], ro, vo, row_offset(i0 + j - 1));
+        if (j == 0) stamp(2);
         if (j == 0) mid();
-        if (j == 1) sync();
+        if (j == 0) stamp(3);
+        if (j == 1) stamp(4);
+        // The batch's barrier sits at a DIFFERENT place in the two halves of the workgroup (in-kernel timeline, tools/wino_timeline.py:
+        // the SIMD's arbiter serves the older wave first, waves 0-3 reached a common barrier ~1 000 cycles ahead of their partners and
+        // idled there): waves 4-7 pass it behind their second row (and prefetch the next batch's first fragments in the third), waves 0-3
+        // only at the end of the batch -- their third row needs nothing the barrier guards.  Slot arithmetic: see `sync`.
+        if ((j == WN_BSYNC && grp_b) || (j == 2 && !grp_b)) sync();
+        if (j == 1) stamp(5);
         __builtin_amdgcn_sched_barrier(0);
       };
       row(std::integral_constant<int, 0>{});
       row(std::integral_constant<int, 1>{});
       row(std::integral_constant<int, 2>{});
+      if (DBG & 512) {
+        stamp(7);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (a.clk && n == 8 && lane == 0) {
+          unsigned long long* c = a.clk + ((long long)blockIdx.x * 8 + wave) * 8;
+#pragma unroll
+          for (int k = 0; k < 8; ++k) c[k] = ts[k];
+        }
+      }
     } else {
 #pragma unroll
       for (int j = 0; j < WN_ROWS; ++j) {
@@ -384,7 +426,7 @@ __global__ __launch_bounds__(WN_THREADS) void conv3x3_c64_wino_kernel(wino_args 
         // (a row that is not stored still issues its store, out of range: every path then has the same vector-memory sequence)
         if (j < 2 || !(grp_b && chain)) epilogue(acc[s2], ro, v2 ? vo : 0x80000000u, row_offset(r2));
         if (j == 0) mid();
-        if (j == 1) sync();
+        if ((j == WN_BSYNC && grp_b) || (j == 2 && !grp_b)) sync();
       }
     }
   };
@@ -550,7 +592,7 @@ int wino_launch(const wino_args& a, int grid, hipStream_t st) {
 // dbg: 0 (developer ablation bits otherwise, WRONG results: 1 no MFMAs, 2 no global loads, 4 no stores, 8 no epilogue arithmetic,
 // 16 no barrier)
 extern "C" int cdfo_conv3x3_c64_wino_dbg(const void* src_cp16, int B, int H, int W, const void* w_wino, const float* bias, int Cout, int act,
-                                         void* out_cp16, int store_mode, int dbg, void* stream) {
+                                         void* out_cp16, int store_mode, int dbg, void* clk_probe, void* stream) {
   hipStream_t st = static_cast<hipStream_t>(stream);
   if (B <= 0 || H <= 0 || W <= 0 || (W & 1) || Cout <= 0 || Cout % 128) return CDFO_EINVAL;
   if (act == CDFO_ACT_SIGMOID || (store_mode != CDFO_STORE_PLAIN && store_mode != CDFO_STORE_S2D && store_mode != CDFO_STORE_S2D_HS)) return CDFO_EINVAL;
@@ -576,6 +618,7 @@ extern "C" int cdfo_conv3x3_c64_wino_dbg(const void* src_cp16, int B, int H, int
   a.src = static_cast<const unsigned char*>(src_cp16); a.B = B; a.H = H; a.W = W;
   a.w = static_cast<const f16x8_t*>(w_wino); a.bias = bias; a.Cout = Cout; a.act = act;
   a.out = static_cast<_Float16*>(out_cp16); a.s2d = store_mode != CDFO_STORE_PLAIN; a.halfsplit = store_mode == CDFO_STORE_S2D_HS;
+  a.clk = static_cast<unsigned long long*>(clk_probe);
   a.seg_h = best_seg; a.nseg = (H + best_seg - 1) / best_seg; a.nstrips = nstrips; a.nb = (best_seg + 2 + 2) / 3;
   const double px = (double)B * H * W;
   CdfoProfScope prof(st, KID_CONV3_WINO, 2.0 * px * Cout * 64 * 9, 2.0 * (px * Cout + px * 64) + 2.0 * 12 * 64 * Cout);
@@ -603,6 +646,9 @@ extern "C" int cdfo_conv3x3_c64_wino_dbg(const void* src_cp16, int B, int H, int
     case 96: rc = wino_launch<96>(a, nslots * 8, st); break;
     case 128: rc = wino_launch<128>(a, nslots * 8, st); break;
     case 256: rc = wino_launch<256>(a, nslots * 8, st); break;
+    case 512: rc = wino_launch<512>(a, nslots * 8, st); break;
+    case 1024: rc = wino_launch<1024>(a, nslots * 8, st); break;
+    case 1536: rc = wino_launch<1536>(a, nslots * 8, st); break;
     default: return CDFO_EINVAL;
   }
   if (rc) return rc;
@@ -612,7 +658,7 @@ extern "C" int cdfo_conv3x3_c64_wino_dbg(const void* src_cp16, int B, int H, int
 
 extern "C" int cdfo_conv3x3_c64_wino(const void* src_cp16, int B, int H, int W, const void* w_wino, const float* bias, int Cout, int act,
                                      void* out_cp16, int store_mode, void* stream) {
-  return cdfo_conv3x3_c64_wino_dbg(src_cp16, B, H, W, w_wino, bias, Cout, act, out_cp16, store_mode, 0, stream);
+  return cdfo_conv3x3_c64_wino_dbg(src_cp16, B, H, W, w_wino, bias, Cout, act, out_cp16, store_mode, 0, nullptr, stream);
 }
 
 // Block_'s double-resolution branch without its double-resolution source: src_lr_cp16 [B][4][H/2][W/2][16] = up.0(x) (cdfo_block_prologue2's
@@ -620,5 +666,5 @@ extern "C" int cdfo_conv3x3_c64_wino(const void* src_cp16, int B, int H, int W, 
 extern "C" int cdfo_conv3x3_c64_wino_up2(const void* src_lr_cp16, int B, int H, int W, const void* w_wino, const float* bias, int Cout, int act,
                                          void* out_cp16, int store_mode, void* stream) {
   if ((H & 3) || (W & 3) || (store_mode != CDFO_STORE_S2D && store_mode != CDFO_STORE_S2D_HS)) return CDFO_EINVAL;
-  return cdfo_conv3x3_c64_wino_dbg(src_lr_cp16, B, H, W, w_wino, bias, Cout, act, out_cp16, store_mode, -1, stream);
+  return cdfo_conv3x3_c64_wino_dbg(src_lr_cp16, B, H, W, w_wino, bias, Cout, act, out_cp16, store_mode, -1, nullptr, stream);
 }

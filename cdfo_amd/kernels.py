@@ -362,7 +362,7 @@ def halfsplit_to_rows(t: torch.Tensor) -> torch.Tensor:
 
 
 def conv3x3_wino(src: torch.Tensor, pc: PackedConv, *, act: int = ACT_NONE, s2d: bool = False,
-                 out: Optional[torch.Tensor] = None, dbg: int = 0, halfsplit: bool = False) -> torch.Tensor:
+                 out: Optional[torch.Tensor] = None, dbg: int = 0, halfsplit: bool = False, clk: Optional[torch.Tensor] = None) -> torch.Tensor:
     """conv3x3_ws's operands and result on the row-streaming Winograd F(2,3) kernel (cdfo_conv3x3_c64_wino): Cout % 128 == 0, W even."""
     if not src.is_cuda:
         raise NotImplementedError("conv3x3_wino: the HIP path needs device tensors (no CPU fallback)")
@@ -381,7 +381,7 @@ def conv3x3_wino(src: torch.Tensor, pc: PackedConv, *, act: int = ACT_NONE, s2d:
     mode = (5 if halfsplit else 2) if s2d else 0
     if dbg:      # developer ablations (tools/bench_wino.py): wrong results by construction
         check(_lib.lib().cdfo_conv3x3_c64_wino_dbg(_vp(src), B, H, W, _vp(pc.ww), _vp(pc.bias), pc.Cout, act, _vp(out), mode,
-                                                   dbg, _stream()), "cdfo_conv3x3_c64_wino_dbg")
+                                                   dbg, _vp(clk), _stream()), "cdfo_conv3x3_c64_wino_dbg")
         return out
     check(_lib.lib().cdfo_conv3x3_c64_wino(_vp(src), B, H, W, _vp(pc.ww), _vp(pc.bias), pc.Cout, act, _vp(out), mode,
                                            _stream()), "cdfo_conv3x3_c64_wino")

@@ -126,7 +126,8 @@ int cdfo_conv3x3_c64_wino(const void* src_cp16, int B, int H, int W, const void*
                           void* out_cp16, int store_mode, void* stream);
 int cdfo_pack_conv3x3_wino(const float* w_oihw, void* packed, int Cout, void* stream);
 /* the same call with developer ablation bits (dbg != 0: WRONG results; 1 no MFMAs, 2 no global loads, 4 no stores, 8 no epilogue
- * arithmetic, 16 no barrier): tools/bench_wino.py */
+ * arithmetic, 16 no barrier; 512 = timeline probe: clk_probe receives s_memtime stamps [workgroup][wave][8] of one steady-state
+ * batch, 64-bit words, else NULL): tools/bench_wino.py, tools/wino_timeline.py */
 /* Block_'s double-resolution branch (arch.py:398-404: body(up(x))) without its double-resolution source: src_lr_cp16
  * [B][4][H/2][W/2][16] = up.0(x) at the block's resolution (cdfo_block_prologue2's t16); H x W (multiples of 4) = the size of the x2
  * image the convolution runs on.  The bilinear x2 (align_corners = False, clamped taps; the convolution pads the x2 image with zeros)
@@ -135,7 +136,7 @@ int cdfo_pack_conv3x3_wino(const float* w_oihw, void* packed, int Cout, void* st
 int cdfo_conv3x3_c64_wino_up2(const void* src_lr_cp16, int B, int H, int W, const void* w_wino, const float* bias, int Cout, int act,
                               void* out_cp16, int store_mode, void* stream);
 int cdfo_conv3x3_c64_wino_dbg(const void* src_cp16, int B, int H, int W, const void* w_wino, const float* bias, int Cout, int act,
-                              void* out_cp16, int store_mode, int dbg, void* stream);
+                              void* out_cp16, int store_mode, int dbg, void* clk_probe, void* stream);
 /* MVDualAttAlignment's conv_offset[2] (3x3, 64 -> Cout = 27 dg, arch/SIDECVSR_our.py:3285-3289) on the weights-stationary kernel with
  * the module's offset / mask assembly (arch.py:3336-3350) as its epilogue -- the CDFO_STORE_OFFMASK contract of cdfo_conv_args above,
  * single-pass fp16 operands (src fp16 chunk-planar [B][4][H][W][16], weights from cdfo_pack_conv3x3_f16 with CoutP padded channels):

@@ -47,6 +47,7 @@ struct qd_args {
   float eps;
   float* out; int ldo;
   float* gram; int nslot;       // optional [B][nslot][640]: fused Gram pass; `out` then receives v only (64 channels)
+  unsigned long long* clk;      // developer timeline (cdfo_qkv_dw_probe): 8 s_memtime stamps per wave of one steady-state step
 };
 
 __global__ __launch_bounds__(QD_THREADS) void qkv_dw_kernel(qd_args a) {
@@ -315,6 +316,7 @@ __device__ __forceinline__ float q2_sum16(float v) {
   return v;
 }
 
+template <bool TL = false>      // TL: timeline stamps (developer probe)
 __global__ __launch_bounds__(Q2_THREADS) void qkv_dw2_kernel(qd_args a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   float* const ring = reinterpret_cast<float*>(smem);
@@ -446,6 +448,11 @@ __global__ __launch_bounds__(Q2_THREADS) void qkv_dw2_kernel(qd_args a) {
     // instruction stream -- and with it the compiler's count of loads and stores in flight -- is the same on every trip.
     auto step = [&](int hy, f32x4& xr) {      // xr holds row hy + 1's pixels and receives row hy + 3's
       const int slot = (hy - (ya - 2)) & (Q2_RING - 1);
+      unsigned long long ts[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+      auto stamp = [&](int k) {
+        if (TL) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(ts[k]) : : "memory");
+      };
+      stamp(0);
       {   // (a)
         const float mean = q2_sum16((xr[0] + xr[1]) + (xr[2] + xr[3])) * (1.f / 64.f);
         float sq = 0.f;
@@ -465,6 +472,7 @@ __global__ __launch_bounds__(Q2_THREADS) void qkv_dw2_kernel(qd_args a) {
         *reinterpret_cast<q2_bf16x4*>(dst) = vh;
         *reinterpret_cast<q2_bf16x4*>(dst + Q2_FPX / 2) = vl;
       }
+      stamp(1);
       {   // (b): zero outside the image = the depthwise convolution's padding
         const unsigned char* src = fr_r + (hy & 1) * Q2_FROW;
         q2_bf16x8 bh[2], bl[2];
@@ -489,12 +497,15 @@ __global__ __launch_bounds__(Q2_THREADS) void qkv_dw2_kernel(qd_args a) {
           *reinterpret_cast<f32x4*>(yrow + 16 * (ct0 + j)) = v;
         }
       }
+      stamp(2);
       __syncthreads();
+      stamp(3);
       {   // (d): input row hy completes output row hy - 1
         const float* yr = ring + slot * (Q2_ROWB / 4) + (3 * pb) * Q2_YP + cg;
         f32x4 col[5];
 #pragma unroll
         for (int c = 0; c < 5; ++c) col[c] = *reinterpret_cast<const f32x4*>(yr + c * Q2_YP);
+        stamp(4);
         const int oy = hy - 1;
         const bool row_ok = oy >= ya && oy < yb;
         f32x4 o[3];
@@ -514,6 +525,7 @@ __global__ __launch_bounds__(Q2_THREADS) void qkv_dw2_kernel(qd_args a) {
 #pragma unroll
           for (int i = 0; i < 3; ++i) *reinterpret_cast<f32x4*>(vs + i * Q2_VPX) = o[i];
         }
+        stamp(5);
         // Gram: q lanes take own q x the partner's k, k lanes own k x the partner's q (16 products + 4 squares per lane, summed
         // over the lane's three pixels); v lanes run the exchange with their own values and skip the sums
 #pragma unroll
@@ -531,6 +543,7 @@ __global__ __launch_bounds__(Q2_THREADS) void qkv_dw2_kernel(qd_args a) {
           }
         }
       }
+      stamp(6);
       {   // (e): v row hy - 2, 256 contiguous bytes per pixel (16 lanes), dropped by the hardware where there is nothing to write
         const int oy = hy - 2;
         const f32x4 v = *reinterpret_cast<const f32x4*>(sV + (oy & 1) * (Q2_VROW / 4) + spx * Q2_VPX + 4 * sq16);
@@ -538,6 +551,14 @@ __global__ __launch_bounds__(Q2_THREADS) void qkv_dw2_kernel(qd_args a) {
         const unsigned vo = st ? (unsigned)(((oy * W + x0 + spx) * a.ldo + 4 * sq16) * 4) : 0x80000000u;
         typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r_out, (int)vo, 0, 0);
+      }
+      if (TL) {
+        stamp(7);
+        if (a.clk && u == blockIdx.x * per && hy == ya + 24 && lane == 0) {
+          unsigned long long* c = a.clk + ((long long)blockIdx.x * 8 + wave) * 8;
+#pragma unroll
+          for (int k = 0; k < 8; ++k) c[k] = ts[k];
+        }
       }
     };
     // two rows per trip, so that the two x registers swap roles without copies (a copy would wait for the load it renames); a
@@ -553,6 +574,11 @@ __global__ __launch_bounds__(Q2_THREADS) void qkv_dw2_kernel(qd_args a) {
 }  // namespace
 
 static int qd_cu_count() { return cdfo_num_cus(); }     // of the current device
+
+// developer probe: a device buffer of [workgroups][8 waves][8] uint64 for the row-streaming kernel's timeline (tools/qkv_timeline.py);
+// NULL switches it off again
+static unsigned long long* g_q2_clk = nullptr;
+extern "C" void cdfo_qkv_dw_probe(void* clk) { g_q2_clk = static_cast<unsigned long long*>(clk); }
 
 // Number of per-image slots the fused Gram pass needs for these shapes on this device (>= 1): the workgroups of the
 // row-streaming kernel take contiguous unit ranges, an image is touched by ceil(units per image / units per workgroup) + 1 of them.
@@ -581,6 +607,7 @@ extern "C" int cdfo_qkv_dw(const float* x, int ldx, int B, int H, int W, const v
   const long long ntiles = (long long)B * cdiv(H, QD_TR) * cdiv(W, QD_TC);
   const int grid = (int)(ntiles < cus ? ntiles : cus);
   qd_args a;
+  a.clk = nullptr;
   a.x = x; a.ldx = ldx; a.B = B; a.H = H; a.W = W;
   a.w = static_cast<const unsigned short*>(w_bf16); a.bias = bias; a.dw = dw_w; a.eps = eps; a.out = out; a.ldo = ldo; a.gram = gram; a.nslot = gram_slots;
   const double px = (double)B * H * W;
@@ -588,11 +615,20 @@ extern "C" int cdfo_qkv_dw(const float* x, int ldx, int B, int H, int W, const v
   if (gram) {       // the row-streaming kernel (qkv_dw2); the tiled one keeps the 192-channel form
     if (gram_slots < cdfo_qkv_dw_gram_slots(B, H, W)) return CDFO_EINVAL;
     if ((long long)H * W * ldo * 4 >= (1ll << 31)) return CDFO_EINVAL;      // per-image buffer descriptor of the v stores
-    static CdfoAttrOnce once2;
-    const hipError_t e2 = cdfo_set_max_lds(once2, reinterpret_cast<const void*>(qkv_dw2_kernel), Q2_LDS);
-    if (e2 != hipSuccess) return (int)e2;
     const q2_geom G = q2_geometry(H, W);
-    hipLaunchKernelGGL(qkv_dw2_kernel, dim3(q2_grid((long long)B * G.upi, cus)), dim3(Q2_THREADS), Q2_LDS, st, a);
+    a.clk = g_q2_clk;
+    if (g_q2_clk) {
+      static CdfoAttrOnce once3;
+      const hipError_t e3 = cdfo_set_max_lds(once3, reinterpret_cast<const void*>(qkv_dw2_kernel<true>), Q2_LDS);
+      if (e3 != hipSuccess) return (int)e3;
+      hipLaunchKernelGGL(qkv_dw2_kernel<true>, dim3(q2_grid((long long)B * G.upi, cus)), dim3(Q2_THREADS), Q2_LDS, st, a);
+      CDFO_LAUNCH_CHECK();
+      return 0;
+    }
+    static CdfoAttrOnce once2;
+    const hipError_t e2 = cdfo_set_max_lds(once2, reinterpret_cast<const void*>(qkv_dw2_kernel<false>), Q2_LDS);
+    if (e2 != hipSuccess) return (int)e2;
+    hipLaunchKernelGGL(qkv_dw2_kernel<false>, dim3(q2_grid((long long)B * G.upi, cus)), dim3(Q2_THREADS), Q2_LDS, st, a);
     CDFO_LAUNCH_CHECK();
     return 0;
   }

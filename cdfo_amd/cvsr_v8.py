@@ -604,8 +604,18 @@ class CVSR_V8(nn.Module):
                 self._probe = None
                 return self._forward(x, mvs0, mvs1, pms, rms, ufs, pre_L1_fea, noise)
             if torch.cuda.is_current_stream_capturing():
-                raise RuntimeError("CVSR_V8 (HIP): the fp16 range guard reads probes back and cannot be captured; use model.capture(), "
-                                   "which checks an eager forward first and captures with the guard off")
+                gp = self.__dict__.get("_graph_probe")
+                if gp is None:
+                    raise RuntimeError("CVSR_V8 (HIP): the fp16 range guard reads probes back and cannot be captured by hand; use "
+                                       "model.capture(), whose graph carries the two probes and whose replay() reads them back")
+                # model.capture() (graph.py): the probes are graph nodes -- zeroed, filled by the two probe kernels, copied to pinned host
+                # memory behind the last kernel; CapturedForward.replay() reads them and repeats a rejected forward eagerly in bf16x3
+                gp.zero_()
+                self._probe, self._guard_events = gp, None
+                try:
+                    return self._forward(x, mvs0, mvs1, pms, rms, ufs, pre_L1_fea, noise)
+                finally:
+                    self._probe = None
             # fp16 range guard: the fp16x2 mode keeps the trunk's tensors (and the alignment's residual blocks) in fp16.  Outside
             # fp16's comfortable range -- max |trunk input| not in [2^-6, 2^11], or a NaN / infinity in the trunk's input or output
             # (what an overflowed fp16 store turns into) -- the forward is repeated in the split-bf16 mode (fp32 exponent range,
@@ -732,7 +742,9 @@ class CVSR_V8(nn.Module):
         """Capture one inference forward at these operands' shapes into a HIP graph (opt-in; fixed shapes).  Returns a
         ``cdfo_amd.graph.CapturedForward``: ``cap(x, mvs0, ...)`` copies the operands into the graph's input buffers, refreshes
         the device-side Philox key (fresh Gumbel noise per replay, arch.py:2169) and replays; it returns graph-owned
-        ``(out, L1_fea)`` buffers that the next replay overwrites.  Same launches as the eager path: bit-identical outputs."""
+        ``(out, L1_fea)`` buffers that the next replay overwrites.  Same launches as the eager path: bit-identical outputs.  In the
+        fp16x2 mode with the range guard on, the graph carries the guard's two probes and ``replay()`` reads them back (a rejected
+        forward is repeated eagerly in bf16x3 into the graph's output buffers), see graph.py."""
         from .graph import CapturedForward
         return CapturedForward(self, x, mvs0, mvs1, pms, rms, ufs, pre_L1_fea, gumbel_uniform, check_range)
 

@@ -10,8 +10,12 @@ What makes a capture of THIS model correct (the pieces were built for ``Streamin
   kernel therefore reads its Philox key from a device word (``cdfo_rdab_prep_rng_dev``) that ``refresh_noise_key`` rewrites
   before every replay -- torch's default generator advances once per forward exactly as in the eager loop, so a run under
   ``torch.manual_seed`` produces the same frames eagerly and from the graph;
-* the fp16 range guard is a host readback and cannot live inside a graph: ``capture`` runs ONE eager, guarded forward on the
-  example inputs first and refuses to capture a workload whose activations leave the fp16 window (use ``precision="bf16x3"``);
+* the fp16 range guard: ``capture`` runs ONE eager, guarded forward on the example inputs first and refuses to capture a workload
+  whose activations leave the fp16 window (use ``precision="bf16x3"``).  Round 5: the two probes of the guard (trunk input, trunk
+  output) are graph nodes too -- zeroed, filled by the probe kernels, copied to pinned host memory behind the last kernel -- and
+  ``replay()`` reads them back: a replay on operands that leave the window is repeated eagerly in bf16x3 INTO the graph's output
+  buffers, exactly what the eager forward does.  ``replay(sync=False)`` returns without waiting (pipelined callers); the check
+  then runs at the start of the next replay, in ``finish_range_guard()`` or when ``last_range`` is read;
 * the caller sees graph-owned buffers: ``inputs`` (write the next batch there, or pass tensors to ``__call__`` and they are
   copied in) and the returned ``(out, L1_fea)``, which the NEXT replay overwrites -- ``clone()`` what must outlive it.
 """
@@ -66,9 +70,25 @@ class CapturedForward:
         self._refresh = getattr(model, "refresh_noise_key", None) if self.draws_noise else None
         if self._refresh is not None:
             self._refresh(self.dev)
+        # the guard's probes inside the graph (CVSR_V8.forward's capturing branch reads model._graph_probe)
+        self.guarded = bool(check_range and getattr(model, "precision", None) == "fp16x2" and getattr(model, "range_guard", False)
+                            and hasattr(model, "_range_fallback"))
+        self._pending, self._seed, self.last_range_seen = False, None, None
+        if self.guarded:
+            self._probe = torch.zeros(4, dtype=torch.int32, device=self.dev)
+            self._probe_host = torch.zeros(4, dtype=torch.int32).pin_memory()
+            self._ev = torch.cuda.Event()
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph), torch.no_grad():
-            self.out, self.L1_fea = call(guard=False)
+            if self.guarded:
+                model._graph_probe = self._probe
+            try:
+                self.out, self.L1_fea = call(guard=True if self.guarded else False)
+            finally:
+                if self.guarded:
+                    model._graph_probe = None
+            if self.guarded:
+                self._probe_host.copy_(self._probe, non_blocking=True)
         torch.cuda.set_rng_state(rng_state, self.dev)
 
     def load(self, x=None, mvs0=None, mvs1=None, pms=None, rms=None, ufs=None, pre_L1_fea=None, gumbel_uniform=None) -> None:
@@ -85,12 +105,48 @@ class CapturedForward:
                 raise ValueError(f"captured for shape {tuple(dst.shape)}, got {tuple(src.shape)}")
             dst.copy_(src)
 
-    def replay(self):
-        """One forward on whatever the input buffers hold.  Returns the graph-owned (out, L1_fea)."""
+    def replay(self, sync: bool = True):
+        """One forward on whatever the input buffers hold.  Returns the graph-owned (out, L1_fea).  With the range guard in the
+        graph (fp16x2): sync=True waits for the forward and settles the guard before returning -- what is returned is final;
+        sync=False returns at once, the guard of THIS replay is settled by the next replay / finish_range_guard() / last_range."""
+        self.finish_range_guard()
         if self._refresh is not None:
-            self._refresh(self.dev)
+            self._seed = self._refresh(self.dev)
         self.graph.replay()
+        if self.guarded:
+            self._ev.record()
+            self._pending = True
+            if sync:
+                self.finish_range_guard()
         return self.out, self.L1_fea
+
+    def finish_range_guard(self) -> None:
+        """Read the probes of the last replay (waits for it); operands outside the fp16 window, or a non-finite trunk result: the
+        forward is repeated eagerly in bf16x3 on the graph's input buffers (same noise key) into the graph's output buffers."""
+        if not getattr(self, "_pending", False):
+            return
+        self._pending = False
+        self._ev.synchronize()
+        h = self._probe_host
+        amax = h[0:1].view(torch.float32).item()
+        nonfinite = bool(h[1].item()) or bool(h[3].item())
+        m = self.model
+        self.last_range_seen = {"trunk_input_amax": amax, "nonfinite": nonfinite, "fallback": False}
+        lo, hi = m.FP16_WINDOW
+        if not nonfinite and (amax == 0.0 or lo <= amax <= hi):
+            return
+        ins = self.inputs
+        m._last_range = self.last_range_seen
+        args = (ins[0], ins[1], ins[2], ins[3], ins[4], ins[5], ins[6], None if self._nnoise == 0 else ins[7:],
+                self._seed if self._seed is not None else 0)
+        with torch.cuda.device(self.dev):
+            m._range_fallback(args, self.out, self.L1_fea)
+
+    @property
+    def last_range(self):
+        """What the in-graph range guard saw in the most recent replay (settles it first); None without a guard."""
+        self.finish_range_guard()
+        return self.last_range_seen
 
     def __call__(self, x=None, mvs0=None, mvs1=None, pms=None, rms=None, ufs=None, pre_L1_fea=None, gumbel_uniform=None):
         self.load(x, mvs0, mvs1, pms, rms, ufs, pre_L1_fea, gumbel_uniform)

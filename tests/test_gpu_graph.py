@@ -92,6 +92,44 @@ def test_capture_is_the_inference_schedule_and_refuses_out_of_range_examples():
     assert torch.equal(cap.replay()[0], want)
 
 
+
+def test_captured_forward_carries_the_fp16_range_guard():
+    """Round 5: the guard's two probes are nodes of the captured graph and replay() reads them back.  A replay on operands that
+    push the trunk's input out of the fp16 window is repeated eagerly in bf16x3 INTO the graph's output buffers -- the result the
+    eager, guarded forward returns for the same operands and noise, bit for bit -- and the next replay on ordinary operands is the
+    fp16x2 graph again."""
+    m = _model(25)
+    d, n = _inputs(1, 16, 24, 540)
+    rest = (d["mvs0"], d["mvs1"], d["pms"], d["rms"], d["ufs"])
+    xs = d["x"] * 2.0 ** 13
+    with torch.no_grad():
+        cap = m.capture(d["x"], *rest, gumbel_uniform=n)
+        assert cap.guarded
+        want0, _ = m(d["x"], *rest, gumbel_uniform=n)
+        got0, _ = cap.replay()
+        assert cap.last_range["fallback"] is False and cap.last_range["trunk_input_amax"] > 0
+        assert torch.equal(got0, want0)
+        with pytest.warns(UserWarning, match="fp16 range"):
+            want, want_l1 = m(xs, *rest, gumbel_uniform=n)
+            m.finish_range_guard()
+        assert m.last_range["fallback"], f"scenario drifted: {m.last_range}"
+        want, want_l1 = want.clone(), want_l1.clone()
+        m._warned_range = False
+        with pytest.warns(UserWarning, match="fp16 range"):
+            got, got_l1 = cap(xs, *rest, gumbel_uniform=n)
+        torch.cuda.synchronize()
+        assert cap.last_range["fallback"]
+        assert torch.equal(got, want) and torch.equal(got_l1, want_l1)
+        # ordinary operands again: the graph's own result stands
+        got2, _ = cap(d["x"], *rest, gumbel_uniform=n)
+        assert cap.last_range["fallback"] is False and torch.equal(got2, want0)
+        # sync=False: the check is deferred to finish_range_guard() / last_range / the next replay
+        cap.load(xs)
+        out3, _ = cap.replay(sync=False)
+        assert cap._pending
+        assert cap.last_range["fallback"] and torch.equal(out3, want)
+
+
 def test_v7_replay_with_injected_noise_matches_eager():
     """`CVSR_V7.capture` (round 5): the ~1 000 launches of a V7 forward (three pyramid levels x twelve neighbour pipelines on side
     streams) replayed from one HIP graph give the eager forward's result on the captured and on new operands."""

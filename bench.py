@@ -144,6 +144,10 @@ def parse_args(argv=None):
     ap.add_argument("--batch", type=int, default=8, help="clips per GPU")
     ap.add_argument("--height", type=int, default=270)
     ap.add_argument("--width", type=int, default=480)
+    ap.add_argument("--launch", default="graph", choices=["graph", "eager"],
+                    help="how the timed step is launched: graph = CVSR_V8.capture() once, then per step the operands are copied into the "
+                         "graph's buffers, a fresh noise key is written, the HIP graph is replayed and its range-guard probes are read back; "
+                         "eager = one host launch per kernel (both run the same kernels: bit-identical outputs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true", help="skip the c1 parity spot-check (profiling runs: keeps every launch at the workload's size)")
     ap.add_argument("--precision", default="fp16x2", choices=["f32", "bf16x3", "bf16", "fp16x2"])
@@ -226,8 +230,13 @@ def main():
         with torch.no_grad():
             _, pre = model(d["x"], d["mvs0"], d["mvs1"], d["pms"], d["rms"], d["ufs"], gumbel_uniform=injected)
 
-    def step(noise=injected):
+    graph = {"cap": None}     # the captured forward of the timed configuration (--launch graph), built behind the parity forward
+
+    def step(noise=injected, eager=False):
         with torch.no_grad():
+            if graph["cap"] is not None and not eager and noise is injected:
+                # copies the operands into the graph's buffers, refreshes the noise key, replays, reads the range guard's probes back
+                return graph["cap"](d["x"], d["mvs0"], d["mvs1"], d["pms"], d["rms"], d["ufs"], pre, injected)
             return model(d["x"], d["mvs0"], d["mvs1"], d["pms"], d["rms"], d["ufs"], pre, gumbel_uniform=noise)
 
     def barrier():
@@ -235,11 +244,11 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def timed(nsteps, noise=injected):
+    def timed(nsteps, noise=injected, eager=False):
         barrier()
         t0 = time.perf_counter()
         for _ in range(nsteps):
-            o, _ = step(noise)
+            o, _ = step(noise, eager)
         barrier()
         return time.perf_counter() - t0, o
 
@@ -287,16 +296,48 @@ def main():
             else:
                 parity_cfg = small + " -- small-config only (--no-full-size-parity)"
 
+    # ---- --launch graph: the forward of the timed configuration captured once (cdfo_amd/graph.py); a replay must BE the eager forward:
+    # both run once under the same generator seed and their images are compared bit for bit before anything is timed
+    launch_info = {"mode": "eager"}
+    if args.launch == "graph" and args.precision != "f32":
+        try:
+            with torch.no_grad():
+                cap_fwd = model.capture(d["x"], d["mvs0"], d["mvs1"], d["pms"], d["rms"], d["ufs"], pre, gumbel_uniform=injected)
+            torch.manual_seed(4242 + rank)
+            e_out, _ = step(eager=True)
+            e_out = e_out.clone()
+            graph["cap"] = cap_fwd
+            torch.manual_seed(4242 + rank)
+            g_out, _ = step()
+            torch.cuda.synchronize()
+            same = bool(torch.equal(e_out, g_out))
+            del e_out, g_out
+            if not same:
+                raise SystemExit("bench.py: the replayed HIP graph and the eager forward differ under the same seed")
+            launch_info = {"mode": "hip_graph", "replay_equals_eager_bitwise": True, "range_guard_in_graph": bool(cap_fwd.guarded),
+                           "per_step": "operands copied into the graph's buffers, fresh Philox key, hipGraphLaunch, probes of the fp16 "
+                                       "range guard read back (host waits for the forward)"}
+        except SystemExit:
+            raise
+        except Exception as e:                                # no graph on this box / shape: the eager path is timed, and the line says so
+            graph["cap"] = None
+            launch_info = {"mode": "eager", "graph_capture_failed": repr(e)[:300]}
+
     for _ in range(args.warmup):
         step()
     elapsed, out = timed(args.steps)                      # the headline: no per-launch instrumentation
-    range_info = getattr(model, "last_range", None)
+    range_info = (graph["cap"].last_range if graph["cap"] is not None and graph["cap"].guarded else getattr(model, "last_range", None))
+    if graph["cap"] is not None:                          # the same steps launched kernel by kernel, for the record
+        step(eager=True)
+        elapsed_eager, _ = timed(args.steps, eager=True)
+        launch_info["eager_ms_per_step"] = round(1e3 * elapsed_eager / args.steps, 3)
+        launch_info["eager_frames_per_s"] = round(B * args.steps / elapsed_eager, 3)
 
     # ---- second pass over the same steps with one HIP-event pair per launch: per-kernel durations for the roofline
     nk = lib.cdfo_prof_kid_count()
     cap_records = 4000 * max(1, args.steps)
     _lib.check(lib.cdfo_prof_begin(cap_records), "cdfo_prof_begin")
-    elapsed_prof, _ = timed(args.steps)
+    elapsed_prof, _ = timed(args.steps, eager=True)       # (events are recorded around host launches: the eager path)
     launches = (C.c_int * nk)()
     ms = (C.c_double * nk)()
     fl = (C.c_double * nk)()
@@ -312,15 +353,15 @@ def main():
     if world == 1 and not args.no_extra_modes and not args.streaming:
         nst = max(2, min(args.steps, 5))
         other_noise = None if args.injected_noise else [u.to(dev) for u in inp["gumbel_u"]]
-        step(other_noise)
-        t, _ = timed(nst, other_noise)
+        step(other_noise, eager=True)
+        t, _ = timed(nst, other_noise, eager=True)
         extra["injected_noise_path" if not args.injected_noise else "default_noise_path"] = {
             "frames_per_s": round(B * nst / t, 3), "ms_per_step": round(1e3 * t / nst, 3), "steps": nst}
         del other_noise
         if args.precision != "bf16x3":
             model.precision = "bf16x3"
-            step()
-            t, _ = timed(nst)
+            step(eager=True)
+            t, _ = timed(nst, eager=True)
             extra["bf16x3_fp32_grade"] = {"frames_per_s": round(B * nst / t, 3), "ms_per_step": round(1e3 * t / nst, 3),
                                           "steps": nst, "note": "split-bf16 3-pass MFMA everywhere: <= 1.2e-5 max-abs vs the fp32 reference"}
             model.precision = args.precision
@@ -328,8 +369,8 @@ def main():
             # BASELINE's literal c3 dtype: plain bf16 MFMA (one rounding of activations and weights, fp32 accumulate) on the same
             # batch, replaying the noise of the parity forward so that clip 0 compares with the same oracle output (below)
             model.precision = "bf16"
-            gb, _ = step(cap_full)
-            t, _ = timed(nst, cap_full)
+            gb, _ = step(cap_full, eager=True)
+            t, _ = timed(nst, cap_full, eager=True)
             g0_bf16 = gb[0:1].cpu()
             extra["bf16_plain"] = {"frames_per_s": round(B * nst / t, 3), "ms_per_step": round(1e3 * t / nst, 3), "steps": nst}
             model.precision = args.precision
@@ -407,7 +448,7 @@ def main():
         wf = F * B * args.steps / t_max / 1e12
         roofline = {"bound": "mfma", **fam(dom), "traffic": traffic, "traffic_stale": traffic_is_stale,
                     "whole_forward_tflops": round(wf, 2), "whole_forward_frac": round(wf / PEAK_TFLOPS[args.precision], 4),
-                    "measured_in": f"second pass over the same {args.steps} steps with one HIP-event pair per launch on the launch "
+                    "measured_in": f"second pass over the same {args.steps} steps, launched eagerly, with one HIP-event pair per launch on the launch "
                                    f"stream ({round(1e3 * allm[:, 4].max().item() / args.steps, 3)} ms per step with the events)",
                     # the other matrix-core convolution kernels of the step, same definitions (not the headline entry)
                     "other_mfma_kernels": [fam(k) for k in range(nk) if KID_NAMES[k] in MFMA16 and k != dom and launches[k]],
@@ -431,7 +472,8 @@ def main():
                                    f"{4 * args.height}x{4 * args.width}, " + ("streaming path (pre_L1_fea cache hit)" if args.streaming else "fresh path (pre_L1_fea=None)") + f", precision={args.precision}, "
                                    + ("pre-made Gumbel noise tensors" if args.injected_noise else "Gumbel noise drawn per forward inside the mask kernel (the reference's default behaviour)"),
                        "clips_per_gpu": B, "lr_padded": [Hp, Wp], "parallelism": f"batch-shard x{world}",
-                       "weights": "random init (seed 0)"},
+                       "weights": "random init (seed 0)", "launch": launch_info["mode"]},
+            "launch": launch_info,
             "parity": {"config": parity_cfg, "max_abs": max_abs, "psnr_y_db": psnr, "bound": PARITY_BOUND,
                        "verified": bool(parity_ok and not args.no_parity),
                        "per_rank_max_abs": [float(v) for v in allm[:, 2]],

@@ -4,7 +4,7 @@
 set -o pipefail
 R=${R:-r05}; COMMIT=${COMMIT:-unknown}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT && O=gpurun_out/prof && mkdir -p $O
-B="python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-parity --no-extra-modes"
+B="python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-parity --no-extra-modes --launch eager"
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- $B > $O/stats.log 2>&1 && \
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/fetch -- $B > $O/fetch.log 2>&1 && \
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/write -- $B > $O/write.log 2>&1 && \

@@ -748,6 +748,13 @@ class CVSR_V8(nn.Module):
         from .graph import CapturedForward
         return CapturedForward(self, x, mvs0, mvs1, pms, rms, ufs, pre_L1_fea, gumbel_uniform, check_range)
 
+    def capture_pipelined(self, x, mvs0, mvs1, pms, rms, ufs, pre_L1_fea=None, gumbel_uniform=None, check_range: bool = True):
+        """Two alternating captured forwards (``cdfo_amd.graph.PipelinedForward``): ``submit(...)`` launches a forward and reads the
+        PREVIOUS forward's range-guard probes afterwards, so the GPU never waits for a graph launch between forwards of a stream of
+        batches.  Results of a ``submit`` are final once the next ``submit`` / ``drain()`` has returned."""
+        from .graph import PipelinedForward
+        return PipelinedForward(self, x, mvs0, mvs1, pms, rms, ufs, pre_L1_fea, gumbel_uniform, check_range)
+
     def refresh_noise_key(self, device=None) -> int:
         """Write a fresh Philox key (advancing torch's default generator like an eager forward does) into the device word that
         CAPTURED forwards read: call before capturing and before every replay of a HIP graph of this model, so that each

@@ -151,3 +151,47 @@ class CapturedForward:
     def __call__(self, x=None, mvs0=None, mvs1=None, pms=None, rms=None, ufs=None, pre_L1_fea=None, gumbel_uniform=None):
         self.load(x, mvs0, mvs1, pms, rms, ufs, pre_L1_fea, gumbel_uniform)
         return self.replay()
+
+
+class PipelinedForward:
+    """Two captured forwards of the same model and shapes, used alternately on one stream.  Each has its OWN memory pool: with a
+    shared pool the second graph's outputs land in memory the first graph uses for intermediates, and a result would be overwritten
+    by the next forward before it has been checked and consumed (measured: tests/probe_pipe.py) -- twice the activation memory of one
+    forward (2 x ~20 GB at eight clips of 272x480) is the price.
+
+    ``CapturedForward.replay()`` either waits for the forward before it returns (the range guard's probes are a host readback), or
+    leaves the check to the next replay -- which then waits before it launches.  Either way the GPU idles for the launch latency of a
+    ~700-node graph once per forward (~1.4 ms at eight clips).  With two graphs, forward k + 1 is launched FIRST and forward k's probes
+    are read afterwards; k's operands and results live in the other graph's buffers, so a forward the guard rejects is still repeated
+    in bf16x3 into the tensors ``submit`` returned for it.
+
+    ``submit(...)`` returns graph-owned ``(out, L1_fea)`` of the forward it launched; they are FINAL once the next ``submit`` (or
+    ``drain()``) has returned, and are overwritten by the submit after that."""
+
+    def __init__(self, model, x, mvs0, mvs1, pms, rms, ufs, pre_L1_fea=None, gumbel_uniform: Optional[Sequence] = None,
+                 check_range: bool = True):
+        a = CapturedForward(model, x, mvs0, mvs1, pms, rms, ufs, pre_L1_fea, gumbel_uniform, check_range)
+        b = CapturedForward(model, x, mvs0, mvs1, pms, rms, ufs, pre_L1_fea, gumbel_uniform, check_range)
+        self.caps, self.k = (a, b), 0
+
+    @property
+    def guarded(self) -> bool:
+        return self.caps[0].guarded
+
+    def submit(self, x=None, mvs0=None, mvs1=None, pms=None, rms=None, ufs=None, pre_L1_fea=None, gumbel_uniform=None):
+        cap, prev = self.caps[self.k & 1], self.caps[(self.k + 1) & 1]
+        self.k += 1
+        cap.load(x, mvs0, mvs1, pms, rms, ufs, pre_L1_fea, gumbel_uniform)
+        res = cap.replay(sync=False)          # (its own previous forward was settled two submits ago)
+        prev.finish_range_guard()             # the forward before this one: its probes are read with this one already queued
+        return res
+
+    def drain(self) -> None:
+        """Settle the range guard of every forward submitted so far (waits for them)."""
+        for c in self.caps:
+            c.finish_range_guard()
+
+    @property
+    def last_range(self):
+        """The guard's verdict on the most recently submitted forward (settles it first)."""
+        return self.caps[(self.k + 1) & 1].last_range if self.k else None

@@ -130,6 +130,44 @@ def test_captured_forward_carries_the_fp16_range_guard():
         assert cap.last_range["fallback"] and torch.equal(out3, want)
 
 
+
+def test_pipelined_forward_settles_the_previous_forward_after_launching_the_next():
+    """cdfo_amd.graph.PipelinedForward: two alternating graphs; submit(k + 1) launches first and reads forward k's probes afterwards.
+    Every result -- ordinary operands, operands the guard rejects (repaired in bf16x3 into the tensors submit returned), ordinary
+    again -- equals the eager, guarded forward bit for bit once the next submit / drain has returned."""
+    m = _model(26)
+    d, n = _inputs(1, 16, 24, 550)
+    d2, n2 = _inputs(1, 16, 24, 551)
+    rest = (d["mvs0"], d["mvs1"], d["pms"], d["rms"], d["ufs"])
+    rest2 = (d2["mvs0"], d2["mvs1"], d2["pms"], d2["rms"], d2["ufs"])
+    xs = d["x"] * 2.0 ** 13
+    seq = [(d["x"], rest, n), (xs, rest, n), (d2["x"], rest2, n2), (d["x"], rest, n), (xs, rest, n)]
+    import warnings
+    with torch.no_grad():
+        pipe = m.capture_pipelined(d["x"], *rest, gumbel_uniform=n)
+        assert pipe.guarded
+        want = []
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            for x, r, nn in seq:
+                o, l1 = m(x, *r, gumbel_uniform=nn)
+                m.finish_range_guard()
+                want.append((o.clone(), l1.clone(), bool(m.last_range["fallback"])))
+        assert [w[2] for w in want] == [False, True, False, False, True], "scenario drifted"
+        m._warned_range = False
+        held = []
+        with pytest.warns(UserWarning, match="fp16 range"):
+            for k, (x, r, nn) in enumerate(seq):
+                held.append(pipe.submit(x, *r, gumbel_uniform=nn))
+                if k:       # the PREVIOUS result is final now (and not yet overwritten: that happens at the submit after this one)
+                    torch.cuda.synchronize()
+                    assert torch.equal(held[k - 1][0], want[k - 1][0]) and torch.equal(held[k - 1][1], want[k - 1][1])
+            pipe.drain()
+        torch.cuda.synchronize()
+        assert pipe.last_range["fallback"]
+        assert torch.equal(held[-1][0], want[-1][0]) and torch.equal(held[-1][1], want[-1][1])
+
+
 def test_v7_replay_with_injected_noise_matches_eager():
     """`CVSR_V7.capture` (round 5): the ~1 000 launches of a V7 forward (three pyramid levels x twelve neighbour pipelines on side
     streams) replayed from one HIP graph give the eager forward's result on the captured and on new operands."""

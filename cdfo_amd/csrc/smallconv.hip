@@ -197,6 +197,118 @@ __global__ __launch_bounds__(256) void udsa_head_kernel(const float* __restrict_
   }
 }
 
+// Round 5: the same convolutions with FOUR output pixels per thread.  The kernel above reads one f32x4 of weights from LDS per four
+// multiply-adds (144 ds_read_b128 per output quad at nine taps): it is bound by the LDS pipe, 4x above its HBM time.  Here a wave owns
+// 64 cells of one output row -- of one output PHASE for the stride-2 transposed form, so that the tap set (1, 2 or 4 of the 9) is the
+// same for every cell -- and lane (g, cg) computes output channels 4 cg .. + 3 of cells g, g + 16, g + 32, g + 48: every weight
+// vector read from LDS feeds sixteen multiply-adds, a store instruction covers sixteen consecutive pixels (1 KiB fp32, 512 B of an
+// fp16 plane).  Row and tap-parity tests are wave-uniform (scalar branches); a cell outside the row or a tap outside the image loads
+// from a clamped address and is zeroed by a select.  stride 1 or 2.
+template <bool TRANSPOSED>
+__global__ __launch_bounds__(256) void small_conv16_px4_kernel(const float* __restrict__ in, int ldi, const float* __restrict__ w,
+                                                               const float* __restrict__ bias, int B, int H, int W, int Ho, int Wo,
+                                                               int stride, int pad, int act, float* __restrict__ out, int ldo,
+                                                               _Float16* __restrict__ out_hl) {
+  constexpr int CIN = 16, COUT = 16;
+  __shared__ __attribute__((aligned(16))) float sw[9 * CIN * COUT];
+  for (int i = threadIdx.x; i < 9 * CIN * COUT; i += blockDim.x) {
+    const int co = i % COUT, ci = (i / COUT) % CIN, t = i / (COUT * CIN);
+    sw[i] = TRANSPOSED ? w[(ci * COUT + co) * 9 + t] : w[(co * CIN + ci) * 9 + t];
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63, g = lane >> 2, cg = lane & 3;
+  const bool ph2 = TRANSPOSED && stride == 2;
+  const int Hr = ph2 ? (Ho + 1) >> 1 : Ho, Wr = ph2 ? (Wo + 1) >> 1 : Wo, nph = ph2 ? 4 : 1;
+  const int wpr = (Wr + 63) >> 6;
+  const long long nwu = (long long)B * nph * Hr * wpr;
+  const f32x4 b4 = bias ? *reinterpret_cast<const f32x4*>(bias + cg * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+  for (long long wu = (long long)blockIdx.x * 4 + (threadIdx.x >> 6); wu < nwu; wu += (long long)gridDim.x * 4) {
+    const int xw = (int)(wu % wpr);
+    long long t = wu / wpr;
+    const int cy = (int)(t % Hr);
+    t /= Hr;
+    const int ph = (int)(t % nph);
+    const long long b = t / nph;
+    const int phy = ph >> 1, phx = ph & 1;
+    const int oy = ph2 ? 2 * cy + phy : cy;
+    if (oy >= Ho) continue;
+    const int ncell = ph2 ? (Wo - phx + 1) >> 1 : Wo;
+    const int cx0 = xw * 64 + g;                      // cells cx0 + 16 j, j = 0 .. 3
+    const int ox0 = ph2 ? 2 * cx0 + phx : cx0, oxs = ph2 ? 32 : 16;     // output column of cell j: ox0 + oxs * j
+    f32x4 acc[4] = {b4, b4, b4, b4};
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+      int iy;
+      if (TRANSPOSED) {                               // oy = iy * stride - pad + ky
+        const int num = oy + pad - ky;
+        if (num < 0 || (stride == 2 && (num & 1))) continue;
+        iy = stride == 2 ? num >> 1 : num;
+      } else {
+        iy = oy * stride - pad + ky;
+      }
+      if (iy < 0 || iy >= H) continue;
+      const float* irow = in + (b * H + iy) * (long long)W * ldi;
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) {
+        int ix0, ixs;                                 // input column of cell j: ix0 + ixs * j
+        if (TRANSPOSED) {
+          const int num = ox0 + pad - kx;             // (its parity is the phase's: the same in every cell of the wave)
+          if (stride == 2 && ((phx + pad - kx) & 1)) continue;
+          ix0 = stride == 2 ? num >> 1 : num;
+          ixs = 16;
+        } else {
+          ix0 = ox0 * stride - pad + kx;
+          ixs = 16 * stride;
+        }
+        const float* ip[4];
+        bool ok[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int ix = ix0 + ixs * j;
+          ok[j] = ix >= 0 && ix < W && cx0 + 16 * j < ncell;
+          ip[j] = irow + (long long)(ok[j] ? ix : 0) * ldi;
+        }
+        const float* wp = sw + (ky * 3 + kx) * CIN * COUT + cg * 4;
+#pragma unroll
+        for (int c4 = 0; c4 < CIN / 4; ++c4) {
+          f32x4 v[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            v[j] = *reinterpret_cast<const f32x4*>(ip[j] + c4 * 4);
+            if (!ok[j]) v[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+          }
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const f32x4 wv = *reinterpret_cast<const f32x4*>(wp + (c4 * 4 + e) * COUT);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[j] += v[j][e] * wv;
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      if (cx0 + 16 * j >= ncell) continue;
+      const long long p = (b * Ho + oy) * Wo + ox0 + oxs * j;
+      f32x4 a4 = acc[j];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) a4[e] = act_apply(a4[e], act);
+      if (out_hl) {        // fp16 hi | lo planes, chunk-planar [B][2][Ho*Wo][16]: the split-fp16 source of cdfo_conv3x3_ring
+        typedef _Float16 f16x4_t __attribute__((ext_vector_type(4)));
+        f16x4_t hi, lo;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { hi[e] = (_Float16)a4[e]; lo[e] = (_Float16)(a4[e] - (float)hi[e]); }
+        const long long P = (long long)Ho * Wo, pix = p - b * P;
+        _Float16* o16 = out_hl + ((b * 2) * P + pix) * 16 + cg * 4;
+        *reinterpret_cast<f16x4_t*>(o16) = hi;
+        *reinterpret_cast<f16x4_t*>(o16 + P * 16) = lo;
+      } else {
+        *reinterpret_cast<f32x4*>(out + p * ldo + cg * 4) = a4;
+      }
+    }
+  }
+}
+
 }  // namespace
 
 static int small_conv16_launch(const float* in, int ldi, const float* w, const float* bias, int B, int H, int W, int stride,
@@ -217,6 +329,18 @@ static int small_conv16_launch(const float* in, int ldi, const float* w, const f
   hipStream_t st = static_cast<hipStream_t>(stream);
   CdfoProfScope prof(static_cast<hipStream_t>(stream), KID_SMALL_CONV, 2.0*9*256*(double)B*Ho*Wo, 4.0*16*((double)B*Ho*Wo+(double)B*H*W));
   _Float16* hl = static_cast<_Float16*>(out_hl);
+  // four output pixels per thread (round 5) for the transposed forms: 70x122 -> 137x241 0.162 -> 0.099 ms, 137x241 -> 272x480 (hi | lo
+  // planes) 0.471 -> 0.309 ms at 56 frames; the plain stride-2 convolutions gain nothing from it (0.268 -> 0.297, 0.095 -> 0.083 ms:
+  // they are bound by their nine strided input reads per output, not by the weight reads) and stay on the one-pixel kernel
+  if (transposed && stride <= 2) {
+    const bool ph2 = transposed && stride == 2;
+    const long long waves = (long long)B * (ph2 ? 4 : 1) * (ph2 ? (Ho + 1) / 2 : Ho) * (((ph2 ? (Wo + 1) / 2 : Wo) + 63) / 64);
+    const int g4 = grid_for(waves * 64);
+    hipLaunchKernelGGL(small_conv16_px4_kernel<true>, dim3(g4), dim3(256), 0, st, in, ldi, w, bias, B, H, W, Ho, Wo, stride, pad, act,
+                       out, ldo, hl);
+    CDFO_LAUNCH_CHECK();
+    return 0;
+  }
   if (transposed)
     hipLaunchKernelGGL((small_conv3x3_kernel<16, 16, true>), dim3(grid), dim3(256), 0, st, in, ldi, w, bias, B, H, W, Ho,
                        Wo, stride, pad, act, out, ldo, hl);

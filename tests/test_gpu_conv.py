@@ -743,3 +743,34 @@ def test_conv3x3_c64_wino_up2(Cout, h, w, B, act):
     err = (got - ref).abs().max().item()
     scale = ref.abs().max().item()
     assert err <= 2.5e-3 * max(1.0, scale), f"wino up2: max-abs {err} (ref scale {scale})"
+
+
+@pytest.mark.parametrize("B,H,W,stride,out_pad,hl", [
+    (2, 6, 6, 2, 0, False), (3, 9, 70, 2, 1, False), (2, 35, 61, 2, 0, True), (1, 70, 122, 2, 0, False), (2, 137, 241, 2, 1, True),
+    (2, 5, 130, 2, 1, False), (2, 7, 9, 1, 0, False)])
+def test_small_conv16_transposed_four_pixels_per_thread(B, H, W, stride, out_pad, hl):
+    """The prior U-net's transposed 16 -> 16 convolutions (arch/SIDECVSR_our.py:1827-1830) on the four-pixels-per-thread kernel
+    (phase-major rows, odd and even output sizes, rows longer and shorter than a wave's 64 cells, the fp16 hi | lo plane output,
+    and the stride-1 form the backward of a plain convolution uses) against torch conv_transpose2d in float64."""
+    from cdfo_amd import kernels as K
+    g = torch.Generator().manual_seed(B * 1000 + H * 10 + W)
+    x = torch.randn(B, 16, H, W, generator=g)
+    w = torch.randn(16, 16, 3, 3, generator=g) / 6
+    b = torch.randn(16, generator=g)
+    pad = 2 if stride == 2 else 1
+    ref = F.leaky_relu(F.conv_transpose2d(x.double(), w.double(), b.double(), stride=stride, padding=pad, output_padding=out_pad), 0.1).float()
+    xg = _nhwc(x).cuda()
+    got = K.small_conv16(xg, w.cuda(), b.cuda(), stride, pad, out_pad, True, K.ACT_LRELU, out_hl=hl)
+    torch.cuda.synchronize()
+    Ho, Wo = ref.shape[2], ref.shape[3]
+    if hl:      # [B][2][Ho*Wo][16] fp16 hi | lo planes
+        assert got.dtype == torch.float16
+        pl = got.float().cpu().reshape(B, 2, Ho, Wo, 16)
+        val = (pl[:, 0] + pl[:, 1]).permute(0, 3, 1, 2)
+        tol = 5e-6 * max(1.0, ref.abs().max().item()) + 1e-6       # hi + lo carries ~22 bits
+    else:
+        val = got.cpu().permute(0, 3, 1, 2)
+        tol = 5e-6 * max(1.0, ref.abs().max().item())
+    assert tuple(val.shape) == tuple(ref.shape)
+    err = (val - ref).abs().max().item()
+    assert err <= tol, f"transposed small conv: {err} > {tol}"

@@ -282,7 +282,12 @@ __global__ __launch_bounds__(WN_THREADS) void conv3x3_c64_wino_kernel(wino_args 
     const auto s0 = __builtin_amdgcn_permlane16_swap(x[0], y[0], false, false);
     const auto s1 = __builtin_amdgcn_permlane16_swap(x[1], y[1], false, false);
     const u32x4 v = {s0[0], s1[0], s0[1], s1[1]};
-    if (!(DBG & 4)) __builtin_amdgcn_raw_buffer_store_b128(v, ro, (int)vo, so, 0);
+    // Non-temporal stores for the plain (1x resolution) form: measured 0.221 -> 0.192 ms at 8 x 272x480, 0.034 -> 0.032 at one clip,
+    // forward 104.52 / 104.27 -> 104.28 / 103.91 ms (same box, alternating).  NOT for the space-to-depth form at eight clips of
+    // 544x960: 0.962 -> 1.040 ms (yet 0.465 -> 0.406 at one clip of 1088x1920: left alone).  dbg 2048 forces them, 8192 forbids them.
+    constexpr bool NT = (DBG & 2048) || (!S2D && !UP && !(DBG & 8192));
+    if (DBG & 4096) __builtin_amdgcn_raw_buffer_store_b128(v, ro, (int)vo, so, 1);        // experiment: sc0
+    else if (!(DBG & 4)) __builtin_amdgcn_raw_buffer_store_b128(v, ro, (int)vo, so, NT ? 2 : 0);
     else if (v[0] == 0x12345678u && v[3] == 0x9abcdef0u) __builtin_amdgcn_raw_buffer_store_b128(v, ro, (int)vo, so, 0);
     // HAZARD (measured, gfx950): a vector instruction that overwrites a data register of a 128-bit buffer store within two wait states of
     // it reaches the store in some lanes.  hipcc pads that case only for stores WITHOUT a scalar offset register (it takes the offset's
@@ -649,6 +654,9 @@ extern "C" int cdfo_conv3x3_c64_wino_dbg(const void* src_cp16, int B, int H, int
     case 512: rc = wino_launch<512>(a, nslots * 8, st); break;
     case 1024: rc = wino_launch<1024>(a, nslots * 8, st); break;
     case 1536: rc = wino_launch<1536>(a, nslots * 8, st); break;
+    case 2048: rc = wino_launch<2048>(a, nslots * 8, st); break;
+    case 4096: rc = wino_launch<4096>(a, nslots * 8, st); break;
+    case 8192: rc = wino_launch<8192>(a, nslots * 8, st); break;
     default: return CDFO_EINVAL;
   }
   if (rc) return rc;

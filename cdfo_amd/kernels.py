@@ -415,7 +415,8 @@ def conv3x3_body0(src: torch.Tensor, pc: PackedConv, *, act: int = ACT_NONE, s2d
     even width, one image of source / result below 2 GiB, CDFO_WINO != 0), the direct weights-stationary kernel otherwise."""
     _, _, H, W, _ = src.shape
     if pc.ww is not None and wino_enabled() and W % 2 == 0 and (not s2d or H % 2 == 0) and H * W * 2 * pc.Cout < (1 << 31):
-        return conv3x3_wino(src, pc, act=act, s2d=s2d)
+        plain_st = (not s2d) and os.environ.get("CDFO_WINO_NT", "1") == "0"    # developer A/B: the 1x launches WITHOUT non-temporal stores
+        return conv3x3_wino(src, pc, act=act, s2d=s2d, dbg=8192 if plain_st else 0)
     return conv3x3_ws(src, pc, act=act, s2d=s2d)
 
 

@@ -283,8 +283,9 @@ __global__ __launch_bounds__(WN_THREADS) void conv3x3_c64_wino_kernel(wino_args 
     const auto s1 = __builtin_amdgcn_permlane16_swap(x[1], y[1], false, false);
     const u32x4 v = {s0[0], s1[0], s0[1], s1[1]};
     // Non-temporal stores for the plain (1x resolution) form: measured 0.221 -> 0.192 ms at 8 x 272x480, 0.034 -> 0.032 at one clip,
-    // forward 104.52 / 104.27 -> 104.28 / 103.91 ms (same box, alternating).  NOT for the space-to-depth form at eight clips of
-    // 544x960: 0.962 -> 1.040 ms (yet 0.465 -> 0.406 at one clip of 1088x1920: left alone).  dbg 2048 forces them, 8192 forbids them.
+    // forward 104.52 / 104.27 -> 104.28 / 103.91 ms (same box, alternating).  The space-to-depth form from a materialised x2 source
+    // measured 0.962 -> 1.040 ms stand-alone at eight clips of 544x960 (0.465 -> 0.406 at one clip of 1088x1920) and is left alone;
+    // the UP form is launched with dbg 2048 (wino_launch_up).  dbg 2048 forces them, 8192 forbids them.
     constexpr bool NT = (DBG & 2048) || (!S2D && !UP && !(DBG & 8192));
     if (DBG & 4096) __builtin_amdgcn_raw_buffer_store_b128(v, ro, (int)vo, so, 1);        // experiment: sc0
     else if (!(DBG & 4)) __builtin_amdgcn_raw_buffer_store_b128(v, ro, (int)vo, so, NT ? 2 : 0);
@@ -572,9 +573,11 @@ extern "C" int cdfo_pack_conv3x3_wino(const float* w_oihw, void* packed, int Cou
 namespace {
 int wino_launch_up(const wino_args& a, int grid, hipStream_t st) {
   static CdfoAttrOnce once;
-  const hipError_t e = cdfo_set_max_lds(once, reinterpret_cast<const void*>(conv3x3_c64_wino_kernel<true, 0, true>), WN_LDS_UP);
+  // (dbg 2048 = non-temporal stores: the 2.1 GB intermediate of the x2 branch is read back once, by a kernel that starts after this one
+  // has finished; same-box A/B of the forward 104.65 / 104.54 -> 103.98 / 104.11 ms)
+  const hipError_t e = cdfo_set_max_lds(once, reinterpret_cast<const void*>(conv3x3_c64_wino_kernel<true, 2048, true>), WN_LDS_UP);
   if (e != hipSuccess) return (int)e;
-  hipLaunchKernelGGL((conv3x3_c64_wino_kernel<true, 0, true>), dim3(grid), dim3(WN_THREADS), WN_LDS_UP, st, a);
+  hipLaunchKernelGGL((conv3x3_c64_wino_kernel<true, 2048, true>), dim3(grid), dim3(WN_THREADS), WN_LDS_UP, st, a);
   return 0;
 }
 

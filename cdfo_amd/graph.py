@@ -79,7 +79,9 @@ class CapturedForward:
             self._probe_host = torch.zeros(4, dtype=torch.int32).pin_memory()
             self._ev = torch.cuda.Event()
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph), torch.no_grad():
+        # thread_local: only THIS thread's calls are checked against the capture -- a process group's watchdog thread (event queries
+        # while bench.py's ranks capture) must not invalidate it
+        with torch.cuda.graph(self.graph, capture_error_mode="thread_local"), torch.no_grad():
             if self.guarded:
                 model._graph_probe = self._probe
             try:

@@ -631,6 +631,14 @@ extern "C" int cdfo_conv3x3_c64_wino_dbg(const void* src_cp16, int B, int H, int
   const double px = (double)B * H * W;
   CdfoProfScope prof(st, KID_CONV3_WINO, 2.0 * px * Cout * 64 * 9, 2.0 * (px * Cout + px * 64) + 2.0 * 12 * 64 * Cout);
   int rc = 0;
+  if (dbg == -2) {       // developer timeline of the UP form (tools/wino_timeline.py --up): dbg 512 | 2048
+    static CdfoAttrOnce once_tl;
+    const hipError_t e = cdfo_set_max_lds(once_tl, reinterpret_cast<const void*>(conv3x3_c64_wino_kernel<true, 2560, true>), WN_LDS_UP);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL((conv3x3_c64_wino_kernel<true, 2560, true>), dim3(nslots * 8), dim3(WN_THREADS), WN_LDS_UP, st, a);
+    CDFO_LAUNCH_CHECK();
+    return 0;
+  }
   if (dbg == -1) {       // cdfo_conv3x3_c64_wino_up2
     rc = wino_launch_up(a, nslots * 8, st);
     if (rc) return rc;

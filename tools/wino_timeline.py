@@ -5,14 +5,23 @@ import torch
 from cdfo_amd import kernels as K
 
 B, H, W, s2d = 8, 544, 960, True
-x = torch.randn(B, H, W, 64, device="cuda")
+UP = "--up" in sys.argv            # the UP form: the same launch from the low-resolution source (bilinear x2 inside the input transform)
+argv = [a for a in sys.argv[1:] if a != "--up"]
 pc = K.pack_conv(torch.randn(256, 64, 3, 3, device="cuda") / 24.0, torch.randn(256, device="cuda"))
-src = K.to_cp16(x)
-out = K.conv3x3_wino(src, pc, act=1, s2d=s2d)
 clk = torch.zeros(256 * 8 * 8, dtype=torch.int64, device="cuda")
-DBG = int(sys.argv[1]) if len(sys.argv) > 1 else 512
-for _ in range(3):
-    K.conv3x3_wino(src, pc, act=1, s2d=s2d, out=out, dbg=DBG, clk=clk)
+DBG = int(argv[0]) if argv else 512
+if UP:
+    from cdfo_amd import _lib
+    src = K.to_cp16(torch.randn(B, H // 2, W // 2, 64, device="cuda"))
+    out = K.conv3x3_wino_up2(src, pc, act=1)
+    for _ in range(3):
+        K.check(_lib.lib().cdfo_conv3x3_c64_wino_dbg(K._vp(src), B, H, W, K._vp(pc.ww), K._vp(pc.bias), pc.Cout, 1, K._vp(out), 2, -2,
+                                                     K._vp(clk), K._stream()), "cdfo_conv3x3_c64_wino_dbg")
+else:
+    src = K.to_cp16(torch.randn(B, H, W, 64, device="cuda"))
+    out = K.conv3x3_wino(src, pc, act=1, s2d=s2d)
+    for _ in range(3):
+        K.conv3x3_wino(src, pc, act=1, s2d=s2d, out=out, dbg=DBG, clk=clk)
 torch.cuda.synchronize()
 c = clk.view(256, 8, 8).cpu().double()
 ok = c[:, :, 7] > 0

@@ -91,6 +91,10 @@ __global__ __launch_bounds__(256) void dcn_win_pack_kernel(const float* __restri
 __device__ __forceinline__ float wn_bload(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
   return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)voff, (int)soff, 0));
 }
+// (offsets and masks are read exactly once per launch, 1.8 GB beside a 267 MB input whose windows neighbouring tiles re-read from L2)
+__device__ __forceinline__ float wn_bload_nt(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)voff, (int)soff, 2));
+}
 __device__ __forceinline__ f32x4 wn_bload4(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
   typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
   return __builtin_bit_cast(f32x4, (u32x4)__builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, 0));
@@ -223,9 +227,9 @@ __global__ __launch_bounds__(WN_THREADS) void dcn_win_kernel(WinArgs a) {
     vo_msk = (unsigned)(d * WN_T * P + p) * 4u;
   };
   auto load_tap = [&](unsigned vo_off, unsigned vo_msk, int t, float& o_h, float& o_w, float& m_k) {
-    o_h = wn_bload(r_off, vo_off, (unsigned)(2 * t * P) * 4u);
-    o_w = wn_bload(r_off, vo_off, (unsigned)((2 * t + 1) * P) * 4u);
-    m_k = MASK ? wn_bload(r_msk, vo_msk, (unsigned)(t * P) * 4u) : 1.f;
+    o_h = wn_bload_nt(r_off, vo_off, (unsigned)(2 * t * P) * 4u);
+    o_w = wn_bload_nt(r_off, vo_off, (unsigned)((2 * t + 1) * P) * 4u);
+    m_k = MASK ? wn_bload_nt(r_msk, vo_msk, (unsigned)(t * P) * 4u) : 1.f;
   };
 
   f32x16 acc[MJ];
